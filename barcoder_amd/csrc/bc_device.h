@@ -1,0 +1,62 @@
+// bc_device.h — device-side library object and launch helpers (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "bc_common.h"
+
+#define BC_HIP(call)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            bc::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                          __LINE__);                                                    \
+            return BC_EHIP;                                                             \
+        }                                                                               \
+    } while (0)
+
+namespace bc {
+
+constexpr int MAX_SEG = 4;      // max_mismatch <= 3 -> up to 4 pigeonhole segments
+constexpr int BLOCK = 256;      // 4 waves of 64
+constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 resident blocks: grid-stride beyond
+
+// hash of a packed k-mer, identical on host (table build) and device (lookup)
+BC_HD static inline uint32_t hash32(uint64_t key) {
+    uint32_t x = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu);
+    x ^= x >> 15;
+    return x * 0x9E3779B1u;
+}
+
+// One pigeonhole seed index (for one value of max_mismatch): the k-mer is cut
+// into nseg = d+1 disjoint segments; the first seed_len bases of segment s key a
+// CSR bucket table.  A guide within d substitutions of a read agrees with it
+// exactly on at least one segment, hence on that segment's seed.
+struct SeedParams {
+    int nseg;
+    int start[MAX_SEG];  // first base of the seed
+    int slen[MAX_SEG];   // seed length in bases
+    const uint32_t* off[MAX_SEG];   // [4^slen + 1] bucket offsets
+    const uint64_t* keys[MAX_SEG];  // [G] guides grouped by bucket, guide index ascending
+    const uint32_t* gidx[MAX_SEG];  // [G] guide index of each entry
+};
+
+}  // namespace bc
+
+struct bc_lib {
+    int device = 0;
+    uint32_t G = 0;
+    int k = 0;
+    uint64_t kmask = 0;
+    std::vector<uint64_t> h_guides;
+    uint64_t* d_guides = nullptr;  // [G] original order (also the brute-force tile source)
+    // exact-match open-addressing table
+    int log_slots = 0;
+    bool wide = false;             // true: 32-bit index slots + verify against d_guides
+    uint64_t* d_slots64 = nullptr;
+    uint32_t* d_slots32 = nullptr;
+    // seed indices, entry d for max_mismatch = d
+    bc::SeedParams seed[bc::MAX_SEG];
+    std::vector<void*> owned;      // every device allocation, for destroy
+};

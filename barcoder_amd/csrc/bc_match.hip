@@ -1,0 +1,665 @@
+// bc_match.hip — read -> library matching on gfx950 (K2 exact, K3 Hamming, K5
+// per-guide histogram).  Integer / byte kernels: no MFMA.
+//
+// Replaces the per-read body of heuristicount.py:428-562 (process_chunk: set
+// lookup + Counter update) and generalises it to <= d substitutions, which the
+// reference can only obtain from `bowtie -v N` (targets.py:496-509).
+//
+// Three algorithms over the same inputs / outputs:
+//   k_match_hash  : d = 0.  One open-addressing probe sequence per read into a
+//                   table that stays L2-resident (1e5 guides -> 2 MiB).
+//   k_match_seed  : d <= 3. Pigeonhole seed index: d+1 CSR bucket tables in L2;
+//                   every candidate is verified with XOR + popcount.
+//   k_match_brute : any d.  Guide table tiled through LDS, lane = read, all
+//                   pairs XOR + popcount.  VALU-bound; the in-GPU cross-check.
+#include "bc_device.h"
+
+using namespace bc;
+
+namespace {
+
+struct MatchOut {
+    int32_t* best_idx;
+    uint8_t* best_dist;
+    uint8_t* n_best;
+    uint32_t* counts;
+    uint64_t* first_seen;
+    uint64_t base;
+};
+
+__device__ __forceinline__ bool read_skipped(uint64_t r, const uint8_t* flags, uint64_t i, int k) {
+    bool s = (k <= 31) && (r >> 63);
+    if (flags) s = s || (flags[i] != 0);
+    return s;
+}
+
+__device__ __forceinline__ void tally(const MatchOut& o, uint64_t i, int32_t idx) {
+    if (idx < 0) return;
+    if (o.counts) atomicAdd(&o.counts[idx], 1u);
+    if (o.first_seen) {
+        unsigned long long v = o.base + i;
+        // a stale (cached) value can only be larger than the true one, so the
+        // plain pre-check never drops a needed update
+        if (v < o.first_seen[idx]) atomicMin((unsigned long long*)&o.first_seen[idx], v);
+    }
+}
+
+__device__ __forceinline__ void emit(const MatchOut& o, uint64_t i, int32_t idx, uint32_t dist,
+                                     uint32_t nb) {
+    o.best_idx[i] = idx;
+    if (o.best_dist) o.best_dist[i] = (uint8_t)dist;
+    if (o.n_best) o.n_best[i] = (uint8_t)(nb > 255u ? 255u : nb);
+    tally(o, i, idx);
+}
+
+// ---------------------------------------------------------------------------
+// K2: exact match.  slot layout (narrow): key bits in place (kmask), guide
+// index + 1 spread over the free bits above k in both 32-bit halves; 0 = empty.
+// wide (k too long for that): slot = index + 1, verified against guides[].
+// ---------------------------------------------------------------------------
+template <bool WIDE>
+__device__ __forceinline__ int32_t hash_lookup(uint64_t key, const uint64_t* __restrict__ s64,
+                                               const uint32_t* __restrict__ s32,
+                                               const uint64_t* __restrict__ guides, int k,
+                                               int log_slots, uint64_t kmask) {
+    const uint32_t smask = (1u << log_slots) - 1u;
+    uint32_t h = hash32(key) >> (32 - log_slots);
+    for (uint32_t probe = 0; probe <= smask; ++probe) {
+        if (WIDE) {
+            uint32_t s = s32[h];
+            if (s == 0) return BC_IDX_MISS;
+            if (guides[s - 1] == key) return (int32_t)(s - 1);
+        } else {
+            uint64_t s = s64[h];
+            if (s == 0) return BC_IDX_MISS;
+            if ((s & kmask) == key) {
+                uint32_t lo = (uint32_t)s >> k, hi = (uint32_t)(s >> 32) >> k;
+                return (int32_t)((lo | (hi << (32 - k))) - 1u);
+            }
+        }
+        h = (h + 1) & smask;
+    }
+    return BC_IDX_MISS;
+}
+
+template <bool WIDE, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict__ reads,
+                                                      const uint8_t* __restrict__ flags, uint64_t n,
+                                                      const uint64_t* __restrict__ s64,
+                                                      const uint32_t* __restrict__ s32,
+                                                      const uint64_t* __restrict__ guides, int k,
+                                                      int log_slots, uint64_t kmask, MatchOut o) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    const uint64_t ngroups = n / VEC;
+    for (uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
+        uint64_t r[VEC];
+        if constexpr (VEC == 4) {
+            const ulonglong2* p = reinterpret_cast<const ulonglong2*>(reads) + g * 2;
+            ulonglong2 a = p[0], b = p[1];
+            r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+        } else {
+            r[0] = reads[g];
+        }
+        int32_t idx[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            uint64_t i = g * VEC + j;
+            if (read_skipped(r[j], flags, i, k)) idx[j] = BC_IDX_SKIP;
+            else idx[j] = hash_lookup<WIDE>(r[j] & kmask, s64, s32, guides, k, log_slots, kmask);
+        }
+        if constexpr (VEC == 4) {
+            reinterpret_cast<int4*>(o.best_idx)[g] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            if (o.best_dist) {
+                uchar4 d;
+                d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
+                d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
+                reinterpret_cast<uchar4*>(o.best_dist)[g] = d;
+            }
+            if (o.n_best) {
+                uchar4 d;
+                d.x = idx[0] >= 0; d.y = idx[1] >= 0; d.z = idx[2] >= 0; d.w = idx[3] >= 0;
+                reinterpret_cast<uchar4*>(o.n_best)[g] = d;
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) tally(o, g * VEC + j, idx[j]);
+        } else {
+            emit(o, g, idx[0], idx[0] >= 0 ? 0u : (uint32_t)BC_DIST_NONE, idx[0] >= 0 ? 1u : 0u);
+        }
+    }
+    // tail (n % VEC reads) by the first threads of block 0
+    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < (n % VEC)) {
+        uint64_t i = ngroups * VEC + threadIdx.x;
+        uint64_t r = reads[i];
+        int32_t idx = read_skipped(r, flags, i, k)
+                          ? BC_IDX_SKIP
+                          : hash_lookup<WIDE>(r & kmask, s64, s32, guides, k, log_slots, kmask);
+        emit(o, i, idx, idx >= 0 ? 0u : (uint32_t)BC_DIST_NONE, idx >= 0 ? 1u : 0u);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3a: pigeonhole seed index.  lane = read.
+// ---------------------------------------------------------------------------
+struct Best {
+    int32_t idx;
+    uint32_t dist, nb, cur;  // cur = min(dist, max_mm): acceptance threshold
+};
+
+__device__ __forceinline__ void consider(Best& b, uint32_t d, uint32_t gi) {
+    if (d < b.dist) {
+        b.dist = d; b.idx = (int32_t)gi; b.nb = 1; b.cur = d;
+    } else {  // d == b.dist (d <= cur <= dist)
+        b.nb++;
+        if ((int32_t)gi < b.idx) b.idx = (int32_t)gi;
+    }
+}
+
+__device__ __forceinline__ uint32_t seed_value(uint32_t lo, uint32_t hi, int start, int slen) {
+    uint32_t m = (1u << slen) - 1u;
+    return ((lo >> start) & m) | (((hi >> start) & m) << slen);
+}
+
+// true when the candidate was already enumerated through an earlier seed
+__device__ __forceinline__ bool seen_earlier(const SeedParams& sp, int s, uint32_t mm) {
+    bool seen = false;
+    for (int t = 0; t < s; ++t) seen = seen || (((mm >> sp.start[t]) & ((1u << sp.slen[t]) - 1u)) == 0u);
+    return seen;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_match_seed(SeedParams sp, const uint64_t* __restrict__ reads,
+                                                      const uint8_t* __restrict__ flags, uint64_t n,
+                                                      int k, uint64_t kmask, int max_mm, MatchOut o) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        uint64_t r = reads[i];
+        if (read_skipped(r, flags, i, k)) {
+            emit(o, i, BC_IDX_SKIP, BC_DIST_NONE, 0);
+            continue;
+        }
+        r &= kmask;
+        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+        Best b{BC_IDX_MISS, BC_DIST_NONE, 0u, (uint32_t)max_mm};
+        for (int s = 0; s < sp.nseg; ++s) {
+            uint32_t sv = seed_value(rlo, rhi, sp.start[s], sp.slen[s]);
+            uint32_t j = sp.off[s][sv], e = sp.off[s][sv + 1];
+            const uint64_t* __restrict__ keys = sp.keys[s];
+            for (; j < e; ++j) {
+                uint64_t g = keys[j];
+                uint32_t mm = (rlo ^ (uint32_t)g) | (rhi ^ (uint32_t)(g >> 32));
+                uint32_t d = __popc(mm);
+                if (d <= b.cur && !seen_earlier(sp, s, mm)) consider(b, d, sp.gidx[s][j]);
+            }
+        }
+        emit(o, i, b.idx, b.dist, b.nb);
+    }
+}
+
+// all hits: one record per (query, guide) pair within max_mm
+__global__ __launch_bounds__(BLOCK) void k_match_all(SeedParams sp, const uint64_t* __restrict__ reads,
+                                                     const uint8_t* __restrict__ flags, uint64_t n,
+                                                     int k, uint64_t kmask, int max_mm,
+                                                     bc_hit* __restrict__ hits, uint64_t cap,
+                                                     unsigned long long* n_hits) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        uint64_t r = reads[i];
+        if (read_skipped(r, flags, i, k)) continue;
+        r &= kmask;
+        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+        for (int s = 0; s < sp.nseg; ++s) {
+            uint32_t sv = seed_value(rlo, rhi, sp.start[s], sp.slen[s]);
+            uint32_t j = sp.off[s][sv], e = sp.off[s][sv + 1];
+            for (; j < e; ++j) {
+                uint64_t g = sp.keys[s][j];
+                uint32_t mm = (rlo ^ (uint32_t)g) | (rhi ^ (uint32_t)(g >> 32));
+                uint32_t d = __popc(mm);
+                if (d <= (uint32_t)max_mm && !seen_earlier(sp, s, mm)) {
+                    unsigned long long at = atomicAdd(n_hits, 1ULL);
+                    if (at < cap) {
+                        bc_hit h;
+                        h.query = (uint32_t)i; h.guide = sp.gidx[s][j]; h.dist = d;
+                        hits[at] = h;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3b: brute force.  Guide tile in LDS (broadcast reads), RPT reads per lane
+// held in registers, 5 VALU per pair (xor, xor, or, bcnt, cmp).
+// ---------------------------------------------------------------------------
+constexpr int BRUTE_TILE = 2048;  // guides per LDS tile (16 KiB)
+constexpr int BRUTE_RPT = 4;      // reads per thread
+
+__global__ __launch_bounds__(BLOCK) void k_match_brute(const uint64_t* __restrict__ guides, uint32_t G,
+                                                       const uint64_t* __restrict__ reads,
+                                                       const uint8_t* __restrict__ flags, uint64_t n,
+                                                       int k, uint64_t kmask, int max_mm, MatchOut o) {
+    __shared__ uint64_t tile[BRUTE_TILE];
+    const uint64_t per_block = (uint64_t)BLOCK * BRUTE_RPT;
+    for (uint64_t blk0 = (uint64_t)blockIdx.x * per_block; blk0 < n; blk0 += (uint64_t)gridDim.x * per_block) {
+        uint32_t rlo[BRUTE_RPT], rhi[BRUTE_RPT];
+        bool live[BRUTE_RPT];
+        Best b[BRUTE_RPT];
+#pragma unroll
+        for (int q = 0; q < BRUTE_RPT; ++q) {
+            uint64_t i = blk0 + (uint64_t)q * BLOCK + threadIdx.x;
+            uint64_t r = (i < n) ? reads[i] : 0;
+            live[q] = (i < n) && !read_skipped(r, flags, i, k);
+            r &= kmask;
+            rlo[q] = (uint32_t)r; rhi[q] = (uint32_t)(r >> 32);
+            // a dead lane keeps cur = 0 and compares against an impossible word
+            b[q] = Best{BC_IDX_MISS, BC_DIST_NONE, 0u, live[q] ? (uint32_t)max_mm : 0u};
+            if (!live[q]) { rlo[q] = 0xFFFFFFFFu; rhi[q] = 0xFFFFFFFFu; }
+        }
+        for (uint32_t t0 = 0; t0 < G; t0 += BRUTE_TILE) {
+            uint32_t tn = min((uint32_t)BRUTE_TILE, G - t0);
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < tn; j += BLOCK) tile[j] = guides[t0 + j];
+            __syncthreads();
+            for (uint32_t j = 0; j < tn; ++j) {
+                uint64_t g = tile[j];
+                uint32_t glo = (uint32_t)g, ghi = (uint32_t)(g >> 32);
+#pragma unroll
+                for (int q = 0; q < BRUTE_RPT; ++q) {
+                    uint32_t d = __popc((rlo[q] ^ glo) | (rhi[q] ^ ghi));
+                    if (d <= b[q].cur && live[q]) consider(b[q], d, t0 + j);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BRUTE_RPT; ++q) {
+            uint64_t i = blk0 + (uint64_t)q * BLOCK + threadIdx.x;
+            if (i >= n) continue;
+            if (live[q]) emit(o, i, b[q].idx, b[q].dist, b[q].nb);
+            else emit(o, i, BC_IDX_SKIP, BC_DIST_NONE, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// synthetic reads (bench / tests)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_synth_reads(const uint64_t* __restrict__ guides, uint32_t G,
+                                                       int k, uint64_t seed, uint64_t first, uint64_t n,
+                                                       int mixture, uint64_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n; t += stride) {
+        uint64_t i = first + t;
+        uint64_t g = guides[synth_guide_index(seed, i, G)];
+        out[t] = synth_read(seed, i, g, k, mixture);
+    }
+}
+
+int grid_for(uint64_t work_items) {
+    uint64_t b = (work_items + BLOCK - 1) / BLOCK;
+    if (b < 1) b = 1;
+    if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+    return (int)b;
+}
+
+template <typename T>
+int dev_upload(bc_lib* lib, const std::vector<T>& h, T** d) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(h.size() * sizeof(T), 16);
+    BC_HIP(hipMalloc(&p, bytes));
+    lib->owned.push_back(p);
+    if (!h.empty()) BC_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *d = (T*)p;
+    return BC_OK;
+}
+
+int floor_log4(uint32_t g) {
+    int l = 0;
+    while (g >= 4) { g >>= 2; ++l; }
+    return l;
+}
+
+int build_seed_index(bc_lib* lib, int d) {
+    SeedParams& sp = lib->seed[d];
+    const int k = lib->k;
+    sp.nseg = std::min(d + 1, k);
+    int want = std::max(4, std::min(12, floor_log4(std::max(lib->G, 1u))));
+    int pos = 0;
+    for (int s = 0; s < sp.nseg; ++s) {
+        int seg = k / sp.nseg + (s < k % sp.nseg ? 1 : 0);
+        sp.start[s] = pos;
+        sp.slen[s] = std::min(seg, want);
+        pos += seg;
+    }
+    for (int s = 0; s < sp.nseg; ++s) {
+        const uint32_t nb = 1u << (2 * sp.slen[s]);
+        const uint32_t m = (1u << sp.slen[s]) - 1u;
+        std::vector<uint32_t> off(nb + 1, 0);
+        auto sv = [&](uint64_t g) {
+            uint32_t lo = (uint32_t)g, hi = (uint32_t)(g >> 32);
+            return ((lo >> sp.start[s]) & m) | (((hi >> sp.start[s]) & m) << sp.slen[s]);
+        };
+        for (uint32_t i = 0; i < lib->G; ++i) off[sv(lib->h_guides[i]) + 1]++;
+        for (uint32_t b = 0; b < nb; ++b) off[b + 1] += off[b];
+        std::vector<uint32_t> cur(off.begin(), off.end() - 1);
+        std::vector<uint64_t> keys(lib->G);
+        std::vector<uint32_t> gidx(lib->G);
+        for (uint32_t i = 0; i < lib->G; ++i) {  // ascending i -> ascending index inside a bucket
+            uint32_t at = cur[sv(lib->h_guides[i])]++;
+            keys[at] = lib->h_guides[i];
+            gidx[at] = i;
+        }
+        uint32_t* d_off; uint64_t* d_keys; uint32_t* d_gidx;
+        int rc;
+        if ((rc = dev_upload(lib, off, &d_off)) != BC_OK) return rc;
+        if ((rc = dev_upload(lib, keys, &d_keys)) != BC_OK) return rc;
+        if ((rc = dev_upload(lib, gidx, &d_gidx)) != BC_OK) return rc;
+        sp.off[s] = d_off; sp.keys[s] = d_keys; sp.gidx[s] = d_gidx;
+    }
+    return BC_OK;
+}
+
+int build_hash(bc_lib* lib) {
+    const int k = lib->k;
+    int ls = 4;
+    while ((1ull << ls) < (uint64_t)lib->G * 5 / 2 + 1) ++ls;
+    lib->log_slots = ls;
+    const uint32_t nslots = 1u << ls, smask = nslots - 1;
+    int free_bits = 2 * (32 - k);
+    lib->wide = !(free_bits >= 33 || ((uint64_t)lib->G + 1) < (1ull << free_bits));
+    if (k == 32) lib->wide = true;
+    if (lib->wide) {
+        std::vector<uint32_t> slots(nslots, 0);
+        for (uint32_t i = 0; i < lib->G; ++i) {
+            uint32_t h = hash32(lib->h_guides[i]) >> (32 - ls);
+            while (slots[h]) {
+                if (lib->h_guides[slots[h] - 1] == lib->h_guides[i]) {
+                    set_error("bc_lib_create: duplicate guide at index %u (first at %u)", i, slots[h] - 1);
+                    return BC_EINVAL;
+                }
+                h = (h + 1) & smask;
+            }
+            slots[h] = i + 1;
+        }
+        return dev_upload(lib, slots, &lib->d_slots32);
+    }
+    std::vector<uint64_t> slots(nslots, 0);
+    const uint32_t fm = (k >= 32) ? 0u : ((1u << (32 - k)) - 1u);
+    for (uint32_t i = 0; i < lib->G; ++i) {
+        uint64_t key = lib->h_guides[i];
+        uint32_t h = hash32(key) >> (32 - ls);
+        while (slots[h]) {
+            if ((slots[h] & lib->kmask) == key) {
+                set_error("bc_lib_create: duplicate guide at index %u", i);
+                return BC_EINVAL;
+            }
+            h = (h + 1) & smask;
+        }
+        uint32_t v = i + 1;
+        uint64_t lo = (uint64_t)(v & fm) << k;
+        uint64_t hi = (uint64_t)((v >> (32 - k)) & fm) << (32 + k);
+        slots[h] = key | lo | hi;
+    }
+    return dev_upload(lib, slots, &lib->d_slots64);
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
+                 int max_mm, int algo, const MatchOut& o, hipStream_t st) {
+    if (n == 0) return BC_OK;
+    if (algo == BC_ALGO_AUTO) algo = (max_mm == 0) ? BC_ALGO_HASH : BC_ALGO_SEED;
+    if (algo == BC_ALGO_HASH) {
+        if (max_mm != 0) {
+            set_error("bc_match: BC_ALGO_HASH requires max_mismatch == 0");
+            return BC_EINVAL;
+        }
+        bool vec = aligned16(d_reads) && aligned16(o.best_idx) &&
+                   (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
+                   (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0) && n >= 4;
+        if (vec) {
+            int grid = grid_for(n / 4);
+            if (lib->wide)
+                hipLaunchKernelGGL((k_match_hash<true, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
+                                   lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
+            else
+                hipLaunchKernelGGL((k_match_hash<false, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
+                                   lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
+        } else {
+            int grid = grid_for(n);
+            if (lib->wide)
+                hipLaunchKernelGGL((k_match_hash<true, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
+                                   lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
+            else
+                hipLaunchKernelGGL((k_match_hash<false, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
+                                   lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
+        }
+    } else if (algo == BC_ALGO_SEED) {
+        if (max_mm < 0 || max_mm >= MAX_SEG) {
+            set_error("bc_match: BC_ALGO_SEED supports 0 <= max_mismatch <= %d", MAX_SEG - 1);
+            return BC_EINVAL;
+        }
+        hipLaunchKernelGGL(k_match_seed, dim3(grid_for(n)), dim3(BLOCK), 0, st, lib->seed[max_mm], d_reads,
+                           d_flags, n, lib->k, lib->kmask, max_mm, o);
+    } else if (algo == BC_ALGO_BRUTE) {
+        if (max_mm < 0 || max_mm > lib->k) {
+            set_error("bc_match: bad max_mismatch %d", max_mm);
+            return BC_EINVAL;
+        }
+        uint64_t per_block = (uint64_t)BLOCK * BRUTE_RPT;
+        uint64_t blocks = (n + per_block - 1) / per_block;
+        if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+        hipLaunchKernelGGL(k_match_brute, dim3((int)blocks), dim3(BLOCK), 0, st, lib->d_guides, lib->G, d_reads,
+                           d_flags, n, lib->k, lib->kmask, max_mm, o);
+    } else {
+        set_error("bc_match: unknown algo %d", algo);
+        return BC_EINVAL;
+    }
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bc_device_count(int* n_out) {
+    if (!n_out) { set_error("bc_device_count: null"); return BC_EINVAL; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *n_out = 0; set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return BC_ENODEV; }
+    *n_out = n;
+    return BC_OK;
+}
+
+int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device, bc_lib** out) {
+    if (!out || (!h_guides && n_guides) || k < 1 || k > 32 || n_guides == 0) {
+        set_error("bc_lib_create: bad argument (G=%u k=%d)", n_guides, k);
+        return BC_EINVAL;
+    }
+    const uint64_t km = kmer_mask(k);
+    for (uint32_t i = 0; i < n_guides; ++i)
+        if (h_guides[i] & ~km) {
+            set_error("bc_lib_create: guide %u has bits outside a %d-mer (non-ACGT base?)", i, k);
+            return BC_EINVAL;
+        }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("bc_lib_create: no HIP device visible (the matcher has no CPU path)");
+        return BC_ENODEV;
+    }
+    if (device < 0 || device >= ndev) { set_error("bc_lib_create: device %d of %d", device, ndev); return BC_EINVAL; }
+    BC_HIP(hipSetDevice(device));
+    bc_lib* lib = new bc_lib();
+    lib->device = device; lib->G = n_guides; lib->k = k; lib->kmask = km;
+    lib->h_guides.assign(h_guides, h_guides + n_guides);
+    int rc = dev_upload(lib, lib->h_guides, &lib->d_guides);
+    if (rc == BC_OK) rc = build_hash(lib);
+    for (int d = 0; d < MAX_SEG && rc == BC_OK; ++d) rc = build_seed_index(lib, d);
+    if (rc != BC_OK) { bc_lib_destroy(lib); return rc; }
+    *out = lib;
+    return BC_OK;
+}
+
+int bc_lib_destroy(bc_lib* lib) {
+    if (!lib) return BC_OK;
+    (void)hipSetDevice(lib->device);
+    for (void* p : lib->owned) (void)hipFree(p);
+    delete lib;
+    return BC_OK;
+}
+
+int bc_lib_info(const bc_lib* lib, uint32_t* n_guides, int* k, int* device) {
+    if (!lib) { set_error("bc_lib_info: null"); return BC_EINVAL; }
+    if (n_guides) *n_guides = lib->G;
+    if (k) *k = lib->k;
+    if (device) *device = lib->device;
+    return BC_OK;
+}
+
+int bc_match_dev(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
+                 int max_mismatch, int algo, int32_t* d_best_idx, uint8_t* d_best_dist,
+                 uint8_t* d_n_best, uint32_t* d_counts, uint64_t* d_first_seen,
+                 uint64_t first_index_base, void* stream) {
+    if (!lib || (n && (!d_reads || !d_best_idx))) { set_error("bc_match_dev: null argument"); return BC_EINVAL; }
+    BC_HIP(hipSetDevice(lib->device));
+    MatchOut o{d_best_idx, d_best_dist, d_n_best, d_counts, d_first_seen, first_index_base};
+    return launch_match(lib, d_reads, d_flags, n, max_mismatch, algo, o, (hipStream_t)stream);
+}
+
+int bc_match_time_dev(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
+                      int max_mismatch, int algo, int32_t* d_best_idx, uint8_t* d_best_dist,
+                      uint8_t* d_n_best, uint32_t* d_counts, uint64_t* d_first_seen, int iters,
+                      void* stream, float* ms_out) {
+    if (!lib || !ms_out || iters < 1) { set_error("bc_match_time_dev: bad argument"); return BC_EINVAL; }
+    BC_HIP(hipSetDevice(lib->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    BC_HIP(hipEventCreate(&e0));
+    BC_HIP(hipEventCreate(&e1));
+    MatchOut o{d_best_idx, d_best_dist, d_n_best, d_counts, d_first_seen, 0};
+    BC_HIP(hipEventRecord(e0, st));
+    int rc = BC_OK;
+    for (int it = 0; it < iters && rc == BC_OK; ++it)
+        rc = launch_match(lib, d_reads, d_flags, n, max_mismatch, algo, o, st);
+    BC_HIP(hipEventRecord(e1, st));
+    BC_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    BC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    return rc;
+}
+
+int bc_match_all_dev(bc_lib* lib, const uint64_t* d_queries, const uint8_t* d_flags, uint64_t n,
+                     int max_mismatch, bc_hit* d_hits, uint64_t cap, uint64_t* d_n_hits, void* stream) {
+    if (!lib || !d_n_hits || (n && !d_queries) || (cap && !d_hits)) { set_error("bc_match_all_dev: null argument"); return BC_EINVAL; }
+    if (max_mismatch < 0 || max_mismatch >= MAX_SEG) { set_error("bc_match_all_dev: 0 <= max_mismatch <= %d", MAX_SEG - 1); return BC_EINVAL; }
+    if (n > 0xFFFFFFFFull) { set_error("bc_match_all_dev: at most 2^32-1 queries per call"); return BC_EINVAL; }
+    if (n == 0) return BC_OK;
+    BC_HIP(hipSetDevice(lib->device));
+    hipLaunchKernelGGL(k_match_all, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, lib->seed[max_mismatch],
+                       d_queries, d_flags, n, lib->k, lib->kmask, max_mismatch, d_hits, cap,
+                       (unsigned long long*)d_n_hits);
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+int bc_match_host(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, uint64_t n,
+                  int max_mismatch, int algo, int32_t* h_best_idx, uint8_t* h_best_dist,
+                  uint8_t* h_n_best, uint64_t* h_counts, uint64_t* h_first_seen,
+                  uint64_t first_index_base) {
+    if (!lib || (n && (!h_reads || !h_best_idx))) { set_error("bc_match_host: null argument"); return BC_EINVAL; }
+    BC_HIP(hipSetDevice(lib->device));
+    const uint64_t CH = 1ull << 24;
+    const uint64_t c = std::min<uint64_t>(std::max<uint64_t>(n, 1), CH);
+    uint64_t *d_r = nullptr, *d_fs = nullptr;
+    uint8_t *d_f = nullptr, *d_bd = nullptr, *d_nb = nullptr;
+    int32_t* d_bi = nullptr;
+    uint32_t* d_c = nullptr;
+    int rc = BC_OK;
+    std::vector<uint32_t> c32;
+    std::vector<uint64_t> fs;
+    auto body = [&]() -> int {
+        BC_HIP(hipMalloc((void**)&d_r, c * 8));
+        BC_HIP(hipMalloc((void**)&d_bi, c * 4));
+        if (h_flags) BC_HIP(hipMalloc((void**)&d_f, c));
+        if (h_best_dist) BC_HIP(hipMalloc((void**)&d_bd, c));
+        if (h_n_best) BC_HIP(hipMalloc((void**)&d_nb, c));
+        if (h_counts) {
+            BC_HIP(hipMalloc((void**)&d_c, (size_t)lib->G * 4));
+            c32.resize(lib->G);
+        }
+        if (h_first_seen) {
+            BC_HIP(hipMalloc((void**)&d_fs, (size_t)lib->G * 8));
+            BC_HIP(hipMemset(d_fs, 0xFF, (size_t)lib->G * 8));
+            fs.resize(lib->G);
+        }
+        for (uint64_t a = 0; a < n; a += c) {
+            uint64_t m = std::min(c, n - a);
+            BC_HIP(hipMemcpy(d_r, h_reads + a, m * 8, hipMemcpyHostToDevice));
+            if (h_flags) BC_HIP(hipMemcpy(d_f, h_flags + a, m, hipMemcpyHostToDevice));
+            if (d_c) BC_HIP(hipMemset(d_c, 0, (size_t)lib->G * 4));
+            MatchOut o{d_bi, d_bd, d_nb, d_c, d_fs, first_index_base + a};
+            int r2 = launch_match(lib, d_r, d_f, m, max_mismatch, algo, o, 0);
+            if (r2 != BC_OK) return r2;
+            BC_HIP(hipDeviceSynchronize());
+            BC_HIP(hipMemcpy(h_best_idx + a, d_bi, m * 4, hipMemcpyDeviceToHost));
+            if (h_best_dist) BC_HIP(hipMemcpy(h_best_dist + a, d_bd, m, hipMemcpyDeviceToHost));
+            if (h_n_best) BC_HIP(hipMemcpy(h_n_best + a, d_nb, m, hipMemcpyDeviceToHost));
+            if (d_c) {
+                BC_HIP(hipMemcpy(c32.data(), d_c, (size_t)lib->G * 4, hipMemcpyDeviceToHost));
+                for (uint32_t g = 0; g < lib->G; ++g) h_counts[g] += c32[g];
+            }
+        }
+        if (d_fs) {
+            BC_HIP(hipMemcpy(fs.data(), d_fs, (size_t)lib->G * 8, hipMemcpyDeviceToHost));
+            for (uint32_t g = 0; g < lib->G; ++g) h_first_seen[g] = std::min(h_first_seen[g], fs[g]);
+        }
+        return BC_OK;
+    };
+    rc = body();
+    for (void* p : {(void*)d_r, (void*)d_bi, (void*)d_f, (void*)d_bd, (void*)d_nb, (void*)d_c, (void*)d_fs}) (void)hipFree(p);
+    return rc;
+}
+
+int bc_synth_reads_dev(bc_lib* lib, uint64_t seed, uint64_t first_index, uint64_t n, int mixture,
+                       uint64_t* d_reads, void* stream) {
+    if (!lib || (n && !d_reads) || mixture < 0 || mixture > 1) { set_error("bc_synth_reads_dev: bad argument"); return BC_EINVAL; }
+    if (n == 0) return BC_OK;
+    BC_HIP(hipSetDevice(lib->device));
+    hipLaunchKernelGGL(k_synth_reads, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, lib->d_guides,
+                       lib->G, lib->k, seed, first_index, n, mixture, d_reads);
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+// ---- raw device memory helpers ----------------------------------------------
+int bc_dev_set(int device) { BC_HIP(hipSetDevice(device)); return BC_OK; }
+int bc_dev_alloc(void** d_ptr, size_t bytes) {
+    if (!d_ptr) { set_error("bc_dev_alloc: null"); return BC_EINVAL; }
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return BC_ENOMEM; }
+    return BC_OK;
+}
+int bc_dev_free(void* d_ptr) { BC_HIP(hipFree(d_ptr)); return BC_OK; }
+int bc_dev_memset(void* d_ptr, int value, size_t bytes, void* stream) {
+    BC_HIP(hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)stream));
+    return BC_OK;
+}
+int bc_dev_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    BC_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    BC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BC_OK;
+}
+int bc_dev_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream) {
+    BC_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BC_OK;
+}
+int bc_dev_sync(void* stream) {
+    if (stream) BC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    else BC_HIP(hipDeviceSynchronize());
+    return BC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+/*
+ * barcoder.h — C ABI of libbarcoder_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the read->library matching path and the PAM
+ * site scan of ryandward/barcoder.  The reference exposes no FFI for this path
+ * (it is pure Python); each entry point below cites the reference interface
+ * (file:line, relative to the reference checkout) whose per-read / per-base
+ * work it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++ or torch types;
+ *   - every function returns BC_OK (0) or a negative BC_E* code; the message of
+ *     the last failure on the calling thread is bc_last_error();
+ *   - "h_" pointers are host memory, "d_" pointers are device (HBM) memory of
+ *     the device the bc_lib lives on; `stream` is a hipStream_t passed as
+ *     void* (NULL = the null stream);
+ *   - no global state besides the thread-local error string.
+ *
+ * Sequence encoding (DESIGN.md "Data layout"): codes A=0 C=1 G=2 T=3, two bits
+ * per base in "plane form": base i of a k-mer (0 = leftmost / 5', k <= 32) has
+ * its low code bit at bit i and its high code bit at bit 32+i of a uint64_t.
+ * For k <= 31 bit 63 set means "skip this read"; for any k an optional byte
+ * array `flags` (non-zero = skip) carries the same information.
+ */
+#ifndef BARCODER_H
+#define BARCODER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BC_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define BC_OK 0
+#define BC_EINVAL (-1)  /* bad argument (maps to ValueError)            */
+#define BC_ENOMEM (-2)  /* host or device allocation failed             */
+#define BC_EHIP (-3)    /* HIP runtime error (maps to RuntimeError)     */
+#define BC_ENODEV (-4)  /* no usable GPU                                */
+#define BC_ECAP (-5)    /* caller-provided output capacity too small    */
+
+/* best_idx sentinels */
+#define BC_IDX_MISS (-1) /* valid read, no guide within max_mismatch     */
+#define BC_IDX_SKIP (-2) /* read flagged skip (N / flank failure / short) */
+#define BC_DIST_NONE 255
+
+/* skip flag inside a packed read (k <= 31) */
+#define BC_SKIP_BIT (1ULL << 63)
+
+/* match algorithms */
+#define BC_ALGO_AUTO 0  /* exact hash when max_mismatch==0, else seed index */
+#define BC_ALGO_HASH 1  /* d = 0 only: open-addressing table in L2          */
+#define BC_ALGO_SEED 2  /* pigeonhole seed index + verify, d <= 3           */
+#define BC_ALGO_BRUTE 3 /* LDS-tiled all-pairs XOR+popcount, any d          */
+
+/* window status written by bc_pack_windows */
+#define BC_WIN_OK 0       /* flanks present, k-mer packed                        */
+#define BC_WIN_SKIP 1     /* 'N' in read, or flanks absent: contributes nothing  */
+#define BC_WIN_ODD 2      /* flanks present but window short / non-ACGT: the     */
+                          /* caller keeps the string (undocumented label only)   */
+
+typedef struct bc_lib bc_lib; /* device-resident guide library, one per GPU */
+
+/* ---- misc ---------------------------------------------------------------- */
+int bc_version(void);
+const char *bc_last_error(void);
+int bc_device_count(int *n_out);
+
+/* ---- host-side encoding (K1) ---------------------------------------------
+ * bc_pack_kmers: n fixed-length k-mers laid out `stride` bytes apart ->
+ * packed words.  flags[i]=1 (and BC_SKIP_BIT for k<=31) where a character is
+ * not one of ACGT.  Replaces the string form of library entries and windows
+ * (heuristicount.py:41-57 read_fasta, BarCodeLibrary.py:27-45). */
+int bc_pack_kmers(const char *h_seqs, size_t n, int k, size_t stride,
+                  uint64_t *h_out, uint8_t *h_flags /* may be NULL */);
+
+/* bc_unpack_kmers: inverse (for labels in TSV/JSON output). out is n*k chars. */
+int bc_unpack_kmers(const uint64_t *h_packed, size_t n, int k, char *h_out);
+
+/* bc_revcomp_kmers: reverse complement of packed k-mers
+ * (heuristicount.py:29-30 rev_comp, PySamParser.py:8-9). */
+int bc_revcomp_kmers(const uint64_t *h_in, size_t n, int k, uint64_t *h_out);
+
+/* bc_pack_windows: the per-read front half of process_chunk
+ * (heuristicount.py:449-462 validate_read, :520-538 process_single_end):
+ * N-skip (:524), window slice at `start` (:527), flank check (:458-460),
+ * optional reverse complement of the barcode (:532-533).
+ *   text      : concatenated read bytes, read i = text[off[i] .. off[i+1])
+ *   L, R      : flank strings (may be empty), k = barcode length
+ *   reverse   : non-zero -> emit rev_comp(barcode) (single-end reverse reads)
+ *   out       : packed barcode (BC_SKIP_BIT set unless status==BC_WIN_OK)
+ *   status    : BC_WIN_* per read
+ * n_threads <= 0 means all cores. */
+int bc_pack_windows(const char *h_text, const uint64_t *h_off, size_t n_reads,
+                    int64_t start, const char *L, int L_len, const char *R, int R_len,
+                    int k, int reverse, int n_threads,
+                    uint64_t *h_out, uint8_t *h_status);
+
+/* ---- library -------------------------------------------------------------
+ * bc_lib_create: upload G distinct packed guides (index = position in the
+ * array = first-occurrence order of the de-duplicated library,
+ * BarCodeLibrary.py:48-93 / heuristicount.py:41-57) to `device`, build the
+ * exact-match table and the pigeonhole seed indices for d = 1..3.
+ * Duplicate guides are rejected with BC_EINVAL. */
+int bc_lib_create(const uint64_t *h_guides, uint32_t n_guides, int k, int device,
+                  bc_lib **out);
+int bc_lib_destroy(bc_lib *lib);
+int bc_lib_info(const bc_lib *lib, uint32_t *n_guides, int *k, int *device);
+
+/* ---- read -> library match (K2, K3, K5) ----------------------------------
+ * The device twin of the back half of process_chunk (heuristicount.py:449-453
+ * set lookup, :535-538 Counter update) generalised to <= max_mismatch
+ * substitutions (the reference delegates that to `bowtie -v N`,
+ * targets.py:496-509, BowtieRunner.py:111-125).
+ *
+ * Semantics (DESIGN.md "Best-hit definition"): best = the guide at minimum
+ * Hamming distance <= max_mismatch; ties -> lowest guide index; n_best = number
+ * of guides at that distance (saturating at 255).
+ *
+ *   d_reads      : n packed reads
+ *   d_flags      : optional n bytes, non-zero = skip
+ *   d_best_idx   : n int32 out (guide index, BC_IDX_MISS, BC_IDX_SKIP)
+ *   d_best_dist  : optional n uint8 out (distance, BC_DIST_NONE)
+ *   d_n_best     : optional n uint8 out
+ *   d_counts     : optional uint32[n_guides], ATOMICALLY INCREMENTED (caller
+ *                  zeroes it; several launches may accumulate into it)
+ *   d_first_seen : optional uint64[n_guides], atomically min'ed with
+ *                  first_index_base + i for the matched read i (caller
+ *                  initialises to UINT64_MAX); gives heuristicount.py:876-877's
+ *                  first-seen output order
+ */
+int bc_match_dev(bc_lib *lib, const uint64_t *d_reads, const uint8_t *d_flags, uint64_t n,
+                 int max_mismatch, int algo,
+                 int32_t *d_best_idx, uint8_t *d_best_dist, uint8_t *d_n_best,
+                 uint32_t *d_counts, uint64_t *d_first_seen, uint64_t first_index_base,
+                 void *stream);
+
+/* Same with host buffers: H2D, match, D2H on the library's device (chunked so
+ * any n fits).  h_counts (uint64[n_guides]) is ADDED to, h_first_seen
+ * (uint64[n_guides]) is min'ed. */
+int bc_match_host(bc_lib *lib, const uint64_t *h_reads, const uint8_t *h_flags, uint64_t n,
+                  int max_mismatch, int algo,
+                  int32_t *h_best_idx, uint8_t *h_best_dist, uint8_t *h_n_best,
+                  uint64_t *h_counts, uint64_t *h_first_seen, uint64_t first_index_base);
+
+/* ---- all hits (guide -> genome search, the Bowtie bypass) -----------------
+ * For every query word q[i] (a genome window or a read) emit every guide
+ * within max_mismatch as a record {query index, guide index, distance}; this is
+ * what `bowtie -a -v N` returns for spacers against the genome
+ * (BowtieRunner.py:111-125, targets.py:496-509) with the roles of query and
+ * index swapped.  Records are written in unspecified order; *d_n_hits (uint64,
+ * zeroed by the caller) counts ALL hits, also those beyond `cap` (which are
+ * dropped) so the caller can retry with a larger buffer. */
+typedef struct bc_hit {
+    uint32_t query;
+    uint32_t guide;
+    uint32_t dist;
+} bc_hit;
+int bc_match_all_dev(bc_lib *lib, const uint64_t *d_queries, const uint8_t *d_flags,
+                     uint64_t n, int max_mismatch, bc_hit *d_hits, uint64_t cap,
+                     uint64_t *d_n_hits, void *stream);
+
+/* ---- genome encoding + PAM site scan (K4) --------------------------------
+ * bc_genome_pack: ASCII bases -> one uint64 per 32 positions in the same plane
+ * form as a 32-mer (word w = positions 32w..32w+31; low half = low code bits,
+ * high half = high code bits) plus an "invalid" bitmap (bit j of word w set
+ * where the character is not ACGT, case-insensitive, or past the end).
+ * `wrap` > 0 appends the first `wrap` bases again after the end (position
+ * len+i = seq[i % len]) so that sites of a circular sequence that span the
+ * origin have a linear representation: the device-side replacement for the
+ * reference's 100 kb overhang (targets.py:35-56 create_topological_fasta).
+ * Outputs hold ceil((len+wrap)/32) words. */
+int bc_genome_pack(const char *h_seq, uint64_t len, uint64_t wrap, uint64_t *h_bases,
+                   uint32_t *h_invalid);
+
+/* bc_pam_scan_*: for every position p in [0, total_len) report whether the PAM
+ * pattern matches genome[p .. p+pam_len) on the forward strand (bitmap fwd) and
+ * whether revcomp(PAM) matches there, i.e. a PAM on the reverse strand (bitmap
+ * rev).  Bit p%32 of word p/32; ceil(total_len/32) words each.
+ * `pam_masks[j]` is the IUPAC set of pattern position j as a 4-bit mask
+ * (bit0=A bit1=C bit2=G bit3=T; N = 15).  Non-ACGT genome characters and
+ * positions past total_len never match.
+ * This is the per-position test of PAMProcessor.py:34-57
+ * (GuideFinder.find_guides_from_pam), design_guides.py:22-49
+ * (find_sequences_with_barcode_and_pam) and targets.py:219-224 (pam_matches);
+ * the reference-flavoured site lists are selections from these bitmaps
+ * (barcoder_amd/pam.py). */
+int bc_pam_scan_dev(const uint64_t *d_bases, const uint32_t *d_invalid, uint64_t total_len,
+                    const uint8_t *pam_masks, int pam_len, uint32_t *d_fwd, uint32_t *d_rev,
+                    void *stream);
+int bc_pam_scan_host(int device, const uint64_t *h_bases, const uint32_t *h_invalid,
+                     uint64_t total_len, const uint8_t *pam_masks, int pam_len,
+                     uint32_t *h_fwd, uint32_t *h_rev);
+
+/* bc_sites_expand_dev: bitmap -> ascending position list (uint32).  *d_n_out
+ * (uint64) receives the number of set bits; positions beyond `cap` are not
+ * written.  d_tmp must hold ceil(n_words/1024)+1 uint32. */
+int bc_sites_expand_dev(const uint32_t *d_bitmap, uint64_t n_words, uint32_t *d_pos,
+                        uint64_t cap, uint64_t *d_n_out, uint32_t *d_tmp, void *stream);
+
+/* bc_windows_dev: k-mer at each listed position of a packed genome, on the
+ * forward strand (strand=0: genome[p .. p+k)) or reverse-complemented
+ * (strand=1: revcomp(genome[p .. p+k))).  Windows touching a non-ACGT base or
+ * running past total_len get BC_SKIP_BIT (k<=31) and flag 1.
+ * Feeds bc_match_dev / bc_match_all_dev (targets.py:354-410 hit records). */
+int bc_windows_dev(const uint64_t *d_bases, const uint32_t *d_invalid, uint64_t total_len,
+                   const uint32_t *d_pos /* NULL = every position 0..n_pos-1 */,
+                   uint64_t n_pos, int k, int strand, uint64_t *d_out, uint8_t *d_flags,
+                   void *stream);
+
+/* ---- synthetic workloads (bench / tests) -----------
+ * Counter-based splitmix64 streams, identical to barcoder_amd/synth.py.
+ * mixture: 0 = exact (90 % library reads, 10 % random),
+ *          1 = mismatch (60/20/10/5 % with 0/1/2/3 substitutions, 5 % random). */
+int bc_synth_reads_dev(bc_lib *lib, uint64_t seed, uint64_t first_index, uint64_t n,
+                       int mixture, uint64_t *d_reads, void *stream);
+
+/* ---- raw device memory helpers (so a ctypes caller needs no torch) -------- */
+int bc_dev_set(int device);
+int bc_dev_alloc(void **d_ptr, size_t bytes);
+int bc_dev_free(void *d_ptr);
+int bc_dev_memset(void *d_ptr, int value, size_t bytes, void *stream);
+int bc_dev_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int bc_dev_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int bc_dev_sync(void *stream);
+
+/* ---- timing of the dominant kernel (bench.py roofline) --------------------
+ * Runs bc_match_dev `iters` times on `stream` bracketed by HIP events recorded
+ * on that stream and returns the mean kernel-launch duration in ms. */
+int bc_match_time_dev(bc_lib *lib, const uint64_t *d_reads, const uint8_t *d_flags, uint64_t n,
+                      int max_mismatch, int algo, int32_t *d_best_idx, uint8_t *d_best_dist,
+                      uint8_t *d_n_best, uint32_t *d_counts, uint64_t *d_first_seen,
+                      int iters, void *stream, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BARCODER_H */

@@ -1,0 +1,103 @@
+"""GPU parity: every match algorithm vs the string-based CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from barcoder_amd import DeviceLibrary, GpuMatcher
+from barcoder_amd import encoding as E
+from barcoder_amd import synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(G, n, k, mixture, seed, frac_skip=0.02):
+    lib = S.library(G, k, seed=S.LIB_SEED + k)
+    reads = S.reads(lib, k, seed, 0, n, mixture)
+    flags = (S.draw(seed + 99, np.arange(n, dtype=np.uint64), 7) % np.uint64(1000) < np.uint64(int(frac_skip * 1000))).astype(np.uint8)
+    return lib, reads, flags
+
+
+def _check(res, ref):
+    np.testing.assert_array_equal(res.best_idx, ref["best_idx"])
+    np.testing.assert_array_equal(res.best_dist, ref["best_dist"])
+    np.testing.assert_array_equal(res.n_best, ref["n_best"])
+    np.testing.assert_array_equal(res.counts, ref["counts"])
+    np.testing.assert_array_equal(res.first_seen, ref["first_seen"])
+
+
+@pytest.mark.parametrize("k", [20, 32, 12])
+@pytest.mark.parametrize("algo,max_mm", [("hash", 0), ("seed", 0), ("seed", 1), ("seed", 2), ("seed", 3),
+                                         ("brute", 0), ("brute", 2), ("brute", 4)])
+def test_match_parity(gpu_device, oracle, algo, max_mm, k):
+    G, n = 3000, 20011
+    lib, reads, flags = _case(G, n, k, 1 if max_mm else 0, seed=7 + max_mm)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    res = GpuMatcher(dl).match(reads, flags, max_mismatch=max_mm, algo=algo, first_index=5)
+    ref = oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads & E.kmer_mask(k), k), max_mm, skip=flags, base=5)
+    _check(res, ref)
+    assert (res.best_idx >= 0).sum() > n // 2
+
+
+def test_dense_library_ties(gpu_device, oracle):
+    """A library that is dense in sequence space: many ties and n_best > 1."""
+    k = 6
+    lib = np.arange(4 ** k, dtype=np.uint64)
+    # plane form of the 2-bit counter value: spread even/odd bits
+    codes = (lib[:, None] >> (np.arange(k, dtype=np.uint64) * np.uint64(2))) & np.uint64(3)
+    lo = ((codes & np.uint64(1)) << np.arange(k, dtype=np.uint64)).sum(1)
+    hi = ((codes >> np.uint64(1)) << np.arange(k, dtype=np.uint64)).sum(1)
+    allk = (lo | (hi << np.uint64(32))).astype(np.uint64)
+    rng = np.random.default_rng(3)
+    lib = allk[rng.permutation(allk.size)[:1500]]
+    reads = allk[rng.integers(0, allk.size, 5000)]
+    dl = DeviceLibrary(lib, k, gpu_device)
+    m = GpuMatcher(dl)
+    ls, rs = E.unpack_kmers(lib, k), E.unpack_kmers(reads, k)
+    for algo, d in [("seed", 1), ("seed", 2), ("seed", 3), ("brute", 2), ("hash", 0)]:
+        res = m.match(reads, None, max_mismatch=d, algo=algo)
+        _check(res, oracle.best_hit(ls, rs, d))
+    assert res is not None
+
+
+def test_all_hits(gpu_device, oracle):
+    k = 20
+    lib, reads, flags = _case(2000, 5000, k, 1, seed=21)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    for d in (0, 1, 2, 3):
+        hits = GpuMatcher(dl).all_hits(reads, flags, max_mismatch=d)
+        ref = oracle.all_hits(E.unpack_kmers(lib, k), E.unpack_kmers(reads & E.kmer_mask(k), k), d, skip=flags)
+        got = np.stack([hits["query"], hits["guide"], hits["dist"]], axis=1)
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_edge_sizes(gpu_device, oracle):
+    k = 20
+    lib = S.library(50, k)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    m = GpuMatcher(dl)
+    for n in (0, 1, 3, 4, 5, 255, 257):
+        reads = S.reads(lib, k, 3, 0, n, 1)
+        for algo, d in [("hash", 0), ("seed", 2), ("brute", 2)]:
+            res = m.match(reads, None, max_mismatch=d, algo=algo)
+            if n:
+                _check(res, oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads, k), d))
+            else:
+                assert res.best_idx.size == 0 and res.counts.sum() == 0
+
+
+def test_synth_device_matches_numpy(gpu_device):
+    import ctypes as C
+    from barcoder_amd import _native as N
+    k, n = 20, 10007
+    lib = S.library(1234, k)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    L = N.load()
+    d = N.vp()
+    N.check(L.bc_dev_alloc(C.byref(d), n * 8))
+    try:
+        for mix in (0, 1):
+            GpuMatcher(dl).synth_reads_dev(seed=2 + mix, first=1000, n=n, mixture=mix, d_reads=d)
+            out = np.empty(n, np.uint64)
+            N.check(L.bc_dev_d2h(N.ptr(out), d, n * 8, None))
+            np.testing.assert_array_equal(out, S.reads(lib, k, 2 + mix, 1000, n, mix))
+    finally:
+        L.bc_dev_free(d)
