@@ -147,14 +147,16 @@ __global__ __launch_bounds__(BLOCK) void k_windows(const uint64_t* __restrict__ 
                                                    const uint32_t* __restrict__ invalid,
                                                    uint64_t total_len, uint64_t n_words,
                                                    const uint32_t* __restrict__ pos, uint64_t n_pos,
-                                                   int k, int strand, uint64_t* __restrict__ out,
+                                                   int64_t offset, int k, int strand,
+                                                   uint64_t* __restrict__ out,
                                                    uint8_t* __restrict__ flags) {
     const uint32_t km = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n_pos; t += stride) {
-        uint64_t p = pos ? (uint64_t)pos[t] : t;
+        int64_t sp = (int64_t)(pos ? (uint64_t)pos[t] : t) + offset;
+        uint64_t p = (uint64_t)sp;
         uint64_t word = 0;
-        bool bad = (p + (uint64_t)k > total_len);
+        bool bad = sp < 0 || (p + (uint64_t)k > total_len);
         if (!bad) {
             uint64_t w = p >> 5;
             int sh = (int)(p & 31);
@@ -269,8 +271,8 @@ int bc_sites_expand_dev(const uint32_t* d_bitmap, uint64_t n_words, uint32_t* d_
 }
 
 int bc_windows_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t total_len,
-                   const uint32_t* d_pos, uint64_t n_pos, int k, int strand, uint64_t* d_out,
-                   uint8_t* d_flags, void* stream) {
+                   const uint32_t* d_pos, uint64_t n_pos, int64_t offset, int k, int strand,
+                   uint64_t* d_out, uint8_t* d_flags, void* stream) {
     if (!d_bases || !d_invalid || (n_pos && !d_out) || k < 1 || k > 32 || strand < 0 || strand > 1) {
         set_error("bc_windows_dev: bad argument (k=%d strand=%d)", k, strand);
         return BC_EINVAL;
@@ -278,7 +280,7 @@ int bc_windows_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t 
     if (n_pos == 0) return BC_OK;
     uint64_t n_words = (total_len + 31) / 32;
     hipLaunchKernelGGL(k_windows, dim3(grid_for(n_pos)), dim3(BLOCK), 0, (hipStream_t)stream, d_bases,
-                       d_invalid, total_len, n_words, d_pos, n_pos, k, strand, d_out, d_flags);
+                       d_invalid, total_len, n_words, d_pos, n_pos, offset, k, strand, d_out, d_flags);
     BC_HIP(hipGetLastError());
     return BC_OK;
 }

@@ -1,0 +1,506 @@
+"""GPU barcode counter with the call shapes and outputs of the reference's
+heuristicount.py.  The per-read hot loop (`process_chunk`) runs on the MI355X;
+file reading, sampling and flank discovery are host logic.
+
+Mirrors (reference file:line):
+  rev_comp             heuristicount.py:29-30
+  read_fasta           heuristicount.py:41-57
+  open_reads_file      heuristicount.py:60-72
+  validate_barcodes    heuristicount.py:75-97
+  read_in_chunks       heuristicount.py:100-153
+  sample_data          heuristicount.py:156-379
+  find_flanks          heuristicount.py:382-425
+  process_chunk        heuristicount.py:428-562   <- bc_pack_windows + bc_match (HIP)
+  main                 heuristicount.py:565-888
+
+Usage:  python -m barcoder_amd.heuristicount library.fasta reads1.fastq [reads2.fastq]
+"""
+from __future__ import annotations
+
+import argparse
+import gzip
+import logging
+import os
+import sys
+from collections import Counter
+from contextlib import nullcontext
+
+import numpy as np
+
+from . import _native as N
+from .encoding import pack_windows, reads_to_text, unpack_kmers
+from .library import DeviceLibrary
+from .matcher import GpuMatcher
+
+log = logging.getLogger("barcoder_amd.heuristicount")
+
+_COMP = str.maketrans("ATCGN", "TAGCN")
+FEEDBACK = ("If this assumption disrupts your pipeline, we welcome your feedback on our GitHub page:\n"
+            "https://github.com/ryandward/barcoder/issues")
+
+
+def rev_comp(sequence: str) -> str:
+    return sequence[::-1].translate(_COMP)
+
+
+def safe_len(s):
+    return 0 if s is None else len(s)
+
+
+def _zst_open(path, mode):
+    try:
+        import zstandard as zstd
+    except ImportError as e:  # the reference needs the same optional package for .zst
+        raise ValueError(f'"{path}": reading .zst needs the zstandard package') from e
+    return zstd.open(path, mode)
+
+
+def read_fasta(fasta_file):
+    """Every non-header line, stripped, as a set (no upper-casing; a blank line
+    yields "" exactly as in the reference)."""
+    if fasta_file.endswith(".gz"):
+        opener = gzip.open
+    elif fasta_file.endswith(".zst"):
+        opener = _zst_open
+    elif fasta_file.endswith((".fasta", ".fa")):
+        opener = open
+    else:
+        raise ValueError(f'"{fasta_file}" does not appear to be a supported fasta file: .fasta or .fa.')
+    with opener(fasta_file, "rt") as fh:
+        return {line.strip() for line in fh if not line.startswith(">")}
+
+
+def read_fasta_ordered(fasta_file):
+    """Same lines as read_fasta, de-duplicated in file order (= guide index order)."""
+    if fasta_file.endswith(".gz"):
+        opener = gzip.open
+    elif fasta_file.endswith(".zst"):
+        opener = _zst_open
+    else:
+        opener = open
+    with opener(fasta_file, "rt") as fh:
+        return list(dict.fromkeys(line.strip() for line in fh if not line.startswith(">")))
+
+
+def open_reads_file(file_path, mode):
+    if file_path.endswith(".gz"):
+        return gzip.open(file_path, mode)
+    if file_path.endswith(".zst"):
+        return _zst_open(file_path, mode)
+    if file_path.endswith((".fastq", ".fq", ".reads")):
+        return open(file_path, mode)
+    raise ValueError(f'"{file_path}" does not appear to be a supported reads file: .fastq or .reads.')
+
+
+def validate_barcodes(barcodes):
+    if isinstance(barcodes, list):
+        sequences = set(barcodes)
+    elif isinstance(barcodes, set):
+        sequences = barcodes
+    else:
+        raise ValueError("Pass a list or set of barcodes to validate.")
+    if len(sequences) < 10:
+        raise ValueError("The input contains fewer than 10 sequences. Please provide at least 10 short barcodes.")
+    for seq in sequences:
+        if len(seq) > 1000:
+            raise ValueError(f'The sequence "{seq[:30]}..." is longer than 1,000 bases. '
+                             "Provide a list or fasta file of short barcodes.")
+
+
+def read_in_chunks(file1, file2=None, chunk_size=2 ** 16):
+    """Yield (reads1, reads2|None) lists of `chunk_size` sequence lines."""
+    base = os.path.splitext(file1)[0] if file1.endswith((".gz", ".zst")) else file1
+    if base.endswith(".fastq"):
+        per_record, seq_line = 4, 1
+    elif base.endswith(".reads"):
+        per_record, seq_line = 1, 0
+    else:
+        raise ValueError("Unsupported file type. Must be '.fastq' or '.reads'.")
+
+    def sequences(handle):
+        # the sequence line counts as soon as it is read, even if the record's
+        # remaining lines are missing (the reference appends before it skips them)
+        while True:
+            for j in range(per_record):
+                line = handle.readline()
+                if not line:
+                    return
+                if j == seq_line:
+                    yield line.strip()
+
+    with open_reads_file(file1, "rt") as f1, (open_reads_file(file2, "rt") if file2 else nullcontext()) as f2:
+        it1 = sequences(f1)
+        it2 = sequences(f2) if file2 else None
+        reads1, reads2 = [], []
+        for r1 in it1:
+            if it2 is not None:
+                r2 = next(it2, None)
+                if r2 is None:  # mate file ended first: the reference stops here, keeping r1
+                    reads1.append(r1)
+                    break
+                reads2.append(r2)
+            reads1.append(r1)
+            if len(reads1) >= chunk_size:
+                yield reads1[:chunk_size], (reads2[:chunk_size] if reads2 else None)
+                reads1, reads2 = reads1[chunk_size:], (reads2[chunk_size:] if reads2 else [])
+        if reads1:
+            yield reads1, (reads2 if reads2 else None)
+
+
+# ------------------------------------------------------------------------------ sampling
+def sample_data(file1, file2, barcodes, is_paired):
+    """Orientation / offset discovery on the first chunks of reads (host logic,
+    heuristicount.py:156-379).  Returns the same 8-tuple as the reference."""
+    n_lib = len(barcodes)
+    rev_barcodes = {rev_comp(b) for b in barcodes}
+    k = len(next(iter(barcodes)))
+    div = [0, 0]
+    orients = (Counter(), Counter())
+    offsets = (Counter(), Counter())
+    valid = (set(), set())
+    seen_reads, observed, all_novel = set(), set(), []
+    satisfied = False
+    n_chunks = 0
+    read1 = read2 = None
+    for chunk1, chunk2 in read_in_chunks(file1, file2 if is_paired else None, chunk_size=n_lib):
+        n_chunks += 1
+        c_orients = ([], [])
+        c_offsets = ([], [])
+        c_barcodes, c_reads = set(), set()
+        for read1, read2 in zip(chunk1, chunk2 if chunk2 else [None] * len(chunk1)):
+            if read1 in c_reads or (read2 and read2 in c_reads):
+                continue
+            seen_reads.add(read1)
+            if is_paired:
+                seen_reads.add(read2)
+            for i in range(len(read1) - k + 1):
+                kmers = (read1[i:i + k], read2[i:i + k] if is_paired else None)
+                for side in (0, 1):
+                    kmer = kmers[side]
+                    if side == 1 and not is_paired:
+                        break
+                    if kmer in c_barcodes:
+                        break  # already seen this chunk: the reference `continue`s to the next i
+                    read = read1 if side == 0 else read2
+                    for lib, label in ((barcodes, "forward"), (rev_barcodes, "reverse")):
+                        if kmer in lib:
+                            div[side] += 1
+                            c_barcodes.add(kmer)
+                            observed.add(kmers[0])  # sic: the reference records read1's k-mer for both mates
+                            c_orients[side].append(label)
+                            c_offsets[side].append(i)
+                            valid[side].add(read)
+                            c_reads.add(read)
+        all_novel.extend(c_barcodes)
+        for side in (0, 1):
+            orients[side].update(c_orients[side])
+            offsets[side].update(c_offsets[side])
+        top1, top2 = offsets[0].most_common(2), offsets[1].most_common(2)
+        need = 5 * n_lib
+        if is_paired:
+            if div[0] >= need and div[1] >= need:
+                log.info("Many barcodes seen enough in reads...")
+                satisfied = True
+        elif div[0] >= need:
+            log.info("Many barcodes seen enough in reads...")
+            satisfied = True
+        if len(seen_reads) >= need and all_novel:
+            log.info("Read depth diversity satisfied...")
+            satisfied = True
+        if len(all_novel) >= need:
+            log.info("Barcode frequency diversity satisfied...")
+            satisfied = True
+        if satisfied:
+            def dominant(top):
+                return len(top) > 1 and top[0][1] >= 2 * top[1][1]
+            if is_paired:
+                done = (len(top1) == 1 and len(top2) == 1) or (dominant(top1) and dominant(top2))
+            else:
+                done = len(top1) == 1 or dominant(top1)
+            if done:
+                log.info("Dominant offsets found...")
+                break
+    if not satisfied:
+        log.warning("Sequencing depth is probably insufficient! Continuing anyway...")
+
+    def top(counter, present):
+        return counter.most_common(1)[0][0] if present else None
+
+    o1, off1 = top(orients[0], read1), top(offsets[0], read1)
+    o2, off2 = top(orients[1], read2), top(offsets[1], read2)
+    if o1 == "forward" or o2 == "reverse":
+        return len(seen_reads), off1, off2, valid[0], valid[1], observed, False, n_chunks
+    if o1 == "reverse" or o2 == "forward":
+        return len(seen_reads), off2, off1, valid[1], valid[0], observed, True, n_chunks
+    raise ValueError("Unable to determine orientation of reads. Please check the input files.")
+
+
+def find_flanks(reads, start, bc_len, max_flank=10):
+    """Majority <=max_flank-nt flanks left and right of the barcode window, a
+    shorter flank displacing a longer one only when it is >3x as common
+    (heuristicount.py:382-425)."""
+    tallies = {"L": Counter(), "R": Counter()}
+    for read in reads:
+        left = read[start - max_flank:start] if start - max_flank >= 0 else read[0:start]
+        right = read[start + bc_len:start + bc_len + max_flank]
+        for n in range(len(left), 0, -1):
+            tallies["L"][left[-n:]] += 1
+        for n in range(len(right), 0, -1):
+            tallies["R"][right[:n]] += 1
+
+    def best(tally):
+        chosen = None
+        for n in range(max_flank, 0, -1):
+            cands = [s for s in tally if len(s) == n]
+            if not cands:
+                continue
+            top = max(cands, key=tally.__getitem__)
+            if chosen is None or tally[top] > 3 * tally[chosen]:
+                chosen = top
+        return chosen
+
+    return best(tallies["L"]), best(tallies["R"])
+
+
+# ------------------------------------------------------------------------------ hot path
+class ChunkCounter:
+    """Device-side state for process_chunk: the library in HBM plus the window
+    geometry.  One instance serves every chunk of a run."""
+
+    def __init__(self, barcodes, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
+                 device: int = 0, max_mismatch: int = 0, algo: str = "auto", fwd_set=None, rev_set=None):
+        self.k = bc_len
+        self.geom = (L_fwd_start, L_rev_start, L_fwd or "", R_fwd or "", L_rev or "", R_rev or "")
+        self.need_swap = need_swap
+        self.max_mismatch, self.algo = max_mismatch, algo
+        ordered = list(dict.fromkeys(barcodes))
+        # entries that cannot be 2-bit packed can only ever equal an ODD window (host string compare)
+        self.labels = [b for b in ordered if len(b) == bc_len and set(b) <= set("ACGT")]
+        self.fwd_set = fwd_set if fwd_set is not None else {self.geom[2] + b + self.geom[3] for b in ordered}
+        self.rev_set = rev_set if rev_set is not None else {self.geom[4] + rev_comp(b) + self.geom[5] for b in ordered}
+        if not self.labels:
+            raise ValueError("no pure-ACGT barcode of the stated length in the library")
+        self.lib = DeviceLibrary.from_strings(self.labels, device)
+        self.matcher = GpuMatcher(self.lib)
+
+    # windows of one mate: (packed, status, odd -> (in_lib, has_flanks, seq))
+    def _windows(self, reads, start, L, R, reverse, lib_set):
+        text, off = reads_to_text(reads)
+        packed, status = pack_windows(text, off, start, L, R, self.k, reverse)
+        odd = {}
+        for i in np.flatnonzero(status == N.WIN_ODD).tolist():
+            w = reads[i][start:start + len(L) + self.k + len(R)]
+            odd[i] = (w in lib_set, w[len(L):len(w) - len(R)])
+        return packed, status, odd
+
+    def process(self, chunk):
+        """(Counter, n_reads) for one chunk, bit-for-bit the reference's result
+        when max_mismatch == 0."""
+        a, b = chunk
+        reads1, reads2 = (b, a) if self.need_swap else (a, b)
+        s1, s2, Lf, Rf, Lr, Rr = self.geom
+        events = []  # (first read index, key, count)
+        if reads1 and reads2:
+            if len(reads1) != len(reads2):
+                raise ValueError("Length of reads1 and reads2 must be the same for paired-end data.")
+            n = len(reads1)
+            p1, st1, odd1 = self._windows(reads1, s1, Lf, Rf, False, self.fwd_set)
+            p2, st2, odd2 = self._windows(reads2, s2, Lr, Rr, True, self.rev_set)
+            ok = (st1 == N.WIN_OK) & (st2 == N.WIN_OK) & (p1 == p2)
+            flags = (~ok).astype(np.uint8)
+            res = self.matcher.match(p1, flags, self.max_mismatch, self.algo)
+            # pairs with a window that cannot be packed: exact string semantics on the host
+            for i in sorted(set(odd1) | set(odd2)):
+                x, y = reads1[i], reads2[i]
+                if "N" in x or "N" in y:
+                    continue
+                w1 = x[s1:s1 + len(Lf) + self.k + len(Rf)]
+                w2 = y[s2:s2 + len(Lr) + self.k + len(Rr)]
+                q1, q2 = w1[len(Lf):len(w1) - len(Rf)], w2[len(Lr):len(w2) - len(Rr)]
+                has = w1.startswith(Lf) and w1.endswith(Rf) and w2.startswith(Lr) and w2.endswith(Rr)
+                if q1 != rev_comp(q2) or not has:
+                    continue
+                key = q1 if (w1 in self.fwd_set and w2 in self.rev_set) else q1 + "*"
+                events.append((i, key, 1))
+            miss_words = p1
+        else:
+            reverse = not reads1
+            reads = reads2 if reverse else reads1
+            if not reads:
+                return Counter(), 0
+            n = len(reads)
+            start, L, R, lib_set = (s2, Lr, Rr, self.rev_set) if reverse else (s1, Lf, Rf, self.fwd_set)
+            packed, status, odd = self._windows(reads, start, L, R, reverse, lib_set)
+            res = self.matcher.match(packed, (status != N.WIN_OK).astype(np.uint8), self.max_mismatch, self.algo)
+            for i, (in_lib, seq) in odd.items():
+                if reverse:
+                    seq = rev_comp(seq)
+                events.append((i, seq if in_lib else seq + "*", 1))
+            miss_words = packed
+        # documented barcodes: counts and first read index come from the device
+        seen = np.flatnonzero(res.counts)
+        for g, c, f in zip(seen.tolist(), res.counts[seen].tolist(), res.first_seen[seen].tolist()):
+            events.append((f, self.labels[g], c))
+        # undocumented: group the missed (but flank-valid) windows
+        miss = np.flatnonzero(res.best_idx == N.IDX_MISS)
+        if miss.size:
+            words, first, cnt = np.unique(miss_words[miss], return_index=True, return_counts=True)
+            for s, f, c in zip(unpack_kmers(words, self.k), miss[first].tolist(), cnt.tolist()):
+                events.append((f, s + "*", c))
+        counts = Counter()
+        for _f, key, c in sorted(events, key=lambda e: e[0]):
+            counts[key] += c
+        return counts, n
+
+
+_COUNTERS = {}
+
+
+def process_chunk(chunk, bcs_with_flanks_fwd, bcs_with_flanks_rev, L_fwd_start, L_rev_start, bc_len, L_fwd, R_fwd,
+                  L_rev, R_rev, need_swap, device: int = 0):
+    """Drop-in for heuristicount.py:428-562 with the same 11 positional
+    arguments and the same (Counter, int) result; the set lookups and Counter
+    updates run on the GPU.  The device library is built from the flanked sets
+    on first use and cached for later chunks."""
+    key = (id(bcs_with_flanks_fwd), id(bcs_with_flanks_rev), len(bcs_with_flanks_fwd or ()),
+           len(bcs_with_flanks_rev or ()), L_fwd_start, L_rev_start, bc_len, L_fwd, R_fwd, L_rev, R_rev, need_swap,
+           device)
+    cc = _COUNTERS.get(key)
+    if cc is None:
+        Lf, Rf, Lr, Rr = (x or "" for x in (L_fwd, R_fwd, L_rev, R_rev))
+        if bcs_with_flanks_fwd:
+            barcodes = [s[len(Lf):len(s) - len(Rf)] for s in bcs_with_flanks_fwd]
+        else:
+            barcodes = [rev_comp(s[len(Lr):len(s) - len(Rr)]) for s in bcs_with_flanks_rev]
+        cc = ChunkCounter(barcodes, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
+                          device=device, fwd_set=bcs_with_flanks_fwd or set(), rev_set=bcs_with_flanks_rev or set())
+        if len(_COUNTERS) > 8:
+            _COUNTERS.clear()
+        _COUNTERS[key] = cc
+    return cc.process(chunk)
+
+
+# ------------------------------------------------------------------------------ driver
+def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch: int = 0):
+    """Everything main() computes, returned instead of printed: dict with
+    doc (first-seen ordered {barcode: count}), undoc Counter, total_reads, and
+    the discovered geometry."""
+    barcodes = read_fasta(fasta_file)
+    validate_barcodes(barcodes)
+    lengths = {len(b) for b in barcodes}
+    if len(lengths) != 1:
+        log.warning("One of the assumptions of this analysis is that all barcodes are the same length\n%s", FEEDBACK)
+        raise ValueError("All barcodes must be the same length")
+    bc_len = lengths.pop()
+    is_paired = bool(file2)
+    log.info("Sampling reads to identify diversity characteristics...")
+    (n_sampled, bc_start1, bc_start2, sample1, sample2, observed, need_swap, n_chunks) = \
+        sample_data(file1, file2, barcodes, is_paired)
+    log.info("Sampled %s diverse contexts in %s chunks and found %s barcodes in %s forward and %s reverse reads...",
+             f"{n_sampled:,}", n_chunks, f"{safe_len(observed):,}", f"{safe_len(sample1):,}", f"{safe_len(sample2):,}")
+    fwd_name = os.path.basename(file1)
+    rev_name = os.path.basename(file2) if file2 else None
+    if need_swap:
+        log.info("Swapping orientation...")
+        fwd_name, rev_name = rev_name, fwd_name
+    log.info("Identifying flanking sequences...")
+    if sample1 is not None:
+        L_fwd, R_fwd = find_flanks(sample1, bc_start1, bc_len)
+        L_fwd_start = bc_start1 - len(L_fwd) if L_fwd else 0
+    else:
+        L_fwd = R_fwd = L_fwd_start = None
+    if sample2 is not None:
+        L_rev, R_rev = find_flanks(sample2, bc_start2, bc_len)
+        L_rev_start = bc_start2 - len(L_rev) if L_rev else 0
+    else:
+        L_rev = R_rev = L_rev_start = None
+    # the two mates must show reverse-complementary flanks (heuristicount.py:641-688)
+    L_rev_rc = rev_comp(L_rev) if L_rev else None
+    R_rev_rc = rev_comp(R_rev) if R_rev else None
+    violated = False
+    if L_fwd and R_rev_rc:
+        m = min(len(L_fwd), len(R_rev_rc))
+        violated |= L_fwd[-m:] != R_rev_rc[:m]
+    if R_fwd and L_rev_rc:
+        m = min(len(R_fwd), len(L_rev_rc))
+        violated |= R_fwd[:m] != L_rev_rc[:m]
+    if violated:
+        log.warning("Expected complemtarity not found for flanking sequences...")
+        if L_fwd and R_rev_rc:
+            log.info("Left flank:  '%s' (./%s) != '%s' (./%s revcomp)", L_fwd, fwd_name, R_rev_rc, rev_name)
+        if R_fwd and L_rev_rc:
+            log.info("Right flank: '%s' (./%s) != '%s' (./%s revcomp)", R_fwd, fwd_name, L_rev_rc, rev_name)
+        raise ValueError("A critical error occurred: Flank complementarity violation")
+
+    log.info("Executing high-throughput read analysis...")
+    ordered = [b for b in read_fasta_ordered(fasta_file) if b in barcodes]
+    cc = ChunkCounter(ordered, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
+                      device=device, max_mismatch=max_mismatch)
+    doc, undoc = Counter(), Counter()
+    total_reads = 0
+    for chunk in read_in_chunks(file1, file2 if is_paired else None):
+        counts, n = cc.process(chunk)
+        total_reads += n
+        for barcode, c in counts.items():
+            (undoc if barcode.endswith("*") else doc)[barcode] += c
+    return dict(doc=doc, undoc=undoc, total_reads=total_reads, barcodes=barcodes, bc_len=bc_len,
+                bc_start1=bc_start1, bc_start2=bc_start2, flanks_fwd=(L_fwd, R_fwd), flanks_rev=(L_rev, R_rev),
+                need_swap=need_swap, forward_name=fwd_name, reverse_name=rev_name)
+
+
+def summary_lines(r, fasta_file):
+    """The fields of the reference's rich summary table (heuristicount.py:757-874) as plain text."""
+    doc, undoc, total = r["doc"], r["undoc"], r["total_reads"]
+    nd, nu = sum(doc.values()), sum(undoc.values())
+    frac = (lambda x: f"{(x / total if total else 0):.3f}")
+    rows = [("Barcodes", os.path.basename(fasta_file)), ("Forward Reads", r["forward_name"]),
+            ("Reverse Reads", r["reverse_name"]), ("Barcode Length", r["bc_len"]),
+            ("Forward Offset", r["bc_start1"]), ("Reverse Offset", r["bc_start2"]),
+            ("Forward Flanks", "{}...{}".format(*r["flanks_fwd"]) if any(r["flanks_fwd"]) else None),
+            ("Reverse Flanks", "{}...{}".format(*r["flanks_rev"]) if any(r["flanks_rev"]) else None),
+            ("Total Reads", f"{total:,}"), ("Documented Barcode Reads", f"{nd:,}"),
+            ("Undocumented Barcode Reads", f"{nu:,}"), ("Documented Barcodes", f"{len(r['barcodes']):,}"),
+            ("Seen Documented Barcodes", f"{len(doc):,}"),
+            ("Unseen Documented Barcodes", f"{len(r['barcodes']) - len(doc):,}"),
+            ("Uncocumented Barcodes", f"{len(undoc):,}"), ("Barcoded Reads Fraction", frac(nd + nu)),
+            ("Documented Fraction", frac(nd)), ("Undocumented Fraction", frac(nu))]
+    out = [f"{k:>30}  {v}" for k, v in rows if v]
+    for title, c in (("Documented", doc), ("Undocumented", undoc)):
+        top = c.most_common(min(5, len(c)))
+        out.append(f"{'Top %d %s Barcodes' % (len(top), title):>30}")
+        out += [f"{b:>30}  {n:,}" for b, n in top]
+    return out
+
+
+def main(args, device: int = 0):
+    """Same contract as heuristicount.main: log to stderr, `barcode<TAB>count`
+    for documented barcodes in first-seen order on stdout, errors logged and
+    swallowed (heuristicount.py:882-888)."""
+    log.info("Initializing heuristic barcode counting...")
+    try:
+        r = count_barcodes(args.fasta_file, args.file1, args.file2, device=device,
+                           max_mismatch=getattr(args, "mismatches", 0))
+        for line in summary_lines(r, args.fasta_file):
+            print(line, file=sys.stderr)
+        for barcode, count in r["doc"].items():
+            print("\t".join([barcode, str(count)]))
+    except ValueError as ve:
+        log.error("%s", ve)
+    except Exception as e:  # noqa: BLE001 - mirrors the reference
+        log.error("An unexpected error occurred: %s", e)
+
+
+def _cli():
+    p = argparse.ArgumentParser(description="Process Barcodes.")
+    p.add_argument("fasta_file", type=str, help="List or FASTA file containing barcodes.")
+    p.add_argument("file1", type=str, help="First reads file: FASTQ or raw reads.")
+    p.add_argument("file2", type=str, nargs="?", default=None, help="Second reads file: FASTQ or raw reads (optional).")
+    p.add_argument("--mismatches", type=int, default=0, help="count reads within this many substitutions (extension)")
+    p.add_argument("--device", type=int, default=0)
+    a = p.parse_args()
+    logging.basicConfig(level=logging.INFO, stream=sys.stderr, format="%(levelname)s %(message)s")
+    main(a, device=a.device)
+
+
+if __name__ == "__main__":
+    _cli()

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mreads/s through the <=2-mismatch 20-mer matcher.
+
+Workload (BASELINE.json configs[2]): library of 1e5 distinct
+20-mers, 1e8 synthetic reads PER GPU (0/1/2/3 substitutions 60/20/10/5 %, 5 %
+random), generated on the device by the seeded splitmix64 stream so they are
+resident in HBM before the timed region.  A step = one pass of the matcher over
+the rank's reads (best index + distance + n_best + per-guide counts + first-seen)
+followed, for N > 1, by the RCCL all-reduce of the count vector.
+
+Prints ONE JSON line on rank 0 (see the contract in DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = 13          # 8 B packed read in + 4 B best index + 1 B distance out
+HBM_PEAK_GBPS = 8000.0   # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured copy peak
+K = 20
+MAX_MM = 2
+G = 100_000
+
+
+def cpu_baseline(lib_packed, n_sample, seed):
+    """Oracle C brute force (string based) on the first n_sample reads of the stream."""
+    from barcoder_amd import encoding as E, synth as S
+    from oracle import oracle as orc
+    reads = S.reads(lib_packed, K, seed, 0, n_sample, 1)
+    ls, rs = E.unpack_kmers(lib_packed, K), E.unpack_kmers(reads, K)
+    orc.best_hit(ls[:1000], rs[:100], MAX_MM)  # warm up the library load
+    t0 = time.perf_counter()
+    ref = orc.best_hit(ls, rs, MAX_MM)
+    dt = time.perf_counter() - t0
+    return ref, reads, dict(value=n_sample / dt / 1e6, unit="Mreads/s", cores=orc.threads(), kind="port",
+                            sample=f"first {n_sample} reads of the same stream vs the full {len(ls)}-guide library, "
+                                   f"{dt:.1f} s, oracle/oracle.c brute force")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=float, default=1e8, help="reads per GPU")
+    ap.add_argument("--guides", type=int, default=G)
+    ap.add_argument("--algo", default="seed", choices=["seed", "brute"])
+    ap.add_argument("--max-mismatch", type=int, default=MAX_MM)
+    ap.add_argument("--cpu-sample", type=int, default=60_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from barcoder_amd import DeviceLibrary, GpuMatcher, synth as S
+    from barcoder_amd.dist import init_from_env
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    rank, world, local = init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    n = int(args.reads)
+    seed = 2
+
+    lib_packed = S.library(args.guides, K)
+    dl = DeviceLibrary(lib_packed, K, local)
+    m = GpuMatcher(dl)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    reads = torch.empty(n, dtype=torch.int64, device=dev)
+    best_idx = torch.empty(n, dtype=torch.int32, device=dev)
+    best_dist = torch.empty(n, dtype=torch.uint8, device=dev)
+    n_best = torch.empty(n, dtype=torch.uint8, device=dev)
+    counts32 = torch.zeros(args.guides, dtype=torch.int32, device=dev)
+    counts64 = torch.zeros(args.guides, dtype=torch.int64, device=dev)
+    first_seen = torch.full((args.guides,), -1, dtype=torch.int64, device=dev)  # 0xFFFF.. = unseen
+    first = rank * n  # global index of this rank's first read (weak scaling: n per GPU)
+    m.synth_reads_dev(seed, first, n, 1, reads.data_ptr(), stream)
+    torch.cuda.synchronize()
+
+    def step():
+        counts32.zero_()
+        m.match_dev(reads.data_ptr(), n, best_idx.data_ptr(), max_mismatch=args.max_mismatch, algo=args.algo,
+                    d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), d_counts=counts32.data_ptr(),
+                    d_first_seen=first_seen.data_ptr(), first_index=first, stream=stream)
+        counts64.copy_(counts32)
+        if world > 1:
+            dist.all_reduce(counts64, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel alone, HIP events on the launch stream (roofline.achieved)
+    k_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(3, args.steps),
+                      d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), d_counts=counts32.data_ptr(),
+                      d_first_seen=first_seen.data_ptr(), stream=stream)
+    achieved = n * ALGO_BYTES / (k_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        matched = int((best_idx >= 0).sum().item())
+        out = {
+            "metric": "Mreads/s matched, 20-mer <=2 mismatch",
+            "value": world * n * args.steps / dt / 1e6,
+            "unit": "Mreads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"20-mer <={args.max_mismatch}-mismatch best hit, {args.guides}-guide library, "
+                                   f"{n} reads per GPU (BASELINE configs[2])",
+                       "algo": args.algo, "reads_per_gpu": n, "guides": args.guides, "k": K,
+                       "max_mismatch": args.max_mismatch, "matched_fraction": matched / n,
+                       "outputs": "best_idx i32 + best_dist u8 + n_best u8 + counts u32[G] + first_seen u64[G]",
+                       "parallelism": f"reads sharded x{world}, counts all-reduced"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_match_seed" if args.algo == "seed" else "k_match_brute",
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_read": ALGO_BYTES},
+        }
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                t = json.load(open(tr))
+                if t.get("reads") == n and t.get("algo") == args.algo:
+                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu:
+            ref, sample_reads, cb = cpu_baseline(lib_packed, args.cpu_sample, seed)
+            got = best_idx[:args.cpu_sample].cpu().numpy()
+            cb["parity_on_sample"] = bool(np.array_equal(got, ref["best_idx"]))
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -202,15 +202,16 @@ int bc_pam_scan_host(int device, const uint64_t *h_bases, const uint32_t *h_inva
 int bc_sites_expand_dev(const uint32_t *d_bitmap, uint64_t n_words, uint32_t *d_pos,
                         uint64_t cap, uint64_t *d_n_out, uint32_t *d_tmp, void *stream);
 
-/* bc_windows_dev: k-mer at each listed position of a packed genome, on the
- * forward strand (strand=0: genome[p .. p+k)) or reverse-complemented
- * (strand=1: revcomp(genome[p .. p+k))).  Windows touching a non-ACGT base or
- * running past total_len get BC_SKIP_BIT (k<=31) and flag 1.
+/* bc_windows_dev: k-mer at p = pos[t] + offset for each listed position of a
+ * packed genome, on the forward strand (strand=0: genome[p .. p+k)) or
+ * reverse-complemented (strand=1: revcomp(genome[p .. p+k))).  Windows that
+ * touch a non-ACGT base, start before 0 or run past total_len get
+ * BC_SKIP_BIT (k<=31) and flag 1.
  * Feeds bc_match_dev / bc_match_all_dev (targets.py:354-410 hit records). */
 int bc_windows_dev(const uint64_t *d_bases, const uint32_t *d_invalid, uint64_t total_len,
                    const uint32_t *d_pos /* NULL = every position 0..n_pos-1 */,
-                   uint64_t n_pos, int k, int strand, uint64_t *d_out, uint8_t *d_flags,
-                   void *stream);
+                   uint64_t n_pos, int64_t offset, int k, int strand, uint64_t *d_out,
+                   uint8_t *d_flags, void *stream);
 
 /* ---- synthetic workloads (bench / tests) -----------
  * Counter-based splitmix64 streams, identical to barcoder_amd/synth.py.

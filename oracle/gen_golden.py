@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by RUNNING THE REFERENCE in this container.
+
+Run from the repo root:  python oracle/gen_golden.py
+Needs /root/reference (read-only); never runs on the GPU box.  The reference's
+modules are imported unmodified.  Two of their imports are absent offline and
+are not on the measured path: `zstandard` (only used to open .zst files,
+heuristicount.py:46,64) and `babel` (log-text number formatting, Logger.py:1);
+empty stand-in modules are registered for those two names so the import
+succeeds.  Nothing from the reference is copied: only inputs and the outputs it
+computed are written (JSON / TSV / FASTA data).
+
+Outputs
+  heuristicount_chunks.json.gz process_chunk I/O pairs (inputs + Counter, insertion order)
+  heuristicount_main.json.gz  main()/sample_data/find_flanks on small FASTQ scenarios
+  mismatch.json               mismatch.py y_pred values and generated variant tables
+  plasmids.fasta              the 4 shipped SnapGene plasmids as FASTA (reference DATA)
+  cn32_plasmid_rows.tsv       rows of Example_Libraries/CN-32-zmo.tsv on those plasmids
+  cn32_spacers.txt.gz         the `spacer` column of CN-32-zmo.tsv (library of config 1)
+  pam_guidefinder.json.gz     GuideFinder.find_guides_from_pam outputs on the plasmids
+"""
+import contextlib
+import gzip
+import io
+import json
+import os
+import random
+import struct
+import sys
+import tempfile
+import types
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    for name in ("zstandard",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    b, bn = types.ModuleType("babel"), types.ModuleType("babel.numbers")
+    bn.format_decimal = lambda x, **k: str(x)
+    b.numbers = bn
+    sys.modules.setdefault("babel", b)
+    sys.modules.setdefault("babel.numbers", bn)
+    sys.path.insert(0, REF)
+    import heuristicount
+    import mismatch
+    import PAMProcessor
+    return heuristicount, mismatch, PAMProcessor
+
+
+def rand_seq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+def mutate(rng, s, nsub):
+    s = list(s)
+    for p in rng.sample(range(len(s)), nsub):
+        s[p] = rng.choice([c for c in "ACGT" if c != s[p]])
+    return "".join(s)
+
+
+def rc(s):
+    return s[::-1].translate(str.maketrans("ATCGN", "TAGCN"))
+
+
+# ----------------------------------------------------------------------------- chunks
+def chunk_scenarios(h):
+    rng = random.Random(20240601)
+    out = []
+
+    def run(name, chunk, barcodes, L_fwd_start, L_rev_start, bc_len, L_fwd, R_fwd, L_rev, R_rev, need_swap):
+        fwd = {(L_fwd or "") + b + (R_fwd or "") for b in barcodes}
+        rev = {(L_rev or "") + rc(b) + (R_rev or "") for b in barcodes}
+        try:
+            counts, n = h.process_chunk(chunk, fwd, rev, L_fwd_start, L_rev_start, bc_len, L_fwd, R_fwd, L_rev,
+                                        R_rev, need_swap)
+            result = {"counts": list(counts.items()), "n": n}
+        except ValueError as e:
+            result = {"error": str(e)}
+        out.append({"name": name, "chunk": [chunk[0], chunk[1]], "barcodes": barcodes,
+                    "L_fwd_start": L_fwd_start, "L_rev_start": L_rev_start, "bc_len": bc_len, "L_fwd": L_fwd,
+                    "R_fwd": R_fwd, "L_rev": L_rev, "R_rev": R_rev, "need_swap": need_swap, **result})
+
+    for k in (20, 32, 12):
+        barcodes = list(dict.fromkeys(rand_seq(rng, k) for _ in range(120)))
+        Lf, Rf = "CCGGATTCAG", "GTTTTAGAGC"
+        pre = 5
+
+        def make_read(kind):
+            bc = rng.choice(barcodes)
+            if kind == "mm1":
+                bc = mutate(rng, bc, 1)
+            elif kind == "mm2":
+                bc = mutate(rng, bc, 2)
+            elif kind == "rand":
+                bc = rand_seq(rng, k)
+            r = rand_seq(rng, pre) + Lf + bc + Rf + rand_seq(rng, 6)
+            if kind == "N":
+                p = rng.randrange(len(r))
+                r = r[:p] + "N" + r[p + 1:]
+            elif kind == "badL":
+                r = rand_seq(rng, pre) + mutate(rng, Lf, 1) + bc + Rf + rand_seq(rng, 6)
+            elif kind == "badR":
+                r = rand_seq(rng, pre) + Lf + bc + mutate(rng, Rf, 2) + rand_seq(rng, 6)
+            elif kind == "short":
+                r = r[:pre + len(Lf) + rng.randrange(0, k + len(Rf))]
+            elif kind == "lower":
+                p = pre + len(Lf) + rng.randrange(k)
+                r = r[:p] + r[p].lower() + r[p + 1:]
+            elif kind == "odd":
+                p = pre + len(Lf) + rng.randrange(k)
+                r = r[:p] + "R" + r[p + 1:]
+            return r
+
+        kinds = ["ok"] * 60 + ["mm1"] * 10 + ["mm2"] * 5 + ["rand"] * 5 + ["N"] * 4 + ["badL"] * 4 + \
+                ["badR"] * 4 + ["short"] * 4 + ["lower"] * 2 + ["odd"] * 2
+        reads = [make_read(rng.choice(kinds)) for _ in range(500)] + [""]
+        run(f"fwd_flanks_k{k}", [reads, None], barcodes, pre, None, k, Lf, Rf, None, None, False)
+        # no flanks at all: every window of the right length counts (documented or '*')
+        run(f"fwd_noflanks_k{k}", [reads, None], barcodes, pre + len(Lf), None, k, None, None, None, None, False)
+        # only a left / only a right flank
+        run(f"fwd_Lonly_k{k}", [reads, None], barcodes, pre + 4, None, k, Lf[4:], None, None, None, False)
+        run(f"fwd_Ronly_k{k}", [reads, None], barcodes, pre + len(Lf), None, k, None, Rf[:5], None, None, False)
+        # reverse-orientation single-end: the chunk's reads arrive as reads2 via need_swap
+        rreads = [rc(r) if "N" not in r else r for r in reads]
+        Lr, Rr = rc(Rf), rc(Lf)
+        run(f"rev_single_k{k}", [rreads, None], barcodes, None, 6, k, None, None, Lr, Rr, True)
+        # paired-end, mates agree except for a few corrupted ones
+        mates = []
+        for r in reads:
+            m = rc(r) if "N" not in r else r
+            if rng.random() < 0.05 and len(m) > 30:
+                m = mutate(rng, m, 1)
+            mates.append(m)
+        run(f"paired_k{k}", [reads, mates], barcodes, pre, 6, k, Lf, Rf, Lr, Rr, False)
+        run(f"paired_swapped_k{k}", [mates, reads], barcodes, pre, 6, k, Lf, Rf, Lr, Rr, True)
+    # mate-count mismatch -> ValueError (heuristicount.py:483-486)
+    run("paired_len_mismatch", [["ACGT" * 10, "ACGT" * 10], ["ACGT" * 10]], ["ACGTACGTAC"] * 1, 0, 0, 10, None, None,
+        None, None, False)
+    return out
+
+
+# ----------------------------------------------------------------------------- main()
+def main_scenarios(h):
+    rng = random.Random(77)
+    out = []
+    tmp = tempfile.mkdtemp(prefix="bc_golden_")
+
+    def scenario(name, k, n_bc, n_reads, paired, reverse_single=False, ext="fastq", with_flanks=True, pre=5):
+        barcodes = list(dict.fromkeys(rand_seq(rng, k) for _ in range(n_bc)))
+        Lf, Rf = ("CCGGATTCAG", "GTTTTAGAGCTAGAAATAGC") if with_flanks else ("", "")
+        reads1, reads2 = [], []
+        for _ in range(n_reads):
+            u = rng.random()
+            bc = rng.choice(barcodes)
+            if u > 0.95:
+                bc = mutate(rng, bc, 2)
+            elif u > 0.85:
+                bc = mutate(rng, bc, 1)
+            if with_flanks:
+                r = rand_seq(rng, pre) + Lf + bc + Rf
+            else:
+                r = rand_seq(rng, pre) + bc + rand_seq(rng, 12)
+            if rng.random() < 0.01:
+                p = rng.randrange(len(r))
+                r = r[:p] + "N" + r[p + 1:]
+            reads1.append(r)
+            reads2.append(rc(r))
+        fa = os.path.join(tmp, f"{name}.fasta")
+        with open(fa, "w") as f:
+            for i, b in enumerate(barcodes):
+                f.write(f">bc{i}\n{b}\n")
+
+        def write_reads(path, reads):
+            with open(path, "w") as f:
+                for i, r in enumerate(reads):
+                    if ext == "fastq":
+                        f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+                    else:
+                        f.write(r + "\n")
+
+        f1 = os.path.join(tmp, f"{name}_1.{ext}")
+        f2 = os.path.join(tmp, f"{name}_2.{ext}") if paired else None
+        write_reads(f1, reads2 if reverse_single else reads1)
+        if paired:
+            write_reads(f2, reads2)
+        lib = h.read_fasta(fa)
+        sd = h.sample_data(f1, f2, lib, paired)
+        (n_novel, off1, off2, s1, s2, observed, need_swap, n_chunks) = sd
+        fl1 = h.find_flanks(s1, off1, k) if s1 is not None and off1 is not None else None
+        fl2 = h.find_flanks(s2, off2, k) if s2 is not None and off2 is not None and s2 else None
+        args = types.SimpleNamespace(fasta_file=fa, file1=f1, file2=f2)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            h.main(args)
+        out.append({
+            "name": name, "k": k, "barcodes": barcodes, "ext": ext, "paired": paired,
+            "reads1": reads2 if reverse_single else reads1, "reads2": reads2 if paired else None,
+            "sample_data": {"n_novel": n_novel, "offset1": off1, "offset2": off2, "n_valid1": len(s1 or ()),
+                            "n_valid2": len(s2 or ()), "n_observed": len(observed), "need_swap": need_swap,
+                            "num_chunks": n_chunks},
+            "flanks1": list(fl1) if fl1 else None, "flanks2": list(fl2) if fl2 else None,
+            "stdout": buf.getvalue(),
+        })
+
+    scenario("fwd_single", 20, 200, 3000, paired=False)
+    scenario("rev_single", 20, 200, 3000, paired=False, reverse_single=True)
+    scenario("paired", 20, 150, 2500, paired=True)
+    scenario("reads_format_k32", 32, 120, 2000, paired=False, ext="reads")
+    scenario("noflank", 20, 100, 2000, paired=False, with_flanks=False, pre=7)
+    return out
+
+
+# ----------------------------------------------------------------------------- mismatch.py
+def mismatch_cases(mm):
+    rng = random.Random(5)
+    # the weights are plain CSV data (feature,weight,...); mismatch.read_parameters (mismatch.py:38-46)
+    # builds the same {feature: weight} dict through pandas
+    import csv
+    with open(os.path.join(REF, "mismatch_parameters.csv")) as f:
+        params = {row["feature"]: float(row["weight"]) for row in csv.DictReader(f)}
+    pairs = []
+    for _ in range(40):
+        o = rand_seq(rng, 20)
+        v = mutate(rng, o, rng.choice([1, 1, 2, 3]))
+        pairs.append((o, v, mm.calculate_y_pred(o, v, params["GC_content"], params)))
+    pairs.append(("ACGTACGTACGTACGTACGT", "ACGTACGTACGTACGTACGT", None))
+    pairs.append(("ACGTACGTACGTACGTACGT", "ACGTACGTACGTACGTACGA",
+                  mm.calculate_y_pred("ACGTACGTACGTACGTACGT", "ACGTACGTACGTACGTACGA", params["GC_content"], params)))
+    tables = []
+    for _ in range(6):
+        sp = rand_seq(rng, 20)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            mm.generate_mismatches([sp], 0.0, 1.0, 0.1, params, sp)
+        tables.append({"spacer": sp, "tsv": buf.getvalue()})
+    return {"params": params, "pairs": pairs, "tables": tables}
+
+
+# ----------------------------------------------------------------------------- plasmids + PAM
+def read_snapgene(path):
+    """SnapGene .dna: packets `type(1B) len(4B BE) data`; packet 0 = flags(1B) + sequence."""
+    with open(path, "rb") as f:
+        data = f.read()
+    at = 0
+    while at < len(data):
+        t = data[at]
+        (ln,) = struct.unpack(">I", data[at + 1:at + 5])
+        body = data[at + 5:at + 5 + ln]
+        if t == 0:
+            return body[1:].decode("ascii").upper(), bool(body[0] & 1)
+        at += 5 + ln
+    raise ValueError("no sequence packet")
+
+
+class Rec:
+    """Duck-typed record for GuideFinder: .seq supports str() and .reverse_complement()."""
+
+    class _S(str):
+        def reverse_complement(self):
+            return Rec._S(rc(self))
+
+    def __init__(self, s):
+        self.seq = Rec._S(s)
+
+
+def pam_cases(P):
+    names = ["CP023716", "CP023717", "CP023718", "CP023719"]
+    seqs = {}
+    for nme in names:
+        s, circ = read_snapgene(os.path.join(REF, "GCA_003054575.1", nme + ".dna"))
+        seqs[nme + ".1"] = (s, circ)
+    with open(os.path.join(OUT, "plasmids.fasta"), "w") as f:
+        for k, (s, circ) in seqs.items():
+            f.write(f">{k} circular={int(circ)}\n")
+            for i in range(0, len(s), 80):
+                f.write(s[i:i + 80] + "\n")
+    recs = {k: Rec(s) for k, (s, _) in seqs.items()}
+    out = {}
+    for pam, L in (("NGG", 20), ("NGNC", 32), ("TTTN", 23), ("GGGGGGG", 20)):
+        for direction in ("downstream", "upstream"):
+            out[f"{pam}_{L}_{direction}"] = P.GuideFinder(recs, pam, direction, L).find_guides_from_pam()
+    with gzip.open(os.path.join(OUT, "pam_guidefinder.json.gz"), "wt") as f:
+        json.dump(out, f)
+    # rows of the shipped library that lie on these plasmids (known-answer table)
+    rows, spacers = [], []
+    with open(os.path.join(REF, "Example_Libraries", "CN-32-zmo.tsv")) as f:
+        header = f.readline()
+        cols = header.rstrip("\n").split("\t")
+        ci, si = cols.index("chr"), cols.index("spacer")
+        for line in f:
+            parts = line.rstrip("\n").split("\t")
+            spacers.append(parts[si])
+            if parts[ci] in seqs:
+                rows.append(line)
+    with open(os.path.join(OUT, "cn32_plasmid_rows.tsv"), "w") as f:
+        f.write(header)
+        f.writelines(rows)
+    with gzip.open(os.path.join(OUT, "cn32_spacers.txt.gz"), "wt") as f:
+        f.write("\n".join(spacers) + "\n")
+    return len(rows), len(spacers), len(set(spacers))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    h, mm, P = import_reference()
+    with gzip.open(os.path.join(OUT, "heuristicount_chunks.json.gz"), "wt") as f:
+        json.dump(chunk_scenarios(h), f)
+    with gzip.open(os.path.join(OUT, "heuristicount_main.json.gz"), "wt") as f:
+        json.dump(main_scenarios(h), f)
+    with open(os.path.join(OUT, "mismatch.json"), "w") as f:
+        json.dump(mismatch_cases(mm), f)
+    print("plasmid rows / spacers / unique:", pam_cases(P))
+
+
+if __name__ == "__main__":
+    main()
