@@ -28,8 +28,8 @@ CSRC = os.path.join(_HERE, "csrc")
 BC_OK, BC_EINVAL, BC_ENOMEM, BC_EHIP, BC_ENODEV, BC_ECAP = 0, -1, -2, -3, -4, -5
 IDX_MISS, IDX_SKIP, DIST_NONE = -1, -2, 255
 SKIP_BIT = np.uint64(1 << 63)
-ALGO_AUTO, ALGO_HASH, ALGO_SEED, ALGO_BRUTE = 0, 1, 2, 3
-ALGOS = {"auto": ALGO_AUTO, "hash": ALGO_HASH, "seed": ALGO_SEED, "brute": ALGO_BRUTE}
+ALGO_AUTO, ALGO_HASH, ALGO_SEED, ALGO_BRUTE, ALGO_SEED_CSR = 0, 1, 2, 3, 4
+ALGOS = {"auto": ALGO_AUTO, "hash": ALGO_HASH, "seed": ALGO_SEED, "brute": ALGO_BRUTE, "seed_csr": ALGO_SEED_CSR}
 WIN_OK, WIN_SKIP, WIN_ODD = 0, 1, 2
 
 u8p, u32p, u64p, i32p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32))

@@ -42,6 +42,25 @@ struct SeedParams {
     const uint32_t* gidx[MAX_SEG];  // [G] guide index of each entry
 };
 
+// Slab form of the same index (k_match_slab): every bucket is a fixed-size
+// slab of 8-byte entries {rest-of-key, guide index} at a computable address, so
+// one bucket visit is one 64/128-byte L2 request shared by LPR lanes and needs
+// neither an offset lookup nor a separate index lookup.  The last entry of a
+// slab is a link {next slab, LINK} to an overflow slab appended after the
+// primaries.  Requires 2*(k - slen) <= 32 so that the rest fits one dword.
+constexpr uint32_t SLAB_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t SLAB_LINK = 0xFFFFFFFEu;
+struct SlabTable {
+    const uint2* slabs;
+    uint32_t start, slen, half;   // seed position / length; half = k - slen
+    uint32_t log2S;               // entries per slab (incl. the link entry)
+    uint32_t dmask[MAX_SEG];      // dmask[t]: seed t's bases in rest coordinates (t < this table)
+};
+struct SlabParams {
+    int nseg;
+    SlabTable t[MAX_SEG];
+};
+
 }  // namespace bc
 
 struct bc_lib {
@@ -58,5 +77,8 @@ struct bc_lib {
     uint32_t* d_slots32 = nullptr;
     // seed indices, entry d for max_mismatch = d
     bc::SeedParams seed[bc::MAX_SEG];
+    bc::SlabParams slab[bc::MAX_SEG];
+    bool slab_ok[bc::MAX_SEG] = {false, false, false, false};
+    const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> owned;      // every device allocation, for destroy
 };

@@ -12,6 +12,11 @@
 //                   every candidate is verified with XOR + popcount.
 //   k_match_brute : any d.  Guide table tiled through LDS, lane = read, all
 //                   pairs XOR + popcount.  VALU-bound; the in-GPU cross-check.
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "bc_device.h"
 
 using namespace bc;
@@ -22,8 +27,8 @@ struct MatchOut {
     int32_t* best_idx;
     uint8_t* best_dist;
     uint8_t* n_best;
-    uint32_t* counts;
-    uint64_t* first_seen;
+    uint32_t* counts;      // NULL when the tally is done by k_hist afterwards
+    uint64_t* first_seen;  // idem
     uint64_t base;
 };
 
@@ -227,6 +232,239 @@ __global__ __launch_bounds__(BLOCK) void k_match_all(SeedParams sp, const uint64
 }
 
 // ---------------------------------------------------------------------------
+// K3a': pigeonhole seed index in slab form.  LPR lanes share one read: a bucket
+// visit is ONE wave-level load in which the LPR lanes of a read fetch adjacent
+// 16-byte pieces of the same slab (one L2 request per 64/128 bytes), entries
+// carry the guide index, and a read stops after the first table once it has an
+// exact hit (guides are distinct, so nothing can tie with distance 0).
+// ---------------------------------------------------------------------------
+// cross-lane helpers inside a group of LPR lanes.  For LPR = 4 a group is a DPP
+// quad: one v_mov_dpp per exchange instead of a ds_bpermute round trip.
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int LPR>
+__device__ __forceinline__ uint32_t grp_min(uint32_t v) {
+    if constexpr (LPR == 4) {
+        v = min(v, quad_perm<0xB1>(v));  // lanes ^1
+        v = min(v, quad_perm<0x4E>(v));  // lanes ^2
+    } else {
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m));
+    }
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ uint32_t grp_sum(uint32_t v) {
+    if constexpr (LPR == 4) {
+        v += quad_perm<0xB1>(v);
+        v += quad_perm<0x4E>(v);
+    } else {
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m);
+    }
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ uint32_t grp_last(uint32_t v, int last_lane) {  // value held by the group's last lane
+    if constexpr (LPR == 4) return quad_perm<0xFF>(v);
+    else return (uint32_t)__shfl((int)v, last_lane);
+}
+
+constexpr int SLAB_MAX_LOG2S = 5;  // <= 32 entries (256 B) per slab; longer buckets chain
+
+// Running result of one lane: key = dist << 24 | guide index (one v_min keeps the
+// minimum distance and, among ties, the lowest index; the slab layout is only
+// built for libraries below 2^24 guides), cnt = per-distance candidate counts in
+// 16-bit fields, cur = min(max_mm, best distance) = the acceptance threshold.
+struct SlabBest {
+    uint32_t key;
+    uint32_t cur;
+    uint64_t cnt;
+};
+
+// all of a slab's pieces for this lane, issued back to back (memory-level
+// parallelism: the wave has MAXSTEP x 16 requests in flight, not 16)
+template <int LPR, int MAXSTEP>
+__device__ __forceinline__ void slab_load(const SlabTable& T, uint32_t slab, int sub, uint4 (&v)[MAXSTEP]) {
+    const uint4* p = reinterpret_cast<const uint4*>(T.slabs + ((size_t)slab << T.log2S));
+    const int nstep = (1 << T.log2S) / (2 * LPR);
+#pragma unroll
+    for (int st = 0; st < MAXSTEP; ++st)
+        if (st < nstep) v[st] = p[st * LPR + sub];
+}
+
+// verify the loaded entries; returns the chained slab (0 = none), identical in
+// all LPR lanes of the group.  Hot path per entry: xor, shift, or+and, popcount,
+// compare.  Empty slots hold rest = 0 and are rejected in the (rare) accept path.
+template <int LPR, int MAXSTEP, int S>
+__device__ __forceinline__ uint32_t slab_scan(const SlabTable& T, const uint4 (&v)[MAXSTEP], uint32_t rest,
+                                              SlabBest& b, int last_lane) {
+    const int nstep = (1 << T.log2S) / (2 * LPR);
+    const uint32_t hmask = (1u << T.half) - 1u;
+    uint32_t lz = 0, lw = 0;
+#pragma unroll
+    for (int st = 0; st < MAXSTEP; ++st) {
+        if (st < nstep) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t er = e ? v[st].z : v[st].x, gi = e ? v[st].w : v[st].y;
+                const uint32_t x = rest ^ er;
+                const uint32_t mm = (x | (x >> T.half)) & hmask;
+                const uint32_t d = __popc(mm);
+                if (d <= b.cur) {
+                    bool ok = gi < SLAB_LINK;
+#pragma unroll
+                    for (int t = 0; t < S; ++t) ok = ok && ((mm & T.dmask[t]) != 0u);  // not met through an earlier seed
+                    if (ok) {
+                        b.key = min(b.key, (d << 24) | gi);
+                        b.cur = d;  // d <= cur
+                        b.cnt += 1ull << (16 * d);
+                    }
+                }
+            }
+            if (st == nstep - 1) { lz = v[st].z; lw = v[st].w; }
+        }
+    }
+    // the link is the last entry of the slab: second entry of the last lane's last piece
+    lw = grp_last<LPR>(lw, last_lane);
+    lz = grp_last<LPR>(lz, last_lane);
+    return (lw == SLAB_LINK) ? lz : 0u;
+}
+
+// drop the seed field from both planes: rest = lo' | hi' << half  (k <= 28 here, so no shift reaches 32)
+__device__ __forceinline__ uint32_t slab_rest(const SlabTable& T, uint32_t rlo, uint32_t rhi) {
+    const uint32_t below = (1u << T.start) - 1u;
+    const uint32_t sh = T.start + T.slen;
+    const uint32_t lo_r = (rlo & below) | ((rlo >> sh) << T.start);
+    const uint32_t hi_r = (rhi & below) | ((rhi >> sh) << T.start);
+    return lo_r | (hi_r << T.half);
+}
+
+template <int LPR, int NSEG>
+__global__ __launch_bounds__(BLOCK) void k_match_slab(const SlabParams* __restrict__ spp,
+                                                      const uint64_t* __restrict__ reads,
+                                                      const uint8_t* __restrict__ flags, uint64_t n,
+                                                      int k, uint64_t kmask, int max_mm, MatchOut o) {
+    // table descriptors stay in memory (scalar loads on demand): passing the
+    // struct by value made the compiler spill SGPRs through v_writelane/v_readlane
+    const SlabParams& sp = *spp;
+    constexpr int MAXSTEP = (1 << SLAB_MAX_LOG2S) / (2 * LPR);
+    const int sub = threadIdx.x & (LPR - 1);
+    const uint64_t stride = (uint64_t)gridDim.x * (BLOCK / LPR);
+    const int last_lane = (threadIdx.x & 63) | (LPR - 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * (BLOCK / LPR) + (threadIdx.x / LPR); i < n; i += stride) {
+        uint64_t r = reads[i];
+        if (read_skipped(r, flags, i, k)) {
+            if (sub == 0) emit(o, i, BC_IDX_SKIP, BC_DIST_NONE, 0);
+            continue;
+        }
+        r &= kmask;
+        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+        SlabBest b{0xFFFFFFFFu, (uint32_t)max_mm, 0ull};
+        // round 0: the first table alone (an exact hit ends the search: guides are distinct)
+        uint4 v0[MAXSTEP];
+        {
+            const SlabTable& T = sp.t[0];
+            const uint32_t rest = slab_rest(T, rlo, rhi);
+            uint32_t slab = seed_value(rlo, rhi, T.start, T.slen);
+            do {
+                slab_load<LPR, MAXSTEP>(T, slab, sub, v0);
+                slab = slab_scan<LPR, MAXSTEP, 0>(T, v0, rest, b, last_lane);
+            } while (slab != 0u);
+        }
+        b.cur = grp_min<LPR>(b.cur);
+        if (NSEG > 1 && b.cur != 0u) {
+            // round 1: every remaining table's primary slab is requested before any is scanned
+            uint4 vr[NSEG > 1 ? NSEG - 1 : 1][MAXSTEP];
+#pragma unroll
+            for (int s = 1; s < NSEG; ++s)
+                slab_load<LPR, MAXSTEP>(sp.t[s], seed_value(rlo, rhi, sp.t[s].start, sp.t[s].slen), sub, vr[s - 1]);
+            auto round1 = [&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                const SlabTable& T = sp.t[s];
+                const uint32_t rest = slab_rest(T, rlo, rhi);
+                uint32_t slab = slab_scan<LPR, MAXSTEP, s>(T, vr[s - 1], rest, b, last_lane);
+                while (slab != 0u) {  // overflow chain (rare)
+                    slab_load<LPR, MAXSTEP>(T, slab, sub, v0);
+                    slab = slab_scan<LPR, MAXSTEP, s>(T, v0, rest, b, last_lane);
+                }
+                b.cur = grp_min<LPR>(b.cur);
+            };
+            if constexpr (NSEG > 1) round1(std::integral_constant<int, 1>{});
+            if constexpr (NSEG > 2) round1(std::integral_constant<int, 2>{});
+            if constexpr (NSEG > 3) round1(std::integral_constant<int, 3>{});
+        }
+        // combine the LPR partial results: min key = (min distance, lowest index)
+        const uint32_t key = grp_min<LPR>(b.key);
+        const uint32_t md = key >> 24;
+        const uint32_t mine = (md <= 3u) ? (uint32_t)((b.cnt >> (16 * (md & 3u))) & 0xFFFFu) : 0u;
+        const uint32_t nb = grp_sum<LPR>(mine);
+        if (sub == 0) {
+            if (key != 0xFFFFFFFFu) emit(o, i, (int32_t)(key & 0xFFFFFFu), md, nb);
+            else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5: per-guide histogram + first-seen from best_idx, privatised in LDS.
+// Scattered device-scope atomics leave the L2 (one 32-byte memory-side write
+// each, measured: profiles/r01_v1_*); instead each workgroup owns a range of
+// HIST_R guides in LDS (count + first read index), sweeps a slice of best_idx,
+// and flushes its range with contiguous atomics.  grid = passes x slices.
+// ---------------------------------------------------------------------------
+constexpr int HIST_R = 20480;          // guides per pass: 2 x 4 B x 20480 = 160 KiB of LDS
+constexpr int HIST_BLOCK = 1024;
+
+__global__ __launch_bounds__(HIST_BLOCK) void k_hist(const int32_t* __restrict__ best_idx, uint64_t n,
+                                                     uint32_t G, int slices, uint32_t* __restrict__ counts,
+                                                     uint64_t* __restrict__ first_seen, uint64_t base) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* cnt = lds;
+    uint32_t* fs = lds + HIST_R;
+    const int pass = blockIdx.x / slices, slice = blockIdx.x % slices;
+    const uint32_t lo = (uint32_t)pass * HIST_R;
+    const uint32_t width = min((uint32_t)HIST_R, G - lo);
+    for (uint32_t j = threadIdx.x; j < width; j += HIST_BLOCK) { cnt[j] = 0; fs[j] = 0xFFFFFFFFu; }
+    __syncthreads();
+    // slice of reads, 4 indices (16 B) per lane per step
+    const uint64_t n4 = n / 4;
+    const uint64_t per = (n4 + slices - 1) / slices;
+    const uint64_t a = (uint64_t)slice * per, e = min(n4, a + per);
+    const int4* p4 = reinterpret_cast<const int4*>(best_idx);
+    for (uint64_t q = a + threadIdx.x; q < e; q += HIST_BLOCK) {
+        int4 v = p4[q];
+        const int32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t g = (uint32_t)vv[c] - lo;  // negative sentinels wrap far above width
+            if (g < width) {
+                atomicAdd(&cnt[g], 1u);
+                if (first_seen) atomicMin(&fs[g], (uint32_t)(q * 4 + c));
+            }
+        }
+    }
+    if (slice == slices - 1)  // tail reads (n % 4)
+        for (uint64_t i = n4 * 4 + threadIdx.x; i < n; i += HIST_BLOCK) {
+            uint32_t g = (uint32_t)best_idx[i] - lo;
+            if (g < width) {
+                atomicAdd(&cnt[g], 1u);
+                if (first_seen) atomicMin(&fs[g], (uint32_t)i);
+            }
+        }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < width; j += HIST_BLOCK) {
+        uint32_t c = cnt[j];
+        if (c) {
+            if (counts) atomicAdd(&counts[lo + j], c);
+            if (first_seen) atomicMin((unsigned long long*)&first_seen[lo + j], (unsigned long long)(base + fs[j]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3b: brute force.  Guide tile in LDS (broadcast reads), RPT reads per lane
 // held in registers, 5 VALU per pair (xor, xor, or, bcnt, cmp).
 // ---------------------------------------------------------------------------
@@ -317,6 +555,69 @@ int floor_log4(uint32_t g) {
     return l;
 }
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// slab form of table s of the index for max_mismatch = d (see bc_device.h)
+int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off,
+                     const std::vector<uint64_t>& keys, const std::vector<uint32_t>& gidx) {
+    const SeedParams& cs = lib->seed[d];
+    SlabParams& sl = lib->slab[d];
+    if (s == 0) { sl.nseg = cs.nseg; lib->slab_ok[d] = true; }
+    const int start = cs.start[s], slen = cs.slen[s], half = lib->k - slen;
+    if (2 * half > 32 || lib->G >= (1u << 24) || lib->k > 28) { lib->slab_ok[d] = false; return BC_OK; }  // rest: one dword; index: 24 bits
+    if (!lib->slab_ok[d]) return BC_OK;
+    const uint32_t nb = 1u << (2 * slen);
+    // slab size: room for the mean bucket plus ~2 sigma, at least 8 entries (64 B)
+    const double mu = (double)lib->G / nb;
+    int log2S = 3;
+    while (log2S < SLAB_MAX_LOG2S && (double)((1 << log2S) - 1) < mu + 2.0 * sqrt(mu) + 1.0) ++log2S;
+    log2S = std::max(log2S, env_int("BC_SLAB_MIN_LOG2S", 3));
+    log2S = std::min(std::min(SLAB_MAX_LOG2S, env_int("BC_SLAB_MAX_LOG2S", SLAB_MAX_LOG2S)), log2S);
+    const uint32_t S = 1u << log2S;
+    std::vector<uint2> slabs((size_t)nb << log2S, make_uint2(0u, SLAB_EMPTY));
+    const uint32_t below = (1u << start) - 1u;
+    const int sh = start + slen;
+    auto rest_of = [&](uint64_t g) {
+        uint32_t lo = (uint32_t)g, hi = (uint32_t)(g >> 32);
+        uint32_t lo_r = (lo & below) | ((sh >= 32 ? 0u : (lo >> sh)) << start);
+        uint32_t hi_r = (hi & below) | ((sh >= 32 ? 0u : (hi >> sh)) << start);
+        return lo_r | (half >= 32 ? 0u : (hi_r << half));
+    };
+    for (uint32_t b = 0; b < nb; ++b) {
+        size_t cur = b;
+        uint32_t pos = 0;
+        for (uint32_t j = off[b]; j < off[b + 1]; ++j) {
+            if (pos == S - 1) {  // chain an overflow slab
+                size_t nxt = slabs.size() >> log2S;
+                if (nxt >= 0xFFFFFFFEull) { set_error("slab index overflow"); return BC_EINVAL; }
+                slabs.resize(slabs.size() + S, make_uint2(0u, SLAB_EMPTY));
+                slabs[(cur << log2S) + S - 1] = make_uint2((uint32_t)nxt, SLAB_LINK);
+                cur = nxt;
+                pos = 0;
+            }
+            slabs[(cur << log2S) + pos++] = make_uint2(rest_of(keys[j]), gidx[j]);
+        }
+    }
+    uint2* d_slabs;
+    int rc = dev_upload(lib, slabs, &d_slabs);
+    if (rc != BC_OK) return rc;
+    SlabTable& T = sl.t[s];
+    T.slabs = d_slabs; T.start = (uint32_t)start; T.slen = (uint32_t)slen; T.half = (uint32_t)half;
+    T.log2S = (uint32_t)log2S;
+    for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
+        T.dmask[t] = (t < s) ? (((1u << cs.slen[t]) - 1u) << cs.start[t]) : 0u;
+    if (s == cs.nseg - 1) {  // descriptor block for the kernel (read through scalar loads)
+        std::vector<SlabParams> one(1, sl);
+        SlabParams* d_sp;
+        if ((rc = dev_upload(lib, one, &d_sp)) != BC_OK) return rc;
+        lib->d_slab[d] = d_sp;
+    }
+    return BC_OK;
+}
+
 int build_seed_index(bc_lib* lib, int d) {
     SeedParams& sp = lib->seed[d];
     const int k = lib->k;
@@ -353,6 +654,7 @@ int build_seed_index(bc_lib* lib, int d) {
         if ((rc = dev_upload(lib, keys, &d_keys)) != BC_OK) return rc;
         if ((rc = dev_upload(lib, gidx, &d_gidx)) != BC_OK) return rc;
         sp.off[s] = d_off; sp.keys[s] = d_keys; sp.gidx[s] = d_gidx;
+        if ((rc = build_slab_table(lib, d, s, off, keys, gidx)) != BC_OK) return rc;
     }
     return BC_OK;
 }
@@ -402,11 +704,46 @@ int build_hash(bc_lib* lib) {
 }
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
+                        int max_mm, int algo, const MatchOut& o, hipStream_t st);
+
+int launch_hist(bc_lib* lib, const MatchOut& o, uint64_t n, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds_bytes = (size_t)HIST_R * 2 * sizeof(uint32_t);
+    if (!attr_set) {
+        BC_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    const int passes = (int)((lib->G + HIST_R - 1) / HIST_R);
+    const int slices = std::max(1, 256 / passes);
+    const uint64_t CH = 0xFFFFFFF0ull;  // first-seen is tracked as a 32-bit offset inside a sweep
+    for (uint64_t a = 0; a < n; a += CH) {
+        uint64_t m = std::min(CH, n - a);
+        hipLaunchKernelGGL(k_hist, dim3(passes * slices), dim3(HIST_BLOCK), lds_bytes, st, o.best_idx + a, m, lib->G,
+                           slices, o.counts, o.first_seen, o.base + a);
+    }
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
 
 int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
-                 int max_mm, int algo, const MatchOut& o, hipStream_t st) {
+                 int max_mm, int algo, const MatchOut& o_in, hipStream_t st) {
     if (n == 0) return BC_OK;
     if (algo == BC_ALGO_AUTO) algo = (max_mm == 0) ? BC_ALGO_HASH : BC_ALGO_SEED;
+    // tally: in-kernel global atomics for small launches, LDS histogram sweep otherwise
+    MatchOut o = o_in;
+    const int tally_mode = env_int("BC_TALLY", 0);  // 0 auto, 1 atomics, 2 LDS histogram
+    const bool want_tally = o.counts || o.first_seen;
+    bool use_hist = want_tally && aligned16(o.best_idx) && (tally_mode == 2 || (tally_mode == 0 && n >= 4ull * lib->G));
+    if (use_hist) { o.counts = nullptr; o.first_seen = nullptr; }
+    int rc = launch_match_kernel(lib, d_reads, d_flags, n, max_mm, algo, o, st);
+    if (rc != BC_OK) return rc;
+    if (use_hist) return launch_hist(lib, o_in, n, st);
+    return BC_OK;
+}
+
+int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
+                        int max_mm, int algo, const MatchOut& o, hipStream_t st) {
     if (algo == BC_ALGO_HASH) {
         if (max_mm != 0) {
             set_error("bc_match: BC_ALGO_HASH requires max_mismatch == 0");
@@ -432,13 +769,31 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
                 hipLaunchKernelGGL((k_match_hash<false, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
                                    lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
         }
-    } else if (algo == BC_ALGO_SEED) {
+    } else if (algo == BC_ALGO_SEED || algo == BC_ALGO_SEED_CSR) {
         if (max_mm < 0 || max_mm >= MAX_SEG) {
-            set_error("bc_match: BC_ALGO_SEED supports 0 <= max_mismatch <= %d", MAX_SEG - 1);
+            set_error("bc_match: the seed index supports 0 <= max_mismatch <= %d", MAX_SEG - 1);
             return BC_EINVAL;
         }
-        hipLaunchKernelGGL(k_match_seed, dim3(grid_for(n)), dim3(BLOCK), 0, st, lib->seed[max_mm], d_reads,
-                           d_flags, n, lib->k, lib->kmask, max_mm, o);
+        if (algo == BC_ALGO_SEED && lib->slab_ok[max_mm]) {
+            const int lpr = env_int("BC_SLAB_LPR", 4);
+            uint32_t minS = 1u << SLAB_MAX_LOG2S;
+            for (int s = 0; s < lib->slab[max_mm].nseg; ++s) minS = std::min(minS, 1u << lib->slab[max_mm].t[s].log2S);
+            const SlabParams* dp = lib->d_slab[max_mm];
+            const bool l8 = (lpr == 8 && minS >= 16);
+#define BC_SLAB_LAUNCH(LPR_, NSEG_)                                                                          \
+    hipLaunchKernelGGL((k_match_slab<LPR_, NSEG_>), dim3(grid_for(n * LPR_)), dim3(BLOCK), 0, st, dp, d_reads, \
+                       d_flags, n, lib->k, lib->kmask, max_mm, o)
+            switch (lib->slab[max_mm].nseg) {
+                case 1: if (l8) BC_SLAB_LAUNCH(8, 1); else BC_SLAB_LAUNCH(4, 1); break;
+                case 2: if (l8) BC_SLAB_LAUNCH(8, 2); else BC_SLAB_LAUNCH(4, 2); break;
+                case 3: if (l8) BC_SLAB_LAUNCH(8, 3); else BC_SLAB_LAUNCH(4, 3); break;
+                default: if (l8) BC_SLAB_LAUNCH(8, 4); else BC_SLAB_LAUNCH(4, 4); break;
+            }
+#undef BC_SLAB_LAUNCH
+        } else {
+            hipLaunchKernelGGL(k_match_seed, dim3(grid_for(n)), dim3(BLOCK), 0, st, lib->seed[max_mm], d_reads,
+                               d_flags, n, lib->k, lib->kmask, max_mm, o);
+        }
     } else if (algo == BC_ALGO_BRUTE) {
         if (max_mm < 0 || max_mm > lib->k) {
             set_error("bc_match: bad max_mismatch %d", max_mm);

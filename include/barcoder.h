@@ -54,8 +54,10 @@ extern "C" {
 /* match algorithms */
 #define BC_ALGO_AUTO 0  /* exact hash when max_mismatch==0, else seed index */
 #define BC_ALGO_HASH 1  /* d = 0 only: open-addressing table in L2          */
-#define BC_ALGO_SEED 2  /* pigeonhole seed index + verify, d <= 3           */
+#define BC_ALGO_SEED 2  /* pigeonhole seed index + verify, d <= 3 (slab    */
+                        /* layout when the k-mer allows it, else CSR)       */
 #define BC_ALGO_BRUTE 3 /* LDS-tiled all-pairs XOR+popcount, any d          */
+#define BC_ALGO_SEED_CSR 4 /* the seed index in its CSR layout, always      */
 
 /* window status written by bc_pack_windows */
 #define BC_WIN_OK 0       /* flanks present, k-mer packed                        */

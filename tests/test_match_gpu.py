@@ -26,6 +26,7 @@ def _check(res, ref):
 
 @pytest.mark.parametrize("k", [20, 32, 12])
 @pytest.mark.parametrize("algo,max_mm", [("hash", 0), ("seed", 0), ("seed", 1), ("seed", 2), ("seed", 3),
+                                         ("seed_csr", 0), ("seed_csr", 2), ("seed_csr", 3),
                                          ("brute", 0), ("brute", 2), ("brute", 4)])
 def test_match_parity(gpu_device, oracle, algo, max_mm, k):
     G, n = 3000, 20011
@@ -35,6 +36,22 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
     ref = oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads & E.kmer_mask(k), k), max_mm, skip=flags, base=5)
     _check(res, ref)
     assert (res.best_idx >= 0).sum() > n // 2
+
+
+@pytest.mark.parametrize("env", [{"BC_TALLY": "1"}, {"BC_TALLY": "2"}, {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4"},
+                                 {"BC_SLAB_MIN_LOG2S": "3"}, {"BC_SLAB_MIN_LOG2S": "6"}])
+def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
+    """Tally by global atomics vs LDS histogram, 4 vs 8 lanes per read, slab
+    sizes with and without overflow chains: identical outputs."""
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    k, G, n = 20, 6000, 30001
+    lib, reads, flags = _case(G, n, k, 1, seed=31)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    ls, rs = E.unpack_kmers(lib, k), E.unpack_kmers(reads & E.kmer_mask(k), k)
+    for d in (0, 1, 2, 3):
+        res = GpuMatcher(dl).match(reads, flags, max_mismatch=d, algo="seed", first_index=11)
+        _check(res, oracle.best_hit(ls, rs, d, skip=flags, base=11))
 
 
 def test_dense_library_ties(gpu_device, oracle):
@@ -52,7 +69,7 @@ def test_dense_library_ties(gpu_device, oracle):
     dl = DeviceLibrary(lib, k, gpu_device)
     m = GpuMatcher(dl)
     ls, rs = E.unpack_kmers(lib, k), E.unpack_kmers(reads, k)
-    for algo, d in [("seed", 1), ("seed", 2), ("seed", 3), ("brute", 2), ("hash", 0)]:
+    for algo, d in [("seed", 1), ("seed", 2), ("seed", 3), ("seed_csr", 2), ("brute", 2), ("hash", 0)]:
         res = m.match(reads, None, max_mismatch=d, algo=algo)
         _check(res, oracle.best_hit(ls, rs, d))
     assert res is not None
