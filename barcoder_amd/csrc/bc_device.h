@@ -80,5 +80,10 @@ struct bc_lib {
     bc::SlabParams slab[bc::MAX_SEG];
     bool slab_ok[bc::MAX_SEG] = {false, false, false, false};
     const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
+    // miss queue between the exact stage and the seed stage (grown on demand)
+    uint64_t* q_reads = nullptr;
+    uint32_t* q_idx = nullptr;
+    uint32_t* q_count = nullptr;       // [MAX_BLOCKS] entries appended per workgroup
+    uint64_t q_cap = 0;
     std::vector<void*> owned;      // every device allocation, for destroy
 };

@@ -13,6 +13,7 @@
 //   k_match_brute : any d.  Guide table tiled through LDS, lane = read, all
 //                   pairs XOR + popcount.  VALU-bound; the in-GPU cross-check.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -87,13 +88,56 @@ __device__ __forceinline__ int32_t hash_lookup(uint64_t key, const uint64_t* __r
     return BC_IDX_MISS;
 }
 
+// Reads the exact-match stage cannot place are handed to the seed-index stage
+// through a queue.  A single global append counter saturates at ~88 appends/us
+// (measured: 6.3 ms per 33M-read tile), so every workgroup owns a private
+// region of the queue and counts its appends in LDS; stage 2 runs the same grid
+// and workgroup b drains region b.
+struct MissQueue {
+    uint64_t* reads;       // [grid][region_cap] packed read (masked)
+    uint32_t* idx;         // [grid][region_cap] index of the read inside the current tile
+    uint32_t* count;       // [grid] appended entries per workgroup; NULL = no queue (a miss is final)
+    uint32_t region_cap;
+};
+
+template <int VEC>
+__device__ __forceinline__ void queue_push(const MissQueue& q, uint32_t* lds_count, const bool (&push)[VEC],
+                                           const uint64_t (&r)[VEC], const uint32_t (&i)[VEC]) {
+    unsigned long long mask[VEC];
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mask[j] = __ballot(push[j]); total += (uint32_t)__popcll(mask[j]); }
+    if (total == 0u) return;
+    uint32_t base = 0;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned long long active = __ballot(true);
+    const int leader = __ffsll((long long)active) - 1;
+    if ((int)lane == leader) base = atomicAdd(lds_count, total);  // one LDS atomic per wave and step
+    base = (uint32_t)__shfl((int)base, leader);
+    const size_t region = (size_t)blockIdx.x * q.region_cap;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        if (push[j]) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[j], 0u));
+            q.reads[region + base + rank] = r[j];
+            q.idx[region + base + rank] = i[j];
+        }
+        base += (uint32_t)__popcll(mask[j]);
+    }
+}
+
 template <bool WIDE, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict__ reads,
                                                       const uint8_t* __restrict__ flags, uint64_t n,
                                                       const uint64_t* __restrict__ s64,
                                                       const uint32_t* __restrict__ s32,
                                                       const uint64_t* __restrict__ guides, int k,
-                                                      int log_slots, uint64_t kmask, MatchOut o) {
+                                                      int log_slots, uint64_t kmask, MatchOut o, MissQueue q) {
+    __shared__ uint32_t q_n;
+    if (q.count) {
+        if (threadIdx.x == 0) q_n = 0;
+        __syncthreads();
+    }
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     const uint64_t ngroups = n / VEC;
     for (uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
@@ -111,6 +155,14 @@ __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict
             uint64_t i = g * VEC + j;
             if (read_skipped(r[j], flags, i, k)) idx[j] = BC_IDX_SKIP;
             else idx[j] = hash_lookup<WIDE>(r[j] & kmask, s64, s32, guides, k, log_slots, kmask);
+        }
+        if (q.count) {
+            bool push[VEC];
+            uint64_t rr[VEC];
+            uint32_t ii[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { push[j] = idx[j] == BC_IDX_MISS; rr[j] = r[j] & kmask; ii[j] = (uint32_t)(g * VEC + j); }
+            queue_push<VEC>(q, &q_n, push, rr, ii);
         }
         if constexpr (VEC == 4) {
             reinterpret_cast<int4*>(o.best_idx)[g] = make_int4(idx[0], idx[1], idx[2], idx[3]);
@@ -139,6 +191,15 @@ __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict
                           ? BC_IDX_SKIP
                           : hash_lookup<WIDE>(r & kmask, s64, s32, guides, k, log_slots, kmask);
         emit(o, i, idx, idx >= 0 ? 0u : (uint32_t)BC_DIST_NONE, idx >= 0 ? 1u : 0u);
+        if (q.count && idx == BC_IDX_MISS) {  // tail reads (block 0 only): one lane at a time is fine
+            uint32_t at = atomicAdd(&q_n, 1u);
+            q.reads[at] = r & kmask;
+            q.idx[at] = (uint32_t)i;
+        }
+    }
+    if (q.count) {
+        __syncthreads();
+        if (threadIdx.x == 0) q.count[blockIdx.x] = q_n;
     }
 }
 
@@ -272,6 +333,7 @@ __device__ __forceinline__ uint32_t grp_last(uint32_t v, int last_lane) {  // va
     else return (uint32_t)__shfl((int)v, last_lane);
 }
 
+constexpr int QUEUE_MAX_BLOCKS = 8192;  // workgroups (= queue regions) of one two-stage tile
 constexpr int SLAB_MAX_LOG2S = 5;  // <= 32 entries (256 B) per slab; longer buckets chain
 
 // Running result of one lane: key = dist << 24 | guide index (one v_min keeps the
@@ -403,6 +465,127 @@ __global__ __launch_bounds__(BLOCK) void k_match_slab(const SlabParams* __restri
         const uint32_t nb = grp_sum<LPR>(mine);
         if (sub == 0) {
             if (key != 0xFFFFFFFFu) emit(o, i, (int32_t)(key & 0xFFFFFFu), md, nb);
+            else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3a'': second stage of the two-stage matcher.  Input = the queue of reads that
+// have no exact hit (stage 1 = k_match_hash); every lane group is busy on a read
+// that really needs the seed search.  All tables' primary slabs are requested
+// up front; the scan is branch-free:
+//   key  = dist << 24 | guide            -> kmin = min key  (best distance, lowest index)
+//   key2 = key + (255 - max_mm) << 24    -> kmax = max key2 (largest candidate; distances
+//                                           above max_mm wrap below every candidate)
+// One distinct candidate <=> kmin == kmax - bias: n_best = 1.  Anything else
+// (several candidates within max_mm) goes through the exact slow path.
+// ---------------------------------------------------------------------------
+template <int LPR, int MAXSTEP>
+__device__ __forceinline__ uint32_t slab_scan_fast(const SlabTable& T, const uint4 (&v)[MAXSTEP], uint32_t rest,
+                                                   uint32_t bias, uint32_t& kmin, uint32_t& kmax, int last_lane) {
+    const int nstep = (1 << T.log2S) / (2 * LPR);
+    const uint32_t hmask = (1u << T.half) - 1u;
+    uint32_t lz = 0, lw = 0;
+#pragma unroll
+    for (int st = 0; st < MAXSTEP; ++st) {
+        if (st < nstep) {
+            const uint32_t x0 = rest ^ v[st].x, x1 = rest ^ v[st].z;
+            const uint32_t d0 = __popc((x0 | (x0 >> T.half)) & hmask);
+            const uint32_t d1 = __popc((x1 | (x1 >> T.half)) & hmask);
+            const uint32_t k0 = (d0 << 24) | v[st].y, k1 = (d1 << 24) | v[st].w;  // empty / link slots stay 0xFFFFFFFx
+            kmin = min(kmin, min(k0, k1));
+            kmax = max(kmax, max(k0 + bias, k1 + bias));
+            if (st == nstep - 1) { lz = v[st].z; lw = v[st].w; }
+        }
+    }
+    lw = grp_last<LPR>(lw, last_lane);
+    lz = grp_last<LPR>(lz, last_lane);
+    return (lw == SLAB_LINK) ? lz : 0u;
+}
+
+template <int LPR>
+__device__ __forceinline__ uint32_t grp_max(uint32_t v) {
+    if constexpr (LPR == 4) {
+        v = max(v, quad_perm<0xB1>(v));
+        v = max(v, quad_perm<0x4E>(v));
+    } else {
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m));
+    }
+    return v;
+}
+
+// exact evaluation of one read over every table (chains followed, duplicates
+// across seeds removed, counts per distance): the definition of the result
+template <int LPR, int NSEG>
+__device__ __forceinline__ void slab_slow(const SlabParams& sp, uint32_t rlo, uint32_t rhi, int max_mm, int sub,
+                                       int last_lane, uint32_t& key_out, uint32_t& nb_out) {
+    constexpr int MAXSTEP = (1 << SLAB_MAX_LOG2S) / (2 * LPR);
+    SlabBest b{0xFFFFFFFFu, (uint32_t)max_mm, 0ull};
+    uint4 v[MAXSTEP];
+    auto one = [&](auto s_tag) {
+        constexpr int s = decltype(s_tag)::value;
+        const SlabTable& T = sp.t[s];
+        const uint32_t rest = slab_rest(T, rlo, rhi);
+        uint32_t slab = seed_value(rlo, rhi, T.start, T.slen);
+        do {
+            slab_load<LPR, MAXSTEP>(T, slab, sub, v);
+            slab = slab_scan<LPR, MAXSTEP, s>(T, v, rest, b, last_lane);
+        } while (slab != 0u);
+        b.cur = grp_min<LPR>(b.cur);
+    };
+    one(std::integral_constant<int, 0>{});
+    if constexpr (NSEG > 1) one(std::integral_constant<int, 1>{});
+    if constexpr (NSEG > 2) one(std::integral_constant<int, 2>{});
+    if constexpr (NSEG > 3) one(std::integral_constant<int, 3>{});
+    const uint32_t key = grp_min<LPR>(b.key);
+    const uint32_t md = key >> 24;
+    const uint32_t mine = (md <= 3u) ? (uint32_t)((b.cnt >> (16 * (md & 3u))) & 0xFFFFu) : 0u;
+    key_out = key;
+    nb_out = grp_sum<LPR>(mine);
+}
+
+template <int LPR, int NSEG>
+__global__ __launch_bounds__(BLOCK) void k_match_slabq(const SlabParams* __restrict__ spp,
+                                                       const uint64_t* __restrict__ q_reads,
+                                                       const uint32_t* __restrict__ q_idx,
+                                                       const uint32_t* __restrict__ q_count, uint32_t region_cap,
+                                                       int max_mm, MatchOut o) {
+    const SlabParams& sp = *spp;
+    constexpr int MAXSTEP = (1 << SLAB_MAX_LOG2S) / (2 * LPR);
+    const uint32_t n = q_count[blockIdx.x];  // this workgroup drains the region its twin filled
+    q_reads += (size_t)blockIdx.x * region_cap;
+    q_idx += (size_t)blockIdx.x * region_cap;
+    const int sub = threadIdx.x & (LPR - 1);
+    const int last_lane = (threadIdx.x & 63) | (LPR - 1);
+    const uint32_t bias = (255u - (uint32_t)max_mm) << 24;
+    for (uint32_t qi = threadIdx.x / LPR; qi < n; qi += BLOCK / LPR) {
+        const uint64_t r = q_reads[qi];
+        const uint64_t i = q_idx[qi];
+        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+        uint4 v[NSEG][MAXSTEP];
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s)
+            slab_load<LPR, MAXSTEP>(sp.t[s], seed_value(rlo, rhi, sp.t[s].start, sp.t[s].slen), sub, v[s]);
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            const SlabTable& T = sp.t[s];
+            const uint32_t rest = slab_rest(T, rlo, rhi);
+            uint32_t slab = slab_scan_fast<LPR, MAXSTEP>(T, v[s], rest, bias, kmin, kmax, last_lane);
+            while (slab != 0u) {  // overflow chain
+                slab_load<LPR, MAXSTEP>(T, slab, sub, v[s]);
+                slab = slab_scan_fast<LPR, MAXSTEP>(T, v[s], rest, bias, kmin, kmax, last_lane);
+            }
+        }
+        kmin = grp_min<LPR>(kmin);
+        kmax = grp_max<LPR>(kmax);
+        uint32_t key = kmin, nb = 1u;
+        const bool hit = (kmin >> 24) <= (uint32_t)max_mm;
+        if (hit && (kmax - bias) != kmin) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
+        if (sub == 0) {
+            if (hit) emit(o, i, (int32_t)(key & 0xFFFFFFu), key >> 24, nb);
             else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0);
         }
     }
@@ -576,6 +759,11 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     while (log2S < SLAB_MAX_LOG2S && (double)((1 << log2S) - 1) < mu + 2.0 * sqrt(mu) + 1.0) ++log2S;
     log2S = std::max(log2S, env_int("BC_SLAB_MIN_LOG2S", 3));
     log2S = std::min(std::min(SLAB_MAX_LOG2S, env_int("BC_SLAB_MAX_LOG2S", SLAB_MAX_LOG2S)), log2S);
+    if (const char* spec = getenv("BC_SLAB_LOG2S")) {  // tuning aid: explicit per-table sizes "a,b,c"
+        int vals[MAX_SEG] = {0, 0, 0, 0};
+        int nv = sscanf(spec, "%d,%d,%d,%d", &vals[0], &vals[1], &vals[2], &vals[3]);
+        if (s < nv && vals[s] >= 3 && vals[s] <= SLAB_MAX_LOG2S) log2S = vals[s];
+    }
     const uint32_t S = 1u << log2S;
     std::vector<uint2> slabs((size_t)nb << log2S, make_uint2(0u, SLAB_EMPTY));
     const uint32_t below = (1u << start) - 1u;
@@ -742,6 +930,52 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     return BC_OK;
 }
 
+int launch_hash(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o,
+                const MissQueue& q, hipStream_t st, int max_grid = 0) {
+    bool vec = aligned16(d_reads) && aligned16(o.best_idx) && (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
+               (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0) && n >= 4;
+    if (!vec && q.count) {
+        set_error("bc_match: the two-stage matcher needs 16-byte aligned read / result buffers and n >= 4");
+        return BC_EINVAL;
+    }
+    if (vec) {
+        // 4 rows of 256 four-read groups per workgroup unless the caller fixes the grid (queue regions)
+        const uint64_t rows = (n / 4 + BLOCK - 1) / BLOCK;
+        int grid = (int)std::max<uint64_t>(1, max_grid > 0 ? std::min<uint64_t>(rows, (uint64_t)max_grid) : std::min<uint64_t>((rows + 3) / 4, 1u << 20));
+        if (lib->wide)
+            hipLaunchKernelGGL((k_match_hash<true, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
+                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o, q);
+        else
+            hipLaunchKernelGGL((k_match_hash<false, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
+                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o, q);
+    } else {
+        int grid = grid_for(n);
+        if (lib->wide)
+            hipLaunchKernelGGL((k_match_hash<true, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
+                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o, q);
+        else
+            hipLaunchKernelGGL((k_match_hash<false, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
+                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o, q);
+    }
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+// the miss queue lives in the library object and only ever grows; the first
+// large call allocates it (keep it out of a graph capture: warm up first)
+int ensure_queue(bc_lib* lib, uint64_t cap, int grid) {
+    if (!lib->q_count) BC_HIP(hipMalloc((void**)&lib->q_count, sizeof(uint32_t) * QUEUE_MAX_BLOCKS));
+    (void)grid;
+    if (cap <= lib->q_cap) return BC_OK;
+    if (lib->q_reads) (void)hipFree(lib->q_reads);
+    if (lib->q_idx) (void)hipFree(lib->q_idx);
+    lib->q_reads = nullptr; lib->q_idx = nullptr; lib->q_cap = 0;
+    BC_HIP(hipMalloc((void**)&lib->q_reads, cap * sizeof(uint64_t)));
+    BC_HIP(hipMalloc((void**)&lib->q_idx, cap * sizeof(uint32_t)));
+    lib->q_cap = cap;
+    return BC_OK;
+}
+
 int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
                         int max_mm, int algo, const MatchOut& o, hipStream_t st) {
     if (algo == BC_ALGO_HASH) {
@@ -749,26 +983,8 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
             set_error("bc_match: BC_ALGO_HASH requires max_mismatch == 0");
             return BC_EINVAL;
         }
-        bool vec = aligned16(d_reads) && aligned16(o.best_idx) &&
-                   (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
-                   (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0) && n >= 4;
-        if (vec) {
-            int grid = grid_for(n / 4);
-            if (lib->wide)
-                hipLaunchKernelGGL((k_match_hash<true, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
-                                   lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
-            else
-                hipLaunchKernelGGL((k_match_hash<false, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
-                                   lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
-        } else {
-            int grid = grid_for(n);
-            if (lib->wide)
-                hipLaunchKernelGGL((k_match_hash<true, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
-                                   lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
-            else
-                hipLaunchKernelGGL((k_match_hash<false, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n,
-                                   lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
-        }
+        int rc = launch_hash(lib, d_reads, d_flags, n, o, MissQueue{nullptr, nullptr, nullptr, 0}, st);
+        if (rc != BC_OK) return rc;
     } else if (algo == BC_ALGO_SEED || algo == BC_ALGO_SEED_CSR) {
         if (max_mm < 0 || max_mm >= MAX_SEG) {
             set_error("bc_match: the seed index supports 0 <= max_mismatch <= %d", MAX_SEG - 1);
@@ -780,16 +996,56 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
             for (int s = 0; s < lib->slab[max_mm].nseg; ++s) minS = std::min(minS, 1u << lib->slab[max_mm].t[s].log2S);
             const SlabParams* dp = lib->d_slab[max_mm];
             const bool l8 = (lpr == 8 && minS >= 16);
+            const int nseg = lib->slab[max_mm].nseg;
+            const bool vec_ok = aligned16(d_reads) && aligned16(o.best_idx) && n >= 4 &&
+                                (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
+                                (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
+            if (max_mm >= 1 && vec_ok && env_int("BC_TWO_STAGE", 1)) {
+                // stage 1: exact hits through the hash table; stage 2: the residue through the seed index
+                const uint64_t TILE = 1ull << 25;
+                // stage 1 grid and the per-workgroup queue regions (a workgroup sees at most `per` reads)
+                // many small workgroups (4096 reads each) instead of a capped persistent grid: the
+                // hardware dispatcher balances them and no resident slot idles through a long tail
+                const uint64_t tile_max = std::min(n, TILE);
+                const uint64_t rows = (tile_max / 4 + BLOCK - 1) / BLOCK;  // 256-group rows in a tile
+                const int qgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((rows + 3) / 4, QUEUE_MAX_BLOCKS));
+                const uint64_t groups_per_block = (rows + qgrid - 1) / qgrid;
+                const uint32_t region_cap = (uint32_t)(groups_per_block * BLOCK * 4 + 8);
+                int rc = ensure_queue(lib, (uint64_t)qgrid * region_cap, qgrid);
+                if (rc != BC_OK) return rc;
+                for (uint64_t a = 0; a < n; a += TILE) {
+                    const uint64_t m = std::min(TILE, n - a);
+                    MatchOut ot = o;
+                    ot.best_idx += a;
+                    if (ot.best_dist) ot.best_dist += a;
+                    if (ot.n_best) ot.n_best += a;
+                    ot.base += a;
+                    BC_HIP(hipMemsetAsync(lib->q_count, 0, sizeof(uint32_t) * qgrid, st));
+                    MissQueue q{lib->q_reads, lib->q_idx, lib->q_count, region_cap};
+                    rc = launch_hash(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, ot, q, st, qgrid);
+                    if (rc != BC_OK) return rc;
+#define BC_SLABQ_LAUNCH(LPR_, NSEG_)                                                                      \
+    hipLaunchKernelGGL((k_match_slabq<LPR_, NSEG_>), dim3(qgrid), dim3(BLOCK), 0, st, dp, lib->q_reads,     \
+                       lib->q_idx, lib->q_count, region_cap, max_mm, ot)
+                    switch (nseg) {
+                        case 2: if (l8) BC_SLABQ_LAUNCH(8, 2); else BC_SLABQ_LAUNCH(4, 2); break;
+                        case 3: if (l8) BC_SLABQ_LAUNCH(8, 3); else BC_SLABQ_LAUNCH(4, 3); break;
+                        default: if (l8) BC_SLABQ_LAUNCH(8, 4); else BC_SLABQ_LAUNCH(4, 4); break;
+                    }
+#undef BC_SLABQ_LAUNCH
+                }
+            } else {
 #define BC_SLAB_LAUNCH(LPR_, NSEG_)                                                                          \
     hipLaunchKernelGGL((k_match_slab<LPR_, NSEG_>), dim3(grid_for(n * LPR_)), dim3(BLOCK), 0, st, dp, d_reads, \
                        d_flags, n, lib->k, lib->kmask, max_mm, o)
-            switch (lib->slab[max_mm].nseg) {
-                case 1: if (l8) BC_SLAB_LAUNCH(8, 1); else BC_SLAB_LAUNCH(4, 1); break;
-                case 2: if (l8) BC_SLAB_LAUNCH(8, 2); else BC_SLAB_LAUNCH(4, 2); break;
-                case 3: if (l8) BC_SLAB_LAUNCH(8, 3); else BC_SLAB_LAUNCH(4, 3); break;
-                default: if (l8) BC_SLAB_LAUNCH(8, 4); else BC_SLAB_LAUNCH(4, 4); break;
-            }
+                switch (nseg) {
+                    case 1: if (l8) BC_SLAB_LAUNCH(8, 1); else BC_SLAB_LAUNCH(4, 1); break;
+                    case 2: if (l8) BC_SLAB_LAUNCH(8, 2); else BC_SLAB_LAUNCH(4, 2); break;
+                    case 3: if (l8) BC_SLAB_LAUNCH(8, 3); else BC_SLAB_LAUNCH(4, 3); break;
+                    default: if (l8) BC_SLAB_LAUNCH(8, 4); else BC_SLAB_LAUNCH(4, 4); break;
+                }
 #undef BC_SLAB_LAUNCH
+            }
         } else {
             hipLaunchKernelGGL(k_match_seed, dim3(grid_for(n)), dim3(BLOCK), 0, st, lib->seed[max_mm], d_reads,
                                d_flags, n, lib->k, lib->kmask, max_mm, o);
@@ -858,6 +1114,7 @@ int bc_lib_destroy(bc_lib* lib) {
     if (!lib) return BC_OK;
     (void)hipSetDevice(lib->device);
     for (void* p : lib->owned) (void)hipFree(p);
+    for (void* p : {(void*)lib->q_reads, (void*)lib->q_idx, (void*)lib->q_count}) if (p) (void)hipFree(p);
     delete lib;
     return BC_OK;
 }

@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=float, default=1e8, help="reads per GPU")
     ap.add_argument("--guides", type=int, default=G)
-    ap.add_argument("--algo", default="seed", choices=["seed", "seed_csr", "brute"])
+    ap.add_argument("--algo", default="seed", choices=["seed", "seed_csr", "brute", "hash", "auto"])
     ap.add_argument("--max-mismatch", type=int, default=MAX_MM)
     ap.add_argument("--cpu-sample", type=int, default=60_000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -138,7 +138,7 @@ def main():
                        "parallelism": f"reads sharded x{world}, counts all-reduced"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": {"seed": "k_match_slab", "seed_csr": "k_match_seed", "brute": "k_match_brute"}[args.algo],
+                         "kernel": {"seed": "k_match_slab", "seed_csr": "k_match_seed", "brute": "k_match_brute", "hash": "k_match_hash", "auto": "auto"}[args.algo],
                          "kernel_ms": k_ms, "algorithmic_bytes_per_read": ALGO_BYTES},
         }
         tr = os.path.join(ROOT, "profiles", "traffic.json")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 csv output (kernel stats + per-kernel PMC means) as JSON.
 usage: python profiles/summarize.py gpurun_out/prof_<tag> [kernel-substring]"""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 root = sys.argv[1]
@@ -19,7 +19,8 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         for r in csv.DictReader(open(f)):
             if want not in r["Kernel_Name"]:
                 continue
-            name = r["Kernel_Name"].split("(")[0]
+            m = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
+            name = m.group(1) if m else r["Kernel_Name"][:60]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[name] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
         for name, cs in acc.items():
