@@ -333,7 +333,7 @@ __device__ __forceinline__ uint32_t grp_last(uint32_t v, int last_lane) {  // va
     else return (uint32_t)__shfl((int)v, last_lane);
 }
 
-constexpr int QUEUE_MAX_BLOCKS = 8192;  // workgroups (= queue regions) of one two-stage tile
+constexpr int QUEUE_MAX_BLOCKS = 32768;  // workgroups (= queue regions) of one two-stage tile
 constexpr int SLAB_MAX_LOG2S = 5;  // <= 32 entries (256 B) per slab; longer buckets chain
 
 // Running result of one lane: key = dist << 24 | guide index (one v_min keeps the
@@ -1002,7 +1002,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                                 (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
             if (max_mm >= 1 && vec_ok && env_int("BC_TWO_STAGE", 1)) {
                 // stage 1: exact hits through the hash table; stage 2: the residue through the seed index
-                const uint64_t TILE = 1ull << 25;
+                const uint64_t TILE = 1ull << 27;  // 134M reads per stage pair; the queue holds 12 B per read of a tile
                 // stage 1 grid and the per-workgroup queue regions (a workgroup sees at most `per` reads)
                 // many small workgroups (4096 reads each) instead of a capped persistent grid: the
                 // hardware dispatcher balances them and no resident slot idles through a long tail

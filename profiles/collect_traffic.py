@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of profiles/run_prof.sh into
+profiles/traffic.json (read by bench.py for roofline.traffic).
+
+Corrections (MI355X_MICROARCH.md, section HBM): on gfx950 FETCH_SIZE reports half
+the bytes of a 16-byte-per-lane coalesced streaming read, WRITE_SIZE is exact.
+k_match_hash and k_hist stream their input with 16-byte-per-lane loads, so their
+FETCH_SIZE is doubled (checked here: k_match_hash raw 436 MB for an 800 MB read
+array, k_hist raw 1.0 GB for 5 x 400 MB).  k_match_slabq mixes 8-byte queue
+reads with 16-byte-per-lane table pieces served from L2 / Infinity Cache; its
+FETCH_SIZE is recorded raw (a lower bound) and flagged as such.
+usage: python profiles/collect_traffic.py profiles/r01_rocprof_summary.json reads algo max_mm
+"""
+import json, sys
+src, reads, algo, mm = sys.argv[1], int(float(sys.argv[2])), sys.argv[3], int(sys.argv[4])
+d = json.load(open(src))["pmc"]
+rows, total = {}, 0.0
+for name, e in d.items():
+    if not name.startswith(("k_match", "k_hist")):
+        continue
+    f = e.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0) * 1024
+    w = e.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0) * 1024
+    corr = 2.0 if name.startswith(("k_match_hash", "k_hist")) else 1.0
+    rows[name] = {"fetch_raw_bytes": f, "fetch_correction": corr, "write_bytes": w, "hbm_bytes": f * corr + w}
+    total += f * corr + w
+out = {"reads": reads, "algo": algo, "max_mismatch": mm, "hbm_bytes_per_pass": total, "per_kernel": rows,
+       "algorithmic_bytes_per_pass": 13 * reads, "source": src,
+       "note": "FETCH_SIZE counts Infinity-Cache hits too; k_match_slabq's fetch is uncorrected (lower bound)"}
+json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
