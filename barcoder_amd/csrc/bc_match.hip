@@ -592,6 +592,187 @@ __global__ __launch_bounds__(BLOCK) void k_match_slabq(const SlabParams* __restr
 }
 
 // ---------------------------------------------------------------------------
+// K2+K3 fused: one workgroup owns a tile of FUSED_T consecutive reads.
+//   phase 1  exact stage: 4 reads per lane and step through the hash table; results
+//            go to LDS, reads without an exact hit to an LDS queue;
+//   phase 2  seed stage: DPP quads drain the LDS queue through the slab index.
+//            Tables are visited in rounds: after tables 0..j every guide within
+//            distance j has been seen (it keeps >= d+1-j clean segments), so a
+//            read whose best is <= 1 after tables 0 and 1 never touches the large
+//            third table;
+//   phase 3  the tile's results leave LDS as full-width coalesced stores.
+// No global queue, no placeholder writes, no scattered 6-byte result stores.
+// ---------------------------------------------------------------------------
+constexpr int FUSED_T = 2048;                 // reads per workgroup
+constexpr int FUSED_IT = FUSED_T / (BLOCK * 4);
+
+template <bool WIDE, int NSEG, int MSA, int MSB>
+__global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restrict__ spp,
+                                                       const uint64_t* __restrict__ reads,
+                                                       const uint8_t* __restrict__ flags, uint64_t n,
+                                                       const uint64_t* __restrict__ s64,
+                                                       const uint32_t* __restrict__ s32,
+                                                       const uint64_t* __restrict__ guides, int k, int log_slots,
+                                                       uint64_t kmask, int max_mm, MatchOut o) {
+    constexpr int LPR = 4;
+    // LDS: only the queue (20 KiB per workgroup, so registers, not LDS, set the occupancy).
+    // An entry's 8 bytes hold the read until the seed stage has used it, then its result.
+    __shared__ uint64_t q_slot[FUSED_T];
+    __shared__ uint16_t q_pos[FUSED_T];
+    __shared__ uint32_t q_n;
+    const SlabParams& sp = *spp;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * FUSED_T;
+    const uint32_t tn = (uint32_t)min((uint64_t)FUSED_T, n - tile0);  // reads in this tile
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+
+    // ---- phase 1: exact stage; exact hits (and skips) are final and stored at once, coalesced
+#pragma unroll
+    for (int it = 0; it < FUSED_IT; ++it) {
+        const uint32_t p0 = (uint32_t)(it * BLOCK + threadIdx.x) * 4u;  // position in tile of this lane's 4 reads
+        uint64_t r[4] = {0, 0, 0, 0};
+        const bool full = p0 + 3 < tn;
+        if (full) {
+            const ulonglong2* p = reinterpret_cast<const ulonglong2*>(reads + tile0 + p0);
+            ulonglong2 a = p[0], b = p[1];
+            r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) r[j] = reads[tile0 + p0 + j];
+        }
+        int32_t idx[4];
+        bool push[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = p0 + j < tn;
+            if (!in || read_skipped(r[j], flags, tile0 + p0 + j, k)) idx[j] = BC_IDX_SKIP;
+            else idx[j] = hash_lookup<WIDE>(r[j] & kmask, s64, s32, guides, k, log_slots, kmask);
+            push[j] = in && idx[j] == BC_IDX_MISS;
+        }
+        if (full) {
+            reinterpret_cast<int4*>(o.best_idx + tile0)[p0 >> 2] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            if (o.best_dist) {
+                uchar4 d;
+                d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
+                d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
+                reinterpret_cast<uchar4*>(o.best_dist + tile0)[p0 >> 2] = d;
+            }
+            if (o.n_best) {
+                uchar4 c;
+                c.x = idx[0] >= 0; c.y = idx[1] >= 0; c.z = idx[2] >= 0; c.w = idx[3] >= 0;
+                reinterpret_cast<uchar4*>(o.n_best + tile0)[p0 >> 2] = c;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) {
+                    o.best_idx[tile0 + p0 + j] = idx[j];
+                    if (o.best_dist) o.best_dist[tile0 + p0 + j] = idx[j] >= 0 ? 0 : BC_DIST_NONE;
+                    if (o.n_best) o.n_best[tile0 + p0 + j] = idx[j] >= 0;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
+        // wave-aggregated append to the LDS queue
+        unsigned long long mask[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mask[j] = __ballot(push[j]); total += (uint32_t)__popcll(mask[j]); }
+        if (total) {
+            uint32_t base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(&q_n, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (push[j]) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[j] >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask[j], 0u));
+                    q_slot[base + rank] = r[j] & kmask;
+                    q_pos[base + rank] = (uint16_t)(p0 + j);
+                }
+                base += (uint32_t)__popcll(mask[j]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: seed stage over the LDS queue, one DPP quad per read
+    const uint32_t qn = q_n;
+    {
+        const int sub = threadIdx.x & (LPR - 1);
+        const int last_lane = (threadIdx.x & 63) | (LPR - 1);
+        const uint32_t bias = (255u - (uint32_t)max_mm) << 24;
+        for (uint32_t qi = threadIdx.x / LPR; qi < qn; qi += BLOCK / LPR) {
+            const uint64_t r = q_slot[qi];
+            const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+            uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+            constexpr int RA = NSEG < 2 ? NSEG : 2;  // round A: tables 0 and 1
+            {
+                uint4 v[RA][MSA];
+#pragma unroll
+                for (int s = 0; s < RA; ++s)
+                    slab_load<LPR, MSA>(sp.t[s], seed_value(rlo, rhi, sp.t[s].start, sp.t[s].slen), sub, v[s]);
+#pragma unroll
+                for (int s = 0; s < RA; ++s) {
+                    const SlabTable& T = sp.t[s];
+                    const uint32_t rest = slab_rest(T, rlo, rhi);
+                    uint32_t slab = slab_scan_fast<LPR, MSA>(T, v[s], rest, bias, kmin, kmax, last_lane);
+                    while (slab != 0u) {
+                        slab_load<LPR, MSA>(T, slab, sub, v[s]);
+                        slab = slab_scan_fast<LPR, MSA>(T, v[s], rest, bias, kmin, kmax, last_lane);
+                    }
+                }
+            }
+            kmin = grp_min<LPR>(kmin);
+            if (NSEG > 2 && (kmin >> 24) > 1u) {
+                // round B: the remaining tables can only add guides at distance >= 2
+                constexpr int RB = NSEG > 2 ? NSEG - 2 : 1;
+                uint4 v[RB][MSB];
+#pragma unroll
+                for (int s = 0; s < RB; ++s)
+                    slab_load<LPR, MSB>(sp.t[s + 2], seed_value(rlo, rhi, sp.t[s + 2].start, sp.t[s + 2].slen), sub, v[s]);
+#pragma unroll
+                for (int s = 0; s < RB; ++s) {
+                    const SlabTable& T = sp.t[s + 2];
+                    const uint32_t rest = slab_rest(T, rlo, rhi);
+                    uint32_t slab = slab_scan_fast<LPR, MSB>(T, v[s], rest, bias, kmin, kmax, last_lane);
+                    while (slab != 0u) {
+                        slab_load<LPR, MSB>(T, slab, sub, v[s]);
+                        slab = slab_scan_fast<LPR, MSB>(T, v[s], rest, bias, kmin, kmax, last_lane);
+                    }
+                }
+                kmin = grp_min<LPR>(kmin);
+            }
+            kmax = grp_max<LPR>(kmax);
+            uint32_t key = kmin, nb = 1u;
+            const bool hit = (kmin >> 24) <= (uint32_t)max_mm;
+            if (hit && (kmax - bias) != kmin) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
+            if (sub == 0) {  // the entry now carries its result: index | dist << 32 | n_best << 40
+                const uint32_t ri = hit ? (key & 0xFFFFFFu) : (uint32_t)BC_IDX_MISS;
+                const uint32_t rd = hit ? (key >> 24) : (uint32_t)BC_DIST_NONE;
+                const uint32_t rn = hit ? (nb > 255u ? 255u : nb) : 0u;
+                q_slot[qi] = (uint64_t)ri | ((uint64_t)rd << 32) | ((uint64_t)rn << 40);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: queued reads' results over the placeholders phase 1 left (same lines, still in L2)
+    for (uint32_t qi = threadIdx.x; qi < qn; qi += BLOCK) {
+        const uint64_t e = q_slot[qi];
+        const int32_t idx = (int32_t)(uint32_t)e;
+        if (idx == BC_IDX_MISS) continue;  // the placeholder already says so
+        const uint64_t i = tile0 + q_pos[qi];
+        o.best_idx[i] = idx;
+        if (o.best_dist) o.best_dist[i] = (uint8_t)(e >> 32);
+        if (o.n_best) o.n_best[i] = (uint8_t)(e >> 40);
+        tally(o, i, idx);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K5: per-guide histogram + first-seen from best_idx, privatised in LDS.
 // Scattered device-scope atomics leave the L2 (one 32-byte memory-side write
 // each, measured: profiles/r01_v1_*); instead each workgroup owns a range of
@@ -1000,7 +1181,29 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
             const bool vec_ok = aligned16(d_reads) && aligned16(o.best_idx) && n >= 4 &&
                                 (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
                                 (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
-            if (max_mm >= 1 && vec_ok && env_int("BC_TWO_STAGE", 1)) {
+            const int stage_mode = env_int("BC_TWO_STAGE", 1);  // 1 fused (default), 2 two kernels + global queue, 0 single slab kernel
+            if (max_mm >= 1 && vec_ok && stage_mode == 1) {
+                const int grid = (int)((n + FUSED_T - 1) / FUSED_T);
+                // steps (16-byte pieces per lane) of the largest slab in round A (tables 0,1) and round B
+                int sa = 1, sb = 1;
+                for (int s = 0; s < nseg; ++s) {
+                    int st_ = (1 << lib->slab[max_mm].t[s].log2S) / 8;
+                    if (s < 2) sa = std::max(sa, st_); else sb = std::max(sb, st_);
+                }
+                const bool small = (sa <= 2);  // the common case: 64/128-byte slabs for the first two tables
+#define BC_FUSED_LAUNCH(W_, NSEG_, MSA_, MSB_)                                                                   \
+    hipLaunchKernelGGL((k_match_fused<W_, NSEG_, MSA_, MSB_>), dim3(grid), dim3(BLOCK), 0, st, dp, d_reads,      \
+                       d_flags, n, lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots,         \
+                       lib->kmask, max_mm, o)
+#define BC_FUSED_W(NSEG_, MSA_, MSB_) do { if (lib->wide) BC_FUSED_LAUNCH(true, NSEG_, MSA_, MSB_); else BC_FUSED_LAUNCH(false, NSEG_, MSA_, MSB_); } while (0)
+                switch (nseg) {
+                    case 2: if (small) BC_FUSED_W(2, 2, 1); else BC_FUSED_W(2, 4, 1); break;
+                    case 3: if (small) BC_FUSED_W(3, 2, 4); else BC_FUSED_W(3, 4, 4); break;
+                    default: if (small) BC_FUSED_W(4, 2, 4); else BC_FUSED_W(4, 4, 4); break;
+                }
+#undef BC_FUSED_W
+#undef BC_FUSED_LAUNCH
+            } else if (max_mm >= 1 && vec_ok && stage_mode == 2) {
                 // stage 1: exact hits through the hash table; stage 2: the residue through the seed index
                 const uint64_t TILE = 1ull << 27;  // 134M reads per stage pair; the queue holds 12 B per read of a tile
                 // stage 1 grid and the per-workgroup queue regions (a workgroup sees at most `per` reads)
