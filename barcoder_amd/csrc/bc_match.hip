@@ -24,6 +24,15 @@ using namespace bc;
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// streaming input: keep it out of the L2's way (the lookup tables live there)
+__device__ __forceinline__ void load_reads4(const uint64_t* p, uint64_t (&r)[4]) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+    r[0] = (uint64_t)a.x | ((uint64_t)a.y << 32); r[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    r[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); r[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+}
+
 struct MatchOut {
     int32_t* best_idx;
     uint8_t* best_dist;
@@ -143,9 +152,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict
     for (uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
         uint64_t r[VEC];
         if constexpr (VEC == 4) {
-            const ulonglong2* p = reinterpret_cast<const ulonglong2*>(reads) + g * 2;
-            ulonglong2 a = p[0], b = p[1];
-            r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+            load_reads4(reads + g * 4, r);
         } else {
             r[0] = reads[g];
         }
@@ -633,9 +640,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
         uint64_t r[4] = {0, 0, 0, 0};
         const bool full = p0 + 3 < tn;
         if (full) {
-            const ulonglong2* p = reinterpret_cast<const ulonglong2*>(reads + tile0 + p0);
-            ulonglong2 a = p[0], b = p[1];
-            r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+            load_reads4(reads + tile0 + p0, r);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -934,10 +939,11 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     if (2 * half > 32 || lib->G >= (1u << 24) || lib->k > 28) { lib->slab_ok[d] = false; return BC_OK; }  // rest: one dword; index: 24 bits
     if (!lib->slab_ok[d]) return BC_OK;
     const uint32_t nb = 1u << (2 * slen);
-    // slab size: room for the mean bucket plus ~2 sigma, at least 8 entries (64 B)
+    // slab size: 64-byte slabs (7 entries + link) while the mean bucket fits, else 128-byte slabs and
+    // chaining.  Measured on MI355X (G=1e5, k=20, d<=2): sizes (8,8,16) 3.04 ms per 1e8 reads vs
+    // (16,16,32) 3.13 ms — short chained slabs beat long ones (smaller tables, fewer bytes per visit).
     const double mu = (double)lib->G / nb;
-    int log2S = 3;
-    while (log2S < SLAB_MAX_LOG2S && (double)((1 << log2S) - 1) < mu + 2.0 * sqrt(mu) + 1.0) ++log2S;
+    int log2S = (mu <= 7.0) ? 3 : 4;
     log2S = std::max(log2S, env_int("BC_SLAB_MIN_LOG2S", 3));
     log2S = std::min(std::min(SLAB_MAX_LOG2S, env_int("BC_SLAB_MAX_LOG2S", SLAB_MAX_LOG2S)), log2S);
     if (const char* spec = getenv("BC_SLAB_LOG2S")) {  // tuning aid: explicit per-table sizes "a,b,c"
@@ -1031,7 +1037,8 @@ int build_seed_index(bc_lib* lib, int d) {
 int build_hash(bc_lib* lib) {
     const int k = lib->k;
     int ls = 4;
-    while ((1ull << ls) < (uint64_t)lib->G * 5 / 2 + 1) ++ls;
+    const int pct = std::max(110, env_int("BC_HASH_SLOTS_PCT", 500));  // slots >= pct % of G (tuning aid)
+    while ((1ull << ls) < (uint64_t)lib->G * pct / 100 + 1) ++ls;
     lib->log_slots = ls;
     const uint32_t nslots = 1u << ls, smask = nslots - 1;
     int free_bits = 2 * (32 - k);
