@@ -181,3 +181,29 @@ def test_synth_streams_are_stable():
     frac = [(d == i).mean() for i in range(4)]
     assert abs(frac[0] - 0.60) < 0.02 and abs(frac[1] - 0.20) < 0.02 and abs(frac[2] - 0.10) < 0.01
     assert len(S.genome(1000)) == 1000 and set(S.genome(1000)) <= set("ACGT")
+
+
+def test_mismatch_module_matches_reference(capsys):
+    """mismatch.py mirror: y_pred values (float64) and the generated variant tables."""
+    from barcoder_amd import mismatch as M
+    m = _load("mismatch.json")
+    params = m["params"]
+    for o, v, want in m["pairs"]:
+        got = M.calculate_y_pred(o, v, params["GC_content"], params)
+        assert (got is None and want is None) or abs(got - want) < 1e-12
+        mask = sum(1 << i for i, (a, b) in enumerate(zip(o, v)) if a != b)
+        got2 = M.y_pred_from_mask(o, v, mask, params)
+        assert (got2 is None and want is None) or abs(got2 - want) < 1e-12
+    for t in m["tables"]:
+        M.generate_mismatches([t["spacer"]], 0.0, 1.0, 0.1, params, t["spacer"])
+        assert capsys.readouterr().out == t["tsv"]
+
+
+def test_targets_helpers_match_oracle(oracle):
+    from barcoder_amd import targets as T
+    assert T.get_diff("ACGT", "ACGT") is None and T.get_diff("ACGT", "ACCA") == "C3G,A4T"
+    assert T.diff_from_mask("ACGT", "ACCA", 0b1100) == "C3G,A4T"
+    for a, b, n in [(0, 32, 100), (90, 122, 100), (-10, 22, 100), (68, 100, 100)]:
+        assert T.get_coords(a, b, n) == oracle.get_coords(a, b, n)
+    assert T.pam_matches("NGG", "AGG") and not T.pam_matches("NGG", "AGA") and not T.pam_matches("NGG", None)
+    assert T.pam_matches("NNN", "xyz") and T.get_overlap(0, 10, 5, 20) == 5 and T.get_offset("R", 1, 9, 0, 20) == 11

@@ -1,0 +1,109 @@
+"""GPU: guide -> genome search (the Bowtie bypass) against the reference's own
+shipped answer: the rows of Example_Libraries/CN-32-zmo.tsv that lie on the 4
+shipped plasmids (tests/golden/cn32_plasmid_rows.tsv), and against the oracle
+for mismatching searches."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+NAMES = ["CP023716.1", "CP023717.1", "CP023718.1", "CP023719.1"]
+
+
+@pytest.fixture(scope="module")
+def plasmids():
+    from barcoder_amd.library import read_fasta_records
+    from barcoder_amd.targets import Chromosome
+    seqs = read_fasta_records(os.path.join(GOLDEN, "plasmids.fasta"))
+    return [Chromosome(n, s, True) for n, s in zip(NAMES, seqs)]
+
+
+def _golden_rows():
+    with open(os.path.join(GOLDEN, "cn32_plasmid_rows.tsv")) as f:
+        cols = f.readline().rstrip("\n").split("\t")
+        return [dict(zip(cols, line.rstrip("\n").split("\t"))) for line in f]
+
+
+def test_known_answer_table_reproduced(gpu_device, plasmids):
+    """Library = the 706 plasmid spacers of the shipped TSV, genome = the 4 plasmids
+    (circular), PAM NGNC downstream, 0 mismatches: the site list (spacer, chr, pam,
+    target, coordinates, strand) equals the reference's rows."""
+    from barcoder_amd.targets import find_hits, ranges_table
+    gold = _golden_rows()
+    want = {(r["spacer"], r["chr"], r["pam"], r["target"], int(r["tar_start"]), int(r["tar_end"]), r["sp_dir"],
+             int(r["mismatches"])) for r in gold}
+    spacers = list(dict.fromkeys(r["spacer"] for r in gold))
+    assert len(spacers) == 706
+    rows = find_hits(spacers, plasmids, pam="NGNC", num_mismatches=0, pam_direction="downstream", device=gpu_device)
+    got = {(r["spacer"], r["chr"], r["pam"], r["target"], r["tar_start"], r["tar_end"], r["sp_dir"], r["mismatches"])
+           for r in rows}
+    assert got == want
+    assert all(r["type"] == "perfect" and r["diff"] is None and r["len"] == 32 for r in rows)
+    # sorted like targets.py:629-630, and the PySamParser-shaped table follows
+    keys = [(r["chr"], min(r["tar_start"], r["tar_end"]), r["spacer"]) for r in rows]
+    assert keys == sorted(keys)
+    t = ranges_table(rows)
+    assert set(t[0]) == {"Chromosome", "Start", "End", "Mapped", "Strand", "Barcode", "Mismatches"}
+    assert any(r["tar_start"] < 0 for r in rows) == any(int(r["tar_start"]) < 0 for r in gold)
+
+
+@pytest.mark.parametrize("direction", ["downstream", "upstream"])
+@pytest.mark.parametrize("circular", [True, False])
+@pytest.mark.parametrize("pam", ["NGG", "NG", ""])
+def test_mismatch_search_vs_oracle(gpu_device, oracle, plasmids, direction, circular, pam):
+    """<= 2 mismatches, NGG, 20-mers with planted substitutions: compare with a
+    string-level restatement (oracle all_hits + oracle PAM extraction)."""
+    from barcoder_amd.targets import Chromosome, find_hits
+    rng = np.random.default_rng(5)
+    seq = plasmids[0].seq[:6000]
+    ch = Chromosome("c", seq, circular)
+    k, d = 20, 2
+    pl = len(pam)
+    guides = []
+    for _ in range(60):
+        p = int(rng.integers(0, len(seq) - k))
+        s = list(seq[p:p + k])
+        for q in rng.choice(k, int(rng.integers(0, 3)), replace=False):
+            s[q] = rng.choice([c for c in "ACGT" if c != s[q]])
+        s = "".join(s)
+        guides.append(s if rng.random() < 0.5 else oracle.rev_comp(s))
+    guides += [seq[-7:] + seq[:13], oracle.rev_comp(seq[-3:] + seq[:17])]  # origin-spanning sites
+    guides = list(dict.fromkeys(guides))
+    rows = find_hits(guides, [ch], pam=pam, num_mismatches=d, pam_direction=direction, device=gpu_device)
+    got = {(r["spacer"], r["tar_start"], r["tar_end"], r["sp_dir"], r["mismatches"], r["pam"], r["target"], r["diff"])
+           for r in rows}
+    # oracle: every window of the topological string, both strands
+    n = len(seq)
+    topo = seq + (seq[:k + pl - 1] if circular and k + pl > 1 else "")
+    npos = n if circular else n - k + 1
+    wins_f = [topo[p:p + k] for p in range(npos)]
+    want = set()
+    for strand, wins in (("F", wins_f), ("R", [oracle.rev_comp(w) for w in wins_f])):
+        for q, g, dist in oracle.all_hits(guides, wins, d).tolist():
+            a, b = q, q + k
+            fwd_side_right = (strand == "F") == (direction == "downstream")
+            ext = None
+            if pl:
+                if fwd_side_right:
+                    if b + pl > len(topo):
+                        continue
+                    ext = topo[b:b + pl]
+                else:
+                    a2 = a - pl
+                    if a2 < 0:
+                        if not circular:
+                            continue
+                        a2 += n
+                    ext = topo[a2:a2 + pl]
+                if strand == "R":
+                    ext = oracle.rev_comp(ext)
+                if not oracle.pam_matches(pam, ext):
+                    continue
+            ts, te = oracle.fold_coords(a, b, n)
+            target = wins[q]
+            want.add((guides[g], ts, te, strand, dist, ext, target, oracle.get_diff(guides[g], target)))
+    assert got == want
+    assert len(got) >= {0: 40, 2: 5, 3: 0}[pl]
