@@ -52,6 +52,9 @@ SIGNATURES = {
     "bc_revcomp_kmers": (C.c_int, [vp, C.c_size_t, C.c_int, vp]),
     "bc_pack_windows": (C.c_int, [vp, vp, C.c_size_t, C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, vp, vp]),
+    "bc_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "bc_reader_next": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]),
+    "bc_reader_close": (C.c_int, [vp]),
     "bc_lib_create": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]),
     "bc_lib_destroy": (C.c_int, [vp]),
     "bc_lib_info": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1,0 +1,179 @@
+// bc_ingest.cpp — native reads-file reader: the
+// sequence lines of a FASTQ or .reads file (plain, .gz via zlib, .zst via a
+// dlopen'ed libzstd) as one text buffer + offsets, ready for bc_pack_windows.
+//
+// Follows heuristicount.py:100-153 (read_in_chunks): the file type comes from the
+// name after an optional .gz/.zst suffix (".fastq" -> line 2 of every 4,
+// ".reads" -> every line; anything else is rejected, :111-116), every kept line
+// is stripped of surrounding whitespace (:127,:138), and the sequence line of
+// a truncated last record still counts (it is appended before the record's
+// remaining lines are skipped).
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+#include "bc_common.h"
+
+using namespace bc;
+
+namespace {
+
+// minimal libzstd streaming API (resolved at run time; the image ships the
+// shared object but no header)
+struct ZBuf { void* p; size_t size; size_t pos; };
+struct Zstd {
+    void* h = nullptr;
+    void* (*createDCtx)() = nullptr;
+    size_t (*freeDCtx)(void*) = nullptr;
+    size_t (*decompressStream)(void*, ZBuf*, ZBuf*) = nullptr;
+    unsigned (*isError)(size_t) = nullptr;
+    bool load() {
+        if (h) return true;
+        for (const char* n : {"libzstd.so.1", "libzstd.so"}) {
+            h = dlopen(n, RTLD_NOW);
+            if (h) break;
+        }
+        if (!h) return false;
+        createDCtx = (void* (*)())dlsym(h, "ZSTD_createDCtx");
+        freeDCtx = (size_t (*)(void*))dlsym(h, "ZSTD_freeDCtx");
+        decompressStream = (size_t (*)(void*, ZBuf*, ZBuf*))dlsym(h, "ZSTD_decompressStream");
+        isError = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+        return createDCtx && freeDCtx && decompressStream && isError;
+    }
+};
+Zstd g_zstd;
+
+}  // namespace
+
+struct bc_reader {
+    int kind = 0;        // 0 = .reads (every line), 1 = .fastq (line 2 of 4)
+    int comp = 0;        // 0 plain, 1 gz, 2 zst
+    FILE* fp = nullptr;
+    gzFile gz = nullptr;
+    void* zctx = nullptr;
+    std::vector<char> zin;
+    size_t zin_pos = 0, zin_len = 0;
+    std::vector<char> buf;  // decoded bytes not yet consumed
+    size_t pos = 0, len = 0;
+    bool eof = false;
+    uint64_t line_in_record = 0;
+
+    size_t fill(char* dst, size_t cap) {
+        if (comp == 0) return fread(dst, 1, cap, fp);
+        if (comp == 1) {
+            int n = gzread(gz, dst, (unsigned)cap);
+            return n > 0 ? (size_t)n : 0;
+        }
+        size_t produced = 0;
+        while (produced == 0) {
+            if (zin_pos == zin_len) {
+                zin_len = fread(zin.data(), 1, zin.size(), fp);
+                zin_pos = 0;
+                if (zin_len == 0) return 0;
+            }
+            ZBuf in{zin.data(), zin_len, zin_pos}, out{dst, cap, 0};
+            size_t rc = g_zstd.decompressStream(zctx, &out, &in);
+            zin_pos = in.pos;
+            if (g_zstd.isError(rc)) return 0;
+            produced = out.pos;
+        }
+        return produced;
+    }
+};
+
+static bool ends_with(const std::string& s, const char* suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+extern "C" {
+
+int bc_reader_open(const char* path, bc_reader** out) {
+    if (!path || !out) { set_error("bc_reader_open: null argument"); return BC_EINVAL; }
+    std::string p(path), base(path);
+    int comp = 0;
+    if (ends_with(p, ".gz")) { comp = 1; base = p.substr(0, p.size() - 3); }
+    else if (ends_with(p, ".zst")) { comp = 2; base = p.substr(0, p.size() - 4); }
+    int kind;
+    if (ends_with(base, ".fastq")) kind = 1;
+    else if (ends_with(base, ".reads")) kind = 0;
+    else { set_error("Unsupported file type. Must be '.fastq' or '.reads'."); return BC_EINVAL; }
+    bc_reader* r = new bc_reader();
+    r->kind = kind; r->comp = comp;
+    if (comp == 1) {
+        r->gz = gzopen(path, "rb");
+        if (!r->gz) { delete r; set_error("cannot open %s", path); return BC_EINVAL; }
+        gzbuffer(r->gz, 1 << 20);
+    } else {
+        r->fp = fopen(path, "rb");
+        if (!r->fp) { delete r; set_error("cannot open %s", path); return BC_EINVAL; }
+        if (comp == 2) {
+            if (!g_zstd.load()) { fclose(r->fp); delete r; set_error("%s: libzstd is not available", path); return BC_EINVAL; }
+            r->zctx = g_zstd.createDCtx();
+            r->zin.resize(1 << 20);
+        }
+    }
+    r->buf.resize(8 << 20);
+    *out = r;
+    return BC_OK;
+}
+
+int bc_reader_close(bc_reader* r) {
+    if (!r) return BC_OK;
+    if (r->gz) gzclose(r->gz);
+    if (r->fp) fclose(r->fp);
+    if (r->zctx) g_zstd.freeDCtx(r->zctx);
+    delete r;
+    return BC_OK;
+}
+
+// Up to max_reads sequence lines (stripped) into text (capacity text_cap) with
+// offsets off[0..n]; stops early when the next read would not fit (a single
+// read longer than text_cap is BC_ECAP).  *n_out = 0 at end of file.
+int bc_reader_next(bc_reader* r, uint64_t max_reads, char* text, uint64_t text_cap, uint64_t* off,
+                   uint64_t* n_out) {
+    if (!r || !text || !off || !n_out) { set_error("bc_reader_next: null argument"); return BC_EINVAL; }
+    uint64_t n = 0, used = 0;
+    off[0] = 0;
+    const uint64_t per = r->kind ? 4 : 1, seq_line = r->kind ? 1 : 0;
+    while (n < max_reads) {
+        const char* nl = (const char*)memchr(r->buf.data() + r->pos, '\n', r->len - r->pos);
+        while (!nl && !r->eof) {  // pull more decoded bytes behind the unconsumed tail
+            if (r->pos > 0) {
+                memmove(r->buf.data(), r->buf.data() + r->pos, r->len - r->pos);
+                r->len -= r->pos;
+                r->pos = 0;
+            }
+            if (r->len == r->buf.size()) r->buf.resize(r->buf.size() * 2);  // one very long line
+            size_t got = r->fill(r->buf.data() + r->len, r->buf.size() - r->len);
+            if (got == 0) { r->eof = true; break; }
+            nl = (const char*)memchr(r->buf.data() + r->len, '\n', got);
+            r->len += got;
+        }
+        if (!nl && r->pos == r->len) break;  // nothing left
+        const char* line = r->buf.data() + r->pos;
+        const size_t ll = nl ? (size_t)(nl - line) : (r->len - r->pos);
+        if (r->line_in_record == seq_line) {
+            size_t a = 0, b = ll;  // python str.strip(): whitespace off both ends
+            while (a < b && (line[a] == ' ' || (line[a] >= '\t' && line[a] <= '\r'))) ++a;
+            while (b > a && (line[b - 1] == ' ' || (line[b - 1] >= '\t' && line[b - 1] <= '\r'))) --b;
+            if (used + (b - a) > text_cap) {
+                if (n == 0) { set_error("bc_reader_next: a read of %zu bytes does not fit the buffer", b - a); return BC_ECAP; }
+                break;  // not consumed: the next call starts with this line
+            }
+            memcpy(text + used, line + a, b - a);
+            used += b - a;
+            off[++n] = used;
+        }
+        r->line_in_record = (r->line_in_record + 1) % per;
+        r->pos += ll + (nl ? 1 : 0);
+    }
+    *n_out = n;
+    return BC_OK;
+}
+
+}  // extern "C"

@@ -61,6 +61,9 @@ def pack_windows(text: bytes, off, start: int, L: str, R: str, k: int, reverse: 
     out = np.empty(n, np.uint64)
     status = np.empty(n, np.uint8)
     Lb, Rb = (L or "").encode("ascii"), (R or "").encode("ascii")
+    if isinstance(text, np.ndarray):
+        text = N.ptr(np.ascontiguousarray(text)) if text.size else b""
+    off = np.ascontiguousarray(off, np.uint64)
     N.check(N.load().bc_pack_windows(text, N.ptr(off), n, int(start), Lb, len(Lb), Rb, len(Rb), k,
                                      1 if reverse else 0, n_threads, N.ptr(out), N.ptr(status)))
     return out, status

@@ -283,35 +283,41 @@ class ChunkCounter:
         self.lib = DeviceLibrary.from_strings(self.labels, device)
         self.matcher = GpuMatcher(self.lib)
 
-    # windows of one mate: (packed, status, odd -> (in_lib, has_flanks, seq))
-    def _windows(self, reads, start, L, R, reverse, lib_set):
-        text, off = reads_to_text(reads)
+    # windows of one mate: (packed, status, odd -> (in_lib, seq)); `buf` = (text, off)
+    def _windows(self, buf, start, L, R, reverse, lib_set):
+        text, off = buf
         packed, status = pack_windows(text, off, start, L, R, self.k, reverse)
         odd = {}
         for i in np.flatnonzero(status == N.WIN_ODD).tolist():
-            w = reads[i][start:start + len(L) + self.k + len(R)]
+            w = _read_at(buf, i)[start:start + len(L) + self.k + len(R)]
             odd[i] = (w in lib_set, w[len(L):len(w) - len(R)])
         return packed, status, odd
 
     def process(self, chunk):
-        """(Counter, n_reads) for one chunk, bit-for-bit the reference's result
-        when max_mismatch == 0."""
+        """(Counter, n_reads) for one chunk of read lists, bit-for-bit the
+        reference's result when max_mismatch == 0."""
         a, b = chunk
-        reads1, reads2 = (b, a) if self.need_swap else (a, b)
+        return self.process_buffers(reads_to_text(a) if a else None, reads_to_text(b) if b else None)
+
+    def process_buffers(self, buf_a, buf_b):
+        """Same on (text, offsets) buffers (NativeReader output); either may be None."""
+        buf1, buf2 = (buf_b, buf_a) if self.need_swap else (buf_a, buf_b)
+        n1 = 0 if buf1 is None else buf1[1].size - 1
+        n2 = 0 if buf2 is None else buf2[1].size - 1
         s1, s2, Lf, Rf, Lr, Rr = self.geom
         events = []  # (first read index, key, count)
-        if reads1 and reads2:
-            if len(reads1) != len(reads2):
+        if n1 and n2:
+            if n1 != n2:
                 raise ValueError("Length of reads1 and reads2 must be the same for paired-end data.")
-            n = len(reads1)
-            p1, st1, odd1 = self._windows(reads1, s1, Lf, Rf, False, self.fwd_set)
-            p2, st2, odd2 = self._windows(reads2, s2, Lr, Rr, True, self.rev_set)
+            n = n1
+            p1, st1, odd1 = self._windows(buf1, s1, Lf, Rf, False, self.fwd_set)
+            p2, st2, odd2 = self._windows(buf2, s2, Lr, Rr, True, self.rev_set)
             ok = (st1 == N.WIN_OK) & (st2 == N.WIN_OK) & (p1 == p2)
             flags = (~ok).astype(np.uint8)
             res = self.matcher.match(p1, flags, self.max_mismatch, self.algo)
             # pairs with a window that cannot be packed: exact string semantics on the host
             for i in sorted(set(odd1) | set(odd2)):
-                x, y = reads1[i], reads2[i]
+                x, y = _read_at(buf1, i), _read_at(buf2, i)
                 if "N" in x or "N" in y:
                     continue
                 w1 = x[s1:s1 + len(Lf) + self.k + len(Rf)]
@@ -324,13 +330,13 @@ class ChunkCounter:
                 events.append((i, key, 1))
             miss_words = p1
         else:
-            reverse = not reads1
-            reads = reads2 if reverse else reads1
-            if not reads:
+            reverse = not n1
+            buf = buf2 if reverse else buf1
+            n = n2 if reverse else n1
+            if not n:
                 return Counter(), 0
-            n = len(reads)
             start, L, R, lib_set = (s2, Lr, Rr, self.rev_set) if reverse else (s1, Lf, Rf, self.fwd_set)
-            packed, status, odd = self._windows(reads, start, L, R, reverse, lib_set)
+            packed, status, odd = self._windows(buf, start, L, R, reverse, lib_set)
             res = self.matcher.match(packed, (status != N.WIN_OK).astype(np.uint8), self.max_mismatch, self.algo)
             for i, (in_lib, seq) in odd.items():
                 if reverse:
@@ -351,6 +357,13 @@ class ChunkCounter:
         for _f, key, c in sorted(events, key=lambda e: e[0]):
             counts[key] += c
         return counts, n
+
+
+def _read_at(buf, i: int) -> str:
+    text, off = buf
+    a, b = int(off[i]), int(off[i + 1])
+    raw = text[a:b]
+    return (raw.tobytes() if isinstance(raw, np.ndarray) else bytes(raw)).decode("ascii", errors="replace")
 
 
 _COUNTERS = {}
@@ -438,11 +451,21 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
                       device=device, max_mismatch=max_mismatch)
     doc, undoc = Counter(), Counter()
     total_reads = 0
-    for chunk in read_in_chunks(file1, file2 if is_paired else None):
-        counts, n = cc.process(chunk)
-        total_reads += n
-        for barcode, c in counts.items():
-            (undoc if barcode.endswith("*") else doc)[barcode] += c
+    # bulk pass: native reader (bc_reader_*) -> bc_pack_windows -> GPU match, 1M reads at a time
+    from .ingest import NativeReader
+    with NativeReader(file1) as r1, (NativeReader(file2) if is_paired else nullcontext()) as r2:
+        while True:
+            b1 = r1.next()
+            n1 = b1[1].size - 1
+            b2 = None
+            if r2 is not None:
+                b2 = r2.next(max(n1, 1))  # same number of mates; a shorter file ends the pairing with a ValueError
+            if n1 == 0 and (b2 is None or b2[1].size <= 1):
+                break
+            counts, n = cc.process_buffers(b1 if n1 else None, b2 if (b2 is not None and b2[1].size > 1) else None)
+            total_reads += n
+            for barcode, c in counts.items():
+                (undoc if barcode.endswith("*") else doc)[barcode] += c
     return dict(doc=doc, undoc=undoc, total_reads=total_reads, barcodes=barcodes, bc_len=bc_len,
                 bc_start1=bc_start1, bc_start2=bc_start2, flanks_fwd=(L_fwd, R_fwd), flanks_rev=(L_rev, R_rev),
                 need_swap=need_swap, forward_name=fwd_name, reverse_name=rev_name)

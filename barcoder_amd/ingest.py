@@ -1,0 +1,85 @@
+"""Native reads-file reader (bc_reader_*): the sequence lines of .fastq / .reads
+(.gz, .zst) files as text + offsets buffers, the input form of bc_pack_windows.
+Host-side replacement for the per-line Python loop of heuristicount.py:100-153."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class NativeReader:
+    def __init__(self, path: str, max_reads: int = 1 << 20, bytes_per_read: int = 192):
+        self._h = N.vp()
+        N.check(N.load().bc_reader_open(path.encode(), C.byref(self._h)))
+        self.max_reads = int(max_reads)
+        self._text = np.empty(self.max_reads * bytes_per_read, np.uint8)
+        self._off = np.empty(self.max_reads + 1, np.uint64)
+
+    def _next_once(self, m: int):
+        n = C.c_uint64(0)
+        while True:
+            rc = N.load().bc_reader_next(self._h, m, N.ptr(self._text), self._text.size, N.ptr(self._off), C.byref(n))
+            if rc == N.BC_ECAP:  # one read larger than the whole buffer: grow and retry
+                self._text = np.empty(self._text.size * 4, np.uint8)
+                continue
+            N.check(rc)
+            break
+        k = int(n.value)
+        return self._text[:int(self._off[k])], self._off[:k + 1]
+
+    def next(self, max_reads: int | None = None):
+        """(text uint8[...], off uint64[n+1]); n = min(max_reads, reads left in the
+        file).  The views are valid until the next call; n == 0 at EOF."""
+        m = self.max_reads if max_reads is None else min(int(max_reads), self.max_reads)
+        text, off = self._next_once(m)
+        got = off.size - 1
+        if got == 0 or got == m:
+            return text, off
+        # the text buffer filled up before m reads: keep going and stitch the pieces
+        texts, offs = [text.copy()], [off.copy()]
+        while got < m:
+            t, o = self._next_once(m - got)
+            if o.size <= 1:
+                break
+            texts.append(t.copy())
+            offs.append(o[1:] + offs[-1][-1])
+            got += o.size - 1
+        return np.concatenate(texts), np.concatenate(offs)
+
+    def __iter__(self):
+        while True:
+            text, off = self.next()
+            if off.size <= 1:
+                return
+            yield text, off
+
+    def close(self):
+        if self._h:
+            N.load().bc_reader_close(self._h)
+            self._h = N.vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_all(path: str):
+    """Every sequence line of a file as a list of str (tests / small inputs)."""
+    out = []
+    with NativeReader(path, max_reads=1 << 16) as r:
+        for text, off in r:
+            b = text.tobytes()
+            o = off.astype(np.int64)
+            out.extend(b[o[i]:o[i + 1]].decode("ascii", errors="replace") for i in range(o.size - 1))
+    return out

@@ -102,6 +102,18 @@ int bc_pack_windows(const char *h_text, const uint64_t *h_off, size_t n_reads,
                     int k, int reverse, int n_threads,
                     uint64_t *h_out, uint8_t *h_status);
 
+/* ---- reads-file reader (host) ---------------------------------------------
+ * The sequence lines of a .fastq / .reads file (optionally .gz or .zst), as
+ * heuristicount.py:100-153 (read_in_chunks) selects and strips them, delivered
+ * as one text buffer + offsets in the form bc_pack_windows takes.
+ * bc_reader_next returns up to max_reads reads (fewer if text_cap is reached;
+ * *n_out == 0 at end of file). */
+typedef struct bc_reader bc_reader;
+int bc_reader_open(const char *path, bc_reader **out);
+int bc_reader_next(bc_reader *r, uint64_t max_reads, char *h_text, uint64_t text_cap,
+                   uint64_t *h_off /* max_reads + 1 */, uint64_t *n_out);
+int bc_reader_close(bc_reader *r);
+
 /* ---- library -------------------------------------------------------------
  * bc_lib_create: upload G distinct packed guides (index = position in the
  * array = first-occurrence order of the de-duplicated library,

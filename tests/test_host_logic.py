@@ -207,3 +207,57 @@ def test_targets_helpers_match_oracle(oracle):
         assert T.get_coords(a, b, n) == oracle.get_coords(a, b, n)
     assert T.pam_matches("NGG", "AGG") and not T.pam_matches("NGG", "AGA") and not T.pam_matches("NGG", None)
     assert T.pam_matches("NNN", "xyz") and T.get_overlap(0, 10, 5, 20) == 5 and T.get_offset("R", 1, 9, 0, 20) == 11
+
+
+def test_native_reader_matches_python_reader(tmp_path):
+    """bc_reader_* vs heuristicount.read_in_chunks (itself golden-tested) on FASTQ /
+    .reads, plain / gz / zst, CRLF, missing final newline, truncated record, blank lines."""
+    import ctypes
+    import random
+    from barcoder_amd import heuristicount as H, ingest
+    rng = random.Random(1)
+    reads = ["".join(rng.choice("ACGTN") for _ in range(rng.randrange(0, 120))) for _ in range(3000)]
+
+    def write(path, kind, trailing, crlf):
+        nl = "\r\n" if crlf else "\n"
+        op = gzip.open if path.endswith(".gz") else open
+        with op(path, "wt", newline="") as f:
+            for i, r in enumerate(reads):
+                end = "" if (i == len(reads) - 1 and not trailing) else nl
+                f.write(f"@r{i}{nl}{r}{nl}+{nl}{'I' * len(r)}{end}" if kind == "fastq" else r + end)
+
+    for kind in ("fastq", "reads"):
+        for gz in (False, True):
+            for trailing in (True, False):
+                for crlf in (False, True):
+                    p = str(tmp_path / (f"x.{kind}" + (".gz" if gz else "")))
+                    write(p, kind, trailing, crlf)
+                    assert ingest.read_all(p) == sum((c[0] for c in H.read_in_chunks(p)), [])
+    p = str(tmp_path / "t.fastq")
+    open(p, "w").write("@a\nACGT\n+\nIIII\n@b\nGGCC")
+    assert ingest.read_all(p) == ["ACGT", "GGCC"]
+    with pytest.raises(ValueError, match="Unsupported file type"):
+        ingest.NativeReader(str(tmp_path / "x.fq"))
+    with pytest.raises(ValueError):
+        ingest.NativeReader(str(tmp_path / "missing.reads"))
+    # tiny text buffer: stitched pieces, exact read counts
+    r = ingest.NativeReader(str(tmp_path / "x.reads"), max_reads=700, bytes_per_read=8)
+    t, o = r.next(700)
+    assert o.size - 1 == 700 and t.size == int(o[-1]) == sum(len(x) for x in reads[:700])
+    assert sum(o2.size - 1 for _t, o2 in r) == len(reads) - 700
+    # .zst through the system libzstd, when it is there
+    try:
+        z = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        return
+    raw = ("\n".join(reads) + "\n").encode()
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    cap = z.ZSTD_compressBound(len(raw))
+    dst = ctypes.create_string_buffer(cap)
+    m = z.ZSTD_compress(dst, cap, raw, len(raw), 3)
+    pz = tmp_path / "x.reads.zst"
+    pz.write_bytes(dst.raw[:m])
+    assert ingest.read_all(str(pz)) == reads
