@@ -301,11 +301,16 @@ class ChunkCounter:
 
     def process_buffers(self, buf_a, buf_b):
         """Same on (text, offsets) buffers (NativeReader output); either may be None."""
+        return self.match_buffers(buf_a, buf_b).counter(self)
+
+    def match_buffers(self, buf_a, buf_b, first_index: int = 0) -> "ChunkResult":
+        """The device pass of one chunk, results left in array form (no per-key
+        Python work): what the bulk driver accumulates."""
         buf1, buf2 = (buf_b, buf_a) if self.need_swap else (buf_a, buf_b)
         n1 = 0 if buf1 is None else buf1[1].size - 1
         n2 = 0 if buf2 is None else buf2[1].size - 1
         s1, s2, Lf, Rf, Lr, Rr = self.geom
-        events = []  # (first read index, key, count)
+        odd_events = []  # (read index, key)
         if n1 and n2:
             if n1 != n2:
                 raise ValueError("Length of reads1 and reads2 must be the same for paired-end data.")
@@ -314,7 +319,7 @@ class ChunkCounter:
             p2, st2, odd2 = self._windows(buf2, s2, Lr, Rr, True, self.rev_set)
             ok = (st1 == N.WIN_OK) & (st2 == N.WIN_OK) & (p1 == p2)
             flags = (~ok).astype(np.uint8)
-            res = self.matcher.match(p1, flags, self.max_mismatch, self.algo)
+            res = self.matcher.match(p1, flags, self.max_mismatch, self.algo, first_index=first_index)
             # pairs with a window that cannot be packed: exact string semantics on the host
             for i in sorted(set(odd1) | set(odd2)):
                 x, y = _read_at(buf1, i), _read_at(buf2, i)
@@ -326,37 +331,87 @@ class ChunkCounter:
                 has = w1.startswith(Lf) and w1.endswith(Rf) and w2.startswith(Lr) and w2.endswith(Rr)
                 if q1 != rev_comp(q2) or not has:
                     continue
-                key = q1 if (w1 in self.fwd_set and w2 in self.rev_set) else q1 + "*"
-                events.append((i, key, 1))
+                odd_events.append((first_index + i, q1 if (w1 in self.fwd_set and w2 in self.rev_set) else q1 + "*"))
             miss_words = p1
         else:
             reverse = not n1
             buf = buf2 if reverse else buf1
             n = n2 if reverse else n1
             if not n:
-                return Counter(), 0
+                return ChunkResult(0, None, None, None, None, None, [])
             start, L, R, lib_set = (s2, Lr, Rr, self.rev_set) if reverse else (s1, Lf, Rf, self.fwd_set)
             packed, status, odd = self._windows(buf, start, L, R, reverse, lib_set)
-            res = self.matcher.match(packed, (status != N.WIN_OK).astype(np.uint8), self.max_mismatch, self.algo)
+            res = self.matcher.match(packed, (status != N.WIN_OK).astype(np.uint8), self.max_mismatch, self.algo,
+                                     first_index=first_index)
             for i, (in_lib, seq) in odd.items():
                 if reverse:
                     seq = rev_comp(seq)
-                events.append((i, seq if in_lib else seq + "*", 1))
+                odd_events.append((first_index + i, seq if in_lib else seq + "*"))
             miss_words = packed
-        # documented barcodes: counts and first read index come from the device
-        seen = np.flatnonzero(res.counts)
-        for g, c, f in zip(seen.tolist(), res.counts[seen].tolist(), res.first_seen[seen].tolist()):
-            events.append((f, self.labels[g], c))
         # undocumented: group the missed (but flank-valid) windows
         miss = np.flatnonzero(res.best_idx == N.IDX_MISS)
         if miss.size:
             words, first, cnt = np.unique(miss_words[miss], return_index=True, return_counts=True)
-            for s, f, c in zip(unpack_kmers(words, self.k), miss[first].tolist(), cnt.tolist()):
-                events.append((f, s + "*", c))
+            first = miss[first].astype(np.uint64) + np.uint64(first_index)
+        else:
+            words, first, cnt = np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.int64)
+        return ChunkResult(n, res.counts, res.first_seen, words, cnt.astype(np.uint64), first, odd_events)
+
+
+class ChunkResult:
+    """One chunk's outcome in array form: documented counts / first-seen per guide,
+    undocumented packed windows with counts and first indices, odd (string) events."""
+
+    def __init__(self, n, counts, first_seen, u_words, u_counts, u_first, odd_events):
+        self.n, self.counts, self.first_seen = n, counts, first_seen
+        self.u_words, self.u_counts, self.u_first, self.odd_events = u_words, u_counts, u_first, odd_events
+
+    def counter(self, cc):
+        """The reference's (Counter, n): keys inserted in first-seen order."""
+        if self.n == 0:
+            return Counter(), 0
+        events = [(f, key, 1) for f, key in self.odd_events]
+        seen = np.flatnonzero(self.counts)
+        events += [(f, cc.labels[g], c) for g, c, f in
+                   zip(seen.tolist(), self.counts[seen].tolist(), self.first_seen[seen].tolist())]
+        if self.u_words.size:
+            events += [(f, s + "*", c) for s, f, c in
+                       zip(unpack_kmers(self.u_words, cc.k), self.u_first.tolist(), self.u_counts.tolist())]
         counts = Counter()
         for _f, key, c in sorted(events, key=lambda e: e[0]):
             counts[key] += c
-        return counts, n
+        return counts, self.n
+
+
+class PackedCounter:
+    """Counter-like view over undocumented windows kept packed (millions of
+    distinct keys would cost minutes as Python strings): supports len(),
+    values(), most_common(k), items() and `key in`."""
+
+    def __init__(self, k, words, counts, first, extra: Counter):
+        order = np.argsort(first, kind="stable")
+        self.k, self.words, self.counts, self.first, self.extra = k, words[order], counts[order], first[order], extra
+
+    def __len__(self):
+        return int(self.words.size) + len(self.extra)
+
+    def values(self):
+        return list(self.counts.tolist()) + list(self.extra.values())
+
+    def total(self):
+        return int(self.counts.sum()) + sum(self.extra.values())
+
+    def most_common(self, k=None):
+        if k is None:
+            k = len(self)
+        top = np.argsort(-self.counts.astype(np.int64), kind="stable")[:k]
+        cand = [(s + "*", int(c)) for s, c in zip(unpack_kmers(self.words[top], self.k), self.counts[top].tolist())]
+        cand += list(self.extra.items())
+        return sorted(cand, key=lambda kv: -kv[1])[:k]
+
+    def items(self):
+        yield from ((s + "*", int(c)) for s, c in zip(unpack_kmers(self.words, self.k), self.counts.tolist()))
+        yield from self.extra.items()
 
 
 def _read_at(buf, i: int) -> str:
@@ -449,9 +504,13 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     ordered = [b for b in read_fasta_ordered(fasta_file) if b in barcodes]
     cc = ChunkCounter(ordered, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
                       device=device, max_mismatch=max_mismatch)
-    doc, undoc = Counter(), Counter()
     total_reads = 0
-    # bulk pass: native reader (bc_reader_*) -> bc_pack_windows -> GPU match, 1M reads at a time
+    G = len(cc.labels)
+    counts = np.zeros(G, np.uint64)
+    first_seen = np.full(G, np.iinfo(np.uint64).max, np.uint64)
+    u_words, u_counts, u_first, odd_events = [], [], [], []
+    # bulk pass: native reader (bc_reader_*) -> bc_pack_windows -> GPU match, 1M reads at a time;
+    # per-chunk results stay in array form and are merged once at the end
     from .ingest import NativeReader
     with NativeReader(file1) as r1, (NativeReader(file2) if is_paired else nullcontext()) as r2:
         while True:
@@ -462,10 +521,35 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
                 b2 = r2.next(max(n1, 1))  # same number of mates; a shorter file ends the pairing with a ValueError
             if n1 == 0 and (b2 is None or b2[1].size <= 1):
                 break
-            counts, n = cc.process_buffers(b1 if n1 else None, b2 if (b2 is not None and b2[1].size > 1) else None)
-            total_reads += n
-            for barcode, c in counts.items():
-                (undoc if barcode.endswith("*") else doc)[barcode] += c
+            res = cc.match_buffers(b1 if n1 else None, b2 if (b2 is not None and b2[1].size > 1) else None,
+                                   first_index=total_reads)
+            total_reads += res.n
+            if res.n:
+                counts += res.counts
+                np.minimum(first_seen, res.first_seen, out=first_seen)
+                u_words.append(res.u_words); u_counts.append(res.u_counts); u_first.append(res.u_first)
+                odd_events += res.odd_events
+    # documented: first-seen order (heuristicount.py:876-877 prints Counter insertion order)
+    doc_events = [(int(f), cc.labels[g], int(c)) for g, c, f in
+                  zip(np.flatnonzero(counts).tolist(), counts[counts > 0].tolist(), first_seen[counts > 0].tolist())]
+    extra_undoc = Counter()
+    for f, key in odd_events:
+        if key.endswith("*"):
+            extra_undoc[key] += 1
+        else:
+            doc_events.append((f, key, 1))
+    doc = Counter()
+    for _f, key, c in sorted(doc_events, key=lambda e: e[0]):
+        doc[key] += c
+    if u_words:
+        w = np.concatenate(u_words)
+        uw, inv = np.unique(w, return_inverse=True)
+        uc = np.bincount(inv, weights=np.concatenate(u_counts).astype(np.float64), minlength=uw.size).astype(np.uint64)
+        uf = np.full(uw.size, np.iinfo(np.uint64).max, np.uint64)
+        np.minimum.at(uf, inv, np.concatenate(u_first))
+    else:
+        uw = uc = uf = np.zeros(0, np.uint64)
+    undoc = PackedCounter(bc_len, uw, uc, uf, extra_undoc)
     return dict(doc=doc, undoc=undoc, total_reads=total_reads, barcodes=barcodes, bc_len=bc_len,
                 bc_start1=bc_start1, bc_start2=bc_start2, flanks_fwd=(L_fwd, R_fwd), flanks_rev=(L_rev, R_rev),
                 need_swap=need_swap, forward_name=fwd_name, reverse_name=rev_name)
@@ -474,7 +558,7 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
 def summary_lines(r, fasta_file):
     """The fields of the reference's rich summary table (heuristicount.py:757-874) as plain text."""
     doc, undoc, total = r["doc"], r["undoc"], r["total_reads"]
-    nd, nu = sum(doc.values()), sum(undoc.values())
+    nd, nu = sum(doc.values()), (undoc.total() if hasattr(undoc, "total") else sum(undoc.values()))
     frac = (lambda x: f"{(x / total if total else 0):.3f}")
     rows = [("Barcodes", os.path.basename(fasta_file)), ("Forward Reads", r["forward_name"]),
             ("Reverse Reads", r["reverse_name"]), ("Barcode Length", r["bc_len"]),

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end timing of barcoder_amd.heuristicount.count_barcodes on a synthetic
+.reads file (5 nt + CCGGATTCAG + 20-mer + GTTTTAGAGC, the layout of BASELINE.md
+section 2).  usage: python profiles/e2e_bench.py [n_reads] [n_guides]"""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from barcoder_amd import encoding as E, synth as S, heuristicount as H
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
+d = tempfile.mkdtemp(prefix="bc_e2e_")
+lib = S.library(G, 20)
+labels = E.unpack_kmers(lib, 20)
+fa = os.path.join(d, "lib.fasta")
+with open(fa, "w") as f:
+    f.write("".join(f">g{i}\n{s}\n" for i, s in enumerate(labels)))
+t0 = time.perf_counter()
+rd = os.path.join(d, "reads.reads")
+CH = 2_000_000
+lut = np.frombuffer(b"ACGT", np.uint8)
+with open(rd, "wb") as f:
+    for a in range(0, n, CH):
+        m = min(CH, n - a)
+        w = S.reads(lib, 20, 2, a, m, 1)
+        lo, hi = (w & np.uint64(0xFFFFFFFF)).astype(np.uint64), (w >> np.uint64(32)).astype(np.uint64)
+        sh = np.arange(20, dtype=np.uint64)
+        codes = (((lo[:, None] >> sh) & np.uint64(1)) | (((hi[:, None] >> sh) & np.uint64(1)) << np.uint64(1))).astype(np.uint8)
+        pre = lut[(S.draw(9, np.arange(a, a + m, dtype=np.uint64), 0)[:, None] >> (np.arange(5, dtype=np.uint64) * np.uint64(2)) & np.uint64(3)).astype(np.uint8)]
+        row = np.empty((m, 46), np.uint8)
+        row[:, :5] = pre
+        row[:, 5:15] = np.frombuffer(b"CCGGATTCAG", np.uint8)
+        row[:, 15:35] = lut[codes]
+        row[:, 35:45] = np.frombuffer(b"GTTTTAGAGC", np.uint8)
+        row[:, 45] = 10
+        f.write(row.tobytes())
+print(f"generated {n} reads ({os.path.getsize(rd) / 1e6:.0f} MB) in {time.perf_counter() - t0:.1f} s", file=sys.stderr)
+t0 = time.perf_counter()
+r = H.count_barcodes(fa, rd)
+dt = time.perf_counter() - t0
+print({"reads": n, "guides": G, "seconds": round(dt, 2), "Mreads_per_s": round(n / dt / 1e6, 2),
+       "documented_reads": sum(r["doc"].values()), "undocumented_reads": r["undoc"].total(),
+       "offset": r["bc_start1"], "flanks": r["flanks_fwd"]})
+
+# phase timing (second run, warm): sampling vs bulk
+import time as _t
+t0 = _t.perf_counter(); lib_set = H.read_fasta(fa); sd = H.sample_data(rd, None, lib_set, False); t1 = _t.perf_counter()
+fl = H.find_flanks(sd[3], sd[1], 20); t2 = _t.perf_counter()
+from barcoder_amd.ingest import NativeReader
+cc = H.ChunkCounter(labels, 20, sd[1] - len(fl[0] or ""), None, fl[0], fl[1], None, None, False)
+t3 = _t.perf_counter(); tot = 0; tr = tp = tm = 0.0
+with NativeReader(rd) as r:
+    while True:
+        a = _t.perf_counter(); b1 = r.next(); b = _t.perf_counter(); tr += b - a
+        if b1[1].size <= 1: break
+        res = cc.match_buffers(b1, None, first_index=tot); tot += res.n; tm += _t.perf_counter() - b
+t4 = _t.perf_counter()
+print({"sample_data_s": round(t1 - t0, 2), "find_flanks_s": round(t2 - t1, 2), "lib_build_s": round(t3 - t2, 2),
+       "bulk_s": round(t4 - t3, 2), "of_which_reader_s": round(tr, 2), "pack+match+group_s": round(tm, 2),
+       "bulk_Mreads_per_s": round(tot / (t4 - t3) / 1e6, 2)})
