@@ -4,11 +4,12 @@ profiles/traffic.json (read by bench.py for roofline.traffic).
 
 Corrections (MI355X_MICROARCH.md, section HBM): on gfx950 FETCH_SIZE reports half
 the bytes of a 16-byte-per-lane coalesced streaming read, WRITE_SIZE is exact.
-k_match_hash and k_hist stream their input with 16-byte-per-lane loads, so their
-FETCH_SIZE is doubled (checked here: k_match_hash raw 436 MB for an 800 MB read
-array, k_hist raw 1.0 GB for 5 x 400 MB).  k_match_slabq mixes 8-byte queue
-reads with 16-byte-per-lane table pieces served from L2 / Infinity Cache; its
-FETCH_SIZE is recorded raw (a lower bound) and flagged as such.
+k_hist (and the stand-alone k_match_hash) stream their input with 16-byte-per-lane
+loads, so their FETCH_SIZE is doubled (calibration on known byte counts: k_match_hash
+raw 436 MB for an 800 MB read array, k_hist raw 1.0 GB for 5 x 400 MB).
+k_match_fused / k_match_slabq mix the 16-byte-per-lane read stream with table
+pieces served from L2 / Infinity Cache (FETCH_SIZE counts Infinity-Cache hits);
+their FETCH_SIZE is recorded raw (a lower bound) and flagged as such.
 usage: python profiles/collect_traffic.py profiles/r01_rocprof_summary.json reads algo max_mm
 """
 import json, sys
@@ -25,6 +26,6 @@ for name, e in d.items():
     total += f * corr + w
 out = {"reads": reads, "algo": algo, "max_mismatch": mm, "hbm_bytes_per_pass": total, "per_kernel": rows,
        "algorithmic_bytes_per_pass": 13 * reads, "source": src,
-       "note": "FETCH_SIZE counts Infinity-Cache hits too; k_match_slabq's fetch is uncorrected (lower bound)"}
+       "note": "FETCH_SIZE counts Infinity-Cache hits too; the fused / slabq kernels' fetch is uncorrected (lower bound)"}
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
