@@ -85,12 +85,18 @@ __device__ __forceinline__ int32_t hash_lookup(uint64_t key, const uint64_t* __r
             if (s == 0) return BC_IDX_MISS;
             if (guides[s - 1] == key) return (int32_t)(s - 1);
         } else {
-            uint64_t s = s64[h];
-            if (s == 0) return BC_IDX_MISS;
-            if ((s & kmask) == key) {
-                uint32_t lo = (uint32_t)s >> k, hi = (uint32_t)(s >> 32) >> k;
+            // narrow table: buckets of two 8-byte slots fetched by one 16-byte load (log_slots counts
+            // buckets); slot .x fills before .y, so an empty .y ends the probe sequence
+            const ulonglong2 b = reinterpret_cast<const ulonglong2*>(s64)[h];
+            if ((b.x & kmask) == key && b.x != 0) {
+                uint32_t lo = (uint32_t)b.x >> k, hi = (uint32_t)(b.x >> 32) >> k;
                 return (int32_t)((lo | (hi << (32 - k))) - 1u);
             }
+            if ((b.y & kmask) == key && b.y != 0) {
+                uint32_t lo = (uint32_t)b.y >> k, hi = (uint32_t)(b.y >> 32) >> k;
+                return (int32_t)((lo | (hi << (32 - k))) - 1u);
+            }
+            if (b.y == 0) return BC_IDX_MISS;
         }
         h = (h + 1) & smask;
     }
@@ -709,16 +715,29 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
         const int sub = threadIdx.x & (LPR - 1);
         const int last_lane = (threadIdx.x & 63) | (LPR - 1);
         const uint32_t bias = (255u - (uint32_t)max_mm) << 24;
-        for (uint32_t qi = threadIdx.x / LPR; qi < qn; qi += BLOCK / LPR) {
-            const uint64_t r = q_slot[qi];
+        constexpr int RA = NSEG < 2 ? NSEG : 2;  // round A: tables 0 and 1
+        // software pipeline: the next queued read's round-A slabs are requested before the current
+        // read is scanned, so a quad exposes about one memory round trip per read instead of two
+        uint4 v[RA][MSA], vn[RA][MSA];
+        uint32_t qi = threadIdx.x / LPR;
+        uint64_t r = 0, rn = 0;
+        if (qi < qn) {
+            r = q_slot[qi];
+#pragma unroll
+            for (int s = 0; s < RA; ++s)
+                slab_load<LPR, MSA>(sp.t[s], seed_value((uint32_t)r, (uint32_t)(r >> 32), sp.t[s].start, sp.t[s].slen), sub, v[s]);
+        }
+        for (; qi < qn; qi += BLOCK / LPR) {
             const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
             uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-            constexpr int RA = NSEG < 2 ? NSEG : 2;  // round A: tables 0 and 1
-            {
-                uint4 v[RA][MSA];
+            const uint32_t qnext = qi + BLOCK / LPR;
+            if (qnext < qn) {
+                rn = q_slot[qnext];
 #pragma unroll
                 for (int s = 0; s < RA; ++s)
-                    slab_load<LPR, MSA>(sp.t[s], seed_value(rlo, rhi, sp.t[s].start, sp.t[s].slen), sub, v[s]);
+                    slab_load<LPR, MSA>(sp.t[s], seed_value((uint32_t)rn, (uint32_t)(rn >> 32), sp.t[s].start, sp.t[s].slen), sub, vn[s]);
+            }
+            {
 #pragma unroll
                 for (int s = 0; s < RA; ++s) {
                     const SlabTable& T = sp.t[s];
@@ -757,9 +776,14 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
             if (sub == 0) {  // the entry now carries its result: index | dist << 32 | n_best << 40
                 const uint32_t ri = hit ? (key & 0xFFFFFFu) : (uint32_t)BC_IDX_MISS;
                 const uint32_t rd = hit ? (key >> 24) : (uint32_t)BC_DIST_NONE;
-                const uint32_t rn = hit ? (nb > 255u ? 255u : nb) : 0u;
-                q_slot[qi] = (uint64_t)ri | ((uint64_t)rd << 32) | ((uint64_t)rn << 40);
+                const uint32_t rn_ = hit ? (nb > 255u ? 255u : nb) : 0u;
+                q_slot[qi] = (uint64_t)ri | ((uint64_t)rd << 32) | ((uint64_t)rn_ << 40);
             }
+            r = rn;
+#pragma unroll
+            for (int s = 0; s < RA; ++s)
+#pragma unroll
+                for (int st = 0; st < MSA; ++st) v[s][st] = vn[s][st];
         }
     }
     __syncthreads();
@@ -1059,22 +1083,30 @@ int build_hash(bc_lib* lib) {
         }
         return dev_upload(lib, slots, &lib->d_slots32);
     }
-    std::vector<uint64_t> slots(nslots, 0);
+    // narrow: nslots buckets of two slots each (total slots = 2 x the count chosen above / 2: keep the
+    // memory of the single-slot layout by halving the bucket count)
+    lib->log_slots = ls = std::max(3, ls - 1);
+    const uint32_t nb = 1u << ls, bmask = nb - 1;
+    std::vector<uint64_t> slots((size_t)nb * 2, 0);
     const uint32_t fm = (k >= 32) ? 0u : ((1u << (32 - k)) - 1u);
     for (uint32_t i = 0; i < lib->G; ++i) {
         uint64_t key = lib->h_guides[i];
         uint32_t h = hash32(key) >> (32 - ls);
-        while (slots[h]) {
-            if ((slots[h] & lib->kmask) == key) {
-                set_error("bc_lib_create: duplicate guide at index %u", i);
-                return BC_EINVAL;
-            }
-            h = (h + 1) & smask;
-        }
         uint32_t v = i + 1;
         uint64_t lo = (uint64_t)(v & fm) << k;
         uint64_t hi = (uint64_t)((v >> (32 - k)) & fm) << (32 + k);
-        slots[h] = key | lo | hi;
+        const uint64_t word = key | lo | hi;
+        for (;;) {
+            uint64_t& x = slots[(size_t)h * 2];
+            uint64_t& y = slots[(size_t)h * 2 + 1];
+            if ((x && (x & lib->kmask) == key) || (y && (y & lib->kmask) == key)) {
+                set_error("bc_lib_create: duplicate guide at index %u", i);
+                return BC_EINVAL;
+            }
+            if (!x) { x = word; break; }
+            if (!y) { y = word; break; }
+            h = (h + 1) & bmask;
+        }
     }
     return dev_upload(lib, slots, &lib->d_slots64);
 }
@@ -1197,17 +1229,24 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     int st_ = (1 << lib->slab[max_mm].t[s].log2S) / 8;
                     if (s < 2) sa = std::max(sa, st_); else sb = std::max(sb, st_);
                 }
-                const bool small = (sa <= 2);  // the common case: 64/128-byte slabs for the first two tables
 #define BC_FUSED_LAUNCH(W_, NSEG_, MSA_, MSB_)                                                                   \
     hipLaunchKernelGGL((k_match_fused<W_, NSEG_, MSA_, MSB_>), dim3(grid), dim3(BLOCK), 0, st, dp, d_reads,      \
                        d_flags, n, lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots,         \
                        lib->kmask, max_mm, o)
 #define BC_FUSED_W(NSEG_, MSA_, MSB_) do { if (lib->wide) BC_FUSED_LAUNCH(true, NSEG_, MSA_, MSB_); else BC_FUSED_LAUNCH(false, NSEG_, MSA_, MSB_); } while (0)
+#define BC_FUSED_S(NSEG_)                                                        \
+    do {                                                                         \
+        if (sa <= 1 && sb <= 2) BC_FUSED_W(NSEG_, 1, 2);                         \
+        else if (sa <= 2 && sb <= 2) BC_FUSED_W(NSEG_, 2, 2);                    \
+        else if (sa <= 2) BC_FUSED_W(NSEG_, 2, 4);                               \
+        else BC_FUSED_W(NSEG_, 4, 4);                                            \
+    } while (0)
                 switch (nseg) {
-                    case 2: if (small) BC_FUSED_W(2, 2, 1); else BC_FUSED_W(2, 4, 1); break;
-                    case 3: if (small) BC_FUSED_W(3, 2, 4); else BC_FUSED_W(3, 4, 4); break;
-                    default: if (small) BC_FUSED_W(4, 2, 4); else BC_FUSED_W(4, 4, 4); break;
+                    case 2: BC_FUSED_S(2); break;
+                    case 3: BC_FUSED_S(3); break;
+                    default: BC_FUSED_S(4); break;
                 }
+#undef BC_FUSED_S
 #undef BC_FUSED_W
 #undef BC_FUSED_LAUNCH
             } else if (max_mm >= 1 && vec_ok && stage_mode == 2) {
