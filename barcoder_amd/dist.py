@@ -31,11 +31,14 @@ def init_from_env(backend: str | None = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if backend is None:  # BC_DIST_BACKEND=gloo lets one GPU rehearse the N > 1 path
+            backend = os.environ.get("BC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)
     return rank, world, local
 
 
