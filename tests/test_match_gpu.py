@@ -38,11 +38,14 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
     assert (res.best_idx >= 0).sum() > n // 2
 
 
-@pytest.mark.parametrize("env", [{"BC_TALLY": "1"}, {"BC_TALLY": "2"}, {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4"},
-                                 {"BC_SLAB_MIN_LOG2S": "3"}, {"BC_SLAB_MIN_LOG2S": "6"}])
+@pytest.mark.parametrize("env", [{"BC_TALLY": "1"}, {"BC_TALLY": "2"}, {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4", "BC_TWO_STAGE": "0"},
+                                 {"BC_SLAB_LOG2S": "3,3,3,3"}, {"BC_SLAB_LOG2S": "5,5,5,5"}, {"BC_SLAB_LOG2S": "4,3,5,4"},
+                                 {"BC_TWO_STAGE": "0"}, {"BC_TWO_STAGE": "2"}, {"BC_TWO_STAGE": "2", "BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4"},
+                                 {"BC_HASH_SLOTS_PCT": "120"}, {"BC_HASH_SLOTS_PCT": "3000"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
-    """Tally by global atomics vs LDS histogram, 4 vs 8 lanes per read, slab
-    sizes with and without overflow chains: identical outputs."""
+    """Tally by global atomics vs LDS histogram, fused vs two-kernel vs single
+    slab kernel, 4 vs 8 lanes per read, slab sizes with and without overflow
+    chains, hash tables from crowded to sparse: identical outputs."""
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)
     k, G, n = 20, 6000, 30001
