@@ -55,6 +55,13 @@ SIGNATURES = {
     "bc_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "bc_reader_next": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]),
     "bc_reader_close": (C.c_int, [vp]),
+    "bc_sample_data": (C.c_int, [C.c_char_p, C.c_char_p, vp, C.c_uint32, C.c_int, C.POINTER(vp)]),
+    "bc_sample_info": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "bc_sample_flanks": (C.c_int, [vp, C.c_int, C.c_int64, C.c_int, C.c_int, vp, C.POINTER(C.c_int), vp,
+                                   C.POINTER(C.c_int)]),
+    "bc_sample_free": (C.c_int, [vp]),
     "bc_lib_create": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]),
     "bc_lib_destroy": (C.c_int, [vp]),
     "bc_lib_info": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

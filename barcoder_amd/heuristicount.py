@@ -262,6 +262,55 @@ def find_flanks(reads, start, bc_len, max_flank=10):
     return best(tallies["L"]), best(tallies["R"])
 
 
+class NativeSample:
+    """sample_data + find_flanks through the C ABI (bc_sample_*): same results as the
+    Python functions above, without their per-k-mer interpreter cost."""
+
+    def __init__(self, file1, file2, barcodes, is_paired):
+        import ctypes as C
+        ordered = list(barcodes)
+        k = len(ordered[0])
+        if any(len(b) != k for b in ordered):
+            raise ValueError("All barcodes must be the same length")
+        blob = "".join(ordered).encode("ascii", errors="replace")
+        self._h = N.vp()
+        f2 = file2.encode() if (is_paired and file2) else None
+        N.check(N.load().bc_sample_data(file1.encode(), f2, blob, len(ordered), k, C.byref(self._h)))
+        nn, o1, o2 = C.c_int64(), C.c_int64(), C.c_int64()
+        v1, v2, ob, ch = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        sw, sat = C.c_int(), C.c_int()
+        N.check(N.load().bc_sample_info(self._h, C.byref(nn), C.byref(o1), C.byref(o2), C.byref(v1), C.byref(v2),
+                                        C.byref(ob), C.byref(sw), C.byref(ch), C.byref(sat)))
+        self.n_novel = nn.value
+        self.offset1 = None if o1.value < 0 else o1.value
+        self.offset2 = None if o2.value < 0 else o2.value
+        self.n_valid1, self.n_valid2, self.n_observed = v1.value, v2.value, ob.value
+        self.need_swap, self.num_chunks, self.satisfied = bool(sw.value), ch.value, bool(sat.value)
+        if not self.satisfied:
+            log.warning("Sequencing depth is probably insufficient! Continuing anyway...")
+
+    def flanks(self, which: int, start, bc_len: int, max_flank: int = 10):
+        """find_flanks(sample1 if which == 0 else sample2, start, bc_len)."""
+        import ctypes as C
+        if start is None:  # the reference would slice with None; an empty sample gives (None, None) there
+            return None, None
+        L, R = C.create_string_buffer(max_flank + 1), C.create_string_buffer(max_flank + 1)
+        ll, rl = C.c_int(), C.c_int()
+        N.check(N.load().bc_sample_flanks(self._h, which, int(start), bc_len, max_flank, L, C.byref(ll), R, C.byref(rl)))
+        return (None if ll.value < 0 else L.value.decode()), (None if rl.value < 0 else R.value.decode())
+
+    def close(self):
+        if self._h:
+            N.load().bc_sample_free(self._h)
+            self._h = N.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------------------ hot path
 class ChunkCounter:
     """Device-side state for process_chunk: the library in HBM plus the window
@@ -462,26 +511,23 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     bc_len = lengths.pop()
     is_paired = bool(file2)
     log.info("Sampling reads to identify diversity characteristics...")
-    (n_sampled, bc_start1, bc_start2, sample1, sample2, observed, need_swap, n_chunks) = \
-        sample_data(file1, file2, barcodes, is_paired)
+    ordered = [b for b in read_fasta_ordered(fasta_file) if b in barcodes]
+    smp = NativeSample(file1, file2, ordered, is_paired)
+    bc_start1, bc_start2, need_swap = smp.offset1, smp.offset2, smp.need_swap
     log.info("Sampled %s diverse contexts in %s chunks and found %s barcodes in %s forward and %s reverse reads...",
-             f"{n_sampled:,}", n_chunks, f"{safe_len(observed):,}", f"{safe_len(sample1):,}", f"{safe_len(sample2):,}")
+             f"{smp.n_novel:,}", smp.num_chunks, f"{smp.n_observed:,}", f"{smp.n_valid1:,}", f"{smp.n_valid2:,}")
     fwd_name = os.path.basename(file1)
     rev_name = os.path.basename(file2) if file2 else None
     if need_swap:
         log.info("Swapping orientation...")
         fwd_name, rev_name = rev_name, fwd_name
     log.info("Identifying flanking sequences...")
-    if sample1 is not None:
-        L_fwd, R_fwd = find_flanks(sample1, bc_start1, bc_len)
-        L_fwd_start = bc_start1 - len(L_fwd) if L_fwd else 0
-    else:
-        L_fwd = R_fwd = L_fwd_start = None
-    if sample2 is not None:
-        L_rev, R_rev = find_flanks(sample2, bc_start2, bc_len)
-        L_rev_start = bc_start2 - len(L_rev) if L_rev else 0
-    else:
-        L_rev = R_rev = L_rev_start = None
+    # sample1 / sample2 are never None in the reference (empty sets at worst): heuristicount.py:626-638
+    L_fwd, R_fwd = smp.flanks(0, bc_start1, bc_len)
+    L_fwd_start = bc_start1 - len(L_fwd) if L_fwd else 0
+    L_rev, R_rev = smp.flanks(1, bc_start2, bc_len)
+    L_rev_start = bc_start2 - len(L_rev) if L_rev else 0
+    smp.close()
     # the two mates must show reverse-complementary flanks (heuristicount.py:641-688)
     L_rev_rc = rev_comp(L_rev) if L_rev else None
     R_rev_rc = rev_comp(R_rev) if R_rev else None
@@ -501,7 +547,6 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
         raise ValueError("A critical error occurred: Flank complementarity violation")
 
     log.info("Executing high-throughput read analysis...")
-    ordered = [b for b in read_fasta_ordered(fasta_file) if b in barcodes]
     cc = ChunkCounter(ordered, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
                       device=device, max_mismatch=max_mismatch)
     total_reads = 0
@@ -542,11 +587,12 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     for _f, key, c in sorted(doc_events, key=lambda e: e[0]):
         doc[key] += c
     if u_words:
+        # chunks arrive in read order and each holds its own minimum, so the first occurrence of a
+        # word in the concatenation carries its global first index
         w = np.concatenate(u_words)
-        uw, inv = np.unique(w, return_inverse=True)
+        uw, first_at, inv = np.unique(w, return_index=True, return_inverse=True)
         uc = np.bincount(inv, weights=np.concatenate(u_counts).astype(np.float64), minlength=uw.size).astype(np.uint64)
-        uf = np.full(uw.size, np.iinfo(np.uint64).max, np.uint64)
-        np.minimum.at(uf, inv, np.concatenate(u_first))
+        uf = np.concatenate(u_first)[first_at]
     else:
         uw = uc = uf = np.zeros(0, np.uint64)
     undoc = PackedCounter(bc_len, uw, uc, uf, extra_undoc)

@@ -114,6 +114,23 @@ int bc_reader_next(bc_reader *r, uint64_t max_reads, char *h_text, uint64_t text
                    uint64_t *h_off /* max_reads + 1 */, uint64_t *n_out);
 int bc_reader_close(bc_reader *r);
 
+/* ---- sampling (host) --------------------------------------------------------
+ * bc_sample_data: orientation / barcode offset discovery on the first chunks of
+ * the reads file(s), heuristicount.py:156-379 (sample_data).  `barcodes` = G
+ * library entries of k characters.  The result object keeps the sampled reads;
+ * bc_sample_info returns the reference's tuple (offsets -1 = None), and
+ * bc_sample_flanks runs heuristicount.py:382-425 (find_flanks) on sample1 / sample2
+ * (flank length -1 = None; buffers need max_flank + 1 bytes). */
+typedef struct bc_sample bc_sample;
+int bc_sample_data(const char *file1, const char *file2 /* NULL = single-end */,
+                   const char *barcodes, uint32_t n_barcodes, int k, bc_sample **out);
+int bc_sample_info(const bc_sample *s, int64_t *n_novel, int64_t *offset1, int64_t *offset2,
+                   uint64_t *n_valid1, uint64_t *n_valid2, uint64_t *n_observed, int *need_swap,
+                   uint64_t *n_chunks, int *satisfied);
+int bc_sample_flanks(const bc_sample *s, int which, int64_t start, int bc_len, int max_flank,
+                     char *L_out, int *L_len, char *R_out, int *R_len);
+int bc_sample_free(bc_sample *s);
+
 /* ---- library -------------------------------------------------------------
  * bc_lib_create: upload G distinct packed guides (index = position in the
  * array = first-occurrence order of the de-duplicated library,

@@ -261,3 +261,20 @@ def test_native_reader_matches_python_reader(tmp_path):
     pz = tmp_path / "x.reads.zst"
     pz.write_bytes(dst.raw[:m])
     assert ingest.read_all(str(pz)) == reads
+
+
+def test_native_sampling_matches_reference(scenarios):
+    """bc_sample_data / bc_sample_flanks vs the golden sample_data / find_flanks results."""
+    from barcoder_amd import heuristicount as H
+    for s, fa, f1, f2 in scenarios:
+        smp = H.NativeSample(f1, f2, H.read_fasta_ordered(fa), s["paired"])
+        got = dict(n_novel=smp.n_novel, offset1=smp.offset1, offset2=smp.offset2, n_valid1=smp.n_valid1,
+                   n_valid2=smp.n_valid2, n_observed=smp.n_observed, need_swap=smp.need_swap,
+                   num_chunks=smp.num_chunks)
+        assert got == s["sample_data"], s["name"]
+        if s["name"] != "noflank":  # ties there depend on set order in the reference itself
+            f_1 = smp.flanks(0, smp.offset1, s["k"])
+            f_2 = smp.flanks(1, smp.offset2, s["k"])
+            assert list(f_1) == (s["flanks1"] or [None, None]), s["name"]
+            assert list(f_2) == (s["flanks2"] or [None, None]), s["name"]
+        smp.close()
