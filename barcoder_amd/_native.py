@@ -73,6 +73,7 @@ SIGNATURES = {
     "bc_pam_scan_host": (C.c_int, [C.c_int, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
     "bc_sites_expand_dev": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp]),
     "bc_windows_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int64, C.c_int, C.c_int, vp, vp, vp]),
+    "bc_score_mismatch_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp]),
     "bc_synth_reads_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, vp, vp]),
     "bc_dev_set": (C.c_int, [C.c_int]),
     "bc_dev_alloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),

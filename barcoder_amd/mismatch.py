@@ -103,3 +103,43 @@ def generate_mismatches(spacers, min_score, max_score, step, parameters, spacer_
 
 def generate_header():
     print("\t".join(["original", "variant", "change_description", "y_pred"]))
+
+
+# ---------------------------------------------------------------------------- device scoring
+def weights_vector(params: dict) -> np.ndarray:
+    """The reference's {feature: weight} dict in the layout of bc_score_mismatch_dev
+    (missing features weigh 0, like an absent CSV row would fail in the reference)."""
+    w = np.zeros(50, np.float64)
+    w[0] = params["intercept"]
+    for p in range(32):
+        w[1 + p] = params.get(f"{p}", 0.0)
+    for o, a in enumerate("ACGT"):
+        for v, b in enumerate("ACGT"):
+            w[33 + 4 * o + v] = params.get(f"{a}{b}", 0.0)
+    w[49] = params["GC_content"]
+    return w
+
+
+def y_pred_device(originals, variants, params: dict, device: int = 0):
+    """calculate_y_pred for many equal-length pairs on the GPU; list of float / None."""
+    from . import _native as N
+    from .devmem import DevBuf
+    from .encoding import pack_kmers
+    originals, variants = list(originals), list(variants)
+    if not originals:
+        return []
+    k = len(originals[0])
+    po, fo = pack_kmers(originals, k)
+    pv, fv = pack_kmers(variants, k)
+    if fo.any() or fv.any():
+        raise ValueError("sequences must be upper-case ACGT")
+    n = po.size
+    L = N.load()
+    N.check(L.bc_dev_set(device))
+    with DevBuf.from_numpy(po, device) as d_o, DevBuf.from_numpy(pv, device) as d_v, \
+            DevBuf.from_numpy(weights_vector(params), device) as d_w, DevBuf(n * 8, device) as d_y, \
+            DevBuf(n, device) as d_n:
+        N.check(L.bc_score_mismatch_dev(d_o.ptr, d_v.ptr, n, k, d_w.ptr, d_y.ptr, d_n.ptr, None))
+        y = d_y.to_numpy(np.float64, n)
+        none = d_n.to_numpy(np.uint8, n)
+    return [None if z else float(v) for v, z in zip(y, none)]

@@ -244,6 +244,15 @@ int bc_windows_dev(const uint64_t *d_bases, const uint32_t *d_invalid, uint64_t 
                    uint64_t n_pos, int64_t offset, int k, int strand, uint64_t *d_out,
                    uint8_t *d_flags, void *stream);
 
+/* ---- mismatch-efficacy score (mismatch.py:15-35 calculate_y_pred) ------------
+ * y_pred for n (original, variant) pairs of packed k-mers, float64, bit-identical
+ * to the reference's Python arithmetic.  d_weights[50]: [0] intercept, [1+p]
+ * position p (0..31), [33 + 4*o + v] substitution o->v (codes A C G T), [49]
+ * GC_content.  d_none[i] = 1 where the pair is identical (the reference
+ * returns None there); may be NULL. */
+int bc_score_mismatch_dev(const uint64_t *d_orig, const uint64_t *d_var, uint64_t n, int k,
+                          const double *d_weights, double *d_out, uint8_t *d_none, void *stream);
+
 /* ---- synthetic workloads (bench / tests) -----------
  * Counter-based splitmix64 streams, identical to barcoder_amd/synth.py.
  * mixture: 0 = exact (90 % library reads, 10 % random),

@@ -107,3 +107,30 @@ def test_mismatch_search_vs_oracle(gpu_device, oracle, plasmids, direction, circ
             want.add((guides[g], ts, te, strand, dist, ext, target, oracle.get_diff(guides[g], target)))
     assert got == want
     assert len(got) >= {0: 40, 2: 5, 3: 0}[pl]
+
+
+def test_mismatch_score_on_device_is_bit_exact(gpu_device):
+    """bc_score_mismatch_dev vs the reference's own y_pred values (float64, no tolerance)
+    and vs the pinned host mirror on 20k random pairs."""
+    import json
+    import random
+    from barcoder_amd import mismatch as M
+    m = json.load(open(os.path.join(GOLDEN, "mismatch.json")))
+    params = m["params"]
+    pairs = [(o, v, y) for o, v, y in m["pairs"]]
+    got = M.y_pred_device([p[0] for p in pairs], [p[1] for p in pairs], params, gpu_device)
+    for (o, v, want), g in zip(pairs, got):
+        assert g == want, (o, v, g, want)  # None == None for the identical pair, exact float equality otherwise
+    rng = random.Random(11)
+    orig, var = [], []
+    for _ in range(20000):
+        o = "".join(rng.choice("ACGT") for _ in range(20))
+        v = list(o)
+        for p in rng.sample(range(20), rng.randrange(0, 6)):
+            v[p] = rng.choice([c for c in "ACGT" if c != v[p]])
+        orig.append(o)
+        var.append("".join(v))
+    got = M.y_pred_device(orig, var, params, gpu_device)
+    want = [M.calculate_y_pred(o, v, params["GC_content"], params) for o, v in zip(orig, var)]
+    assert got == want
+    assert all(f"{a:.4f}" == f"{b:.4f}" for a, b in zip(got, want) if a is not None)
