@@ -278,3 +278,32 @@ def test_native_sampling_matches_reference(scenarios):
             assert list(f_1) == (s["flanks1"] or [None, None]), s["name"]
             assert list(f_2) == (s["flanks2"] or [None, None]), s["name"]
         smp.close()
+
+
+def test_c_abi_error_mapping():
+    """Status codes -> the exception classes the reference's Python code raises."""
+    import ctypes as C
+    from barcoder_amd import _native as N, encoding as E
+    L = N.load()
+    out = np.zeros(4, np.uint64)
+    assert L.bc_pack_kmers(b"ACGT", 1, 0, 4, N.ptr(out), None) == N.BC_EINVAL
+    assert b"bc_pack_kmers" in L.bc_last_error()
+    with pytest.raises(ValueError, match="bc_pack_kmers"):
+        N.check(L.bc_pack_kmers(b"ACGT", 1, 33, 33, N.ptr(out), None))
+    with pytest.raises(ValueError):
+        N.check(L.bc_lib_create(None, 0, 20, 0, C.byref(N.vp())))
+    with pytest.raises(ValueError, match="never match"):
+        E.pam_masks("NGR")
+    assert E.pam_masks("NGR", iupac=True).tolist() == [15, 4, 5]
+    off = np.array([0, 4], np.uint64)
+    with pytest.raises(ValueError, match="bc_pack_windows"):
+        E.pack_windows(b"ACGT", off, -1, "", "", 4)
+    # windows: N anywhere skips; flanks checked on the clamped python slice; odd characters flagged
+    text, off = E.reads_to_text(["TTACGTGG", "TTACNTGG", "TTACGT", "TTAcGTGG", "GGACGTGG", ""])
+    packed, status = E.pack_windows(text, off, 0, "TT", "GG", 4)
+    assert status.tolist() == [N.WIN_OK, N.WIN_SKIP, N.WIN_SKIP, N.WIN_ODD, N.WIN_SKIP, N.WIN_SKIP]
+    assert E.unpack_kmers(packed[:1], 4) == ["ACGT"]
+    packed_r, _ = E.pack_windows(text, off, 0, "TT", "GG", 4, reverse=True)
+    assert E.unpack_kmers(packed_r[:1], 4) == ["ACGT"]  # ACGT is its own reverse complement
+    text, off = E.reads_to_text(["TTAAGTGG"])
+    assert E.unpack_kmers(E.pack_windows(text, off, 0, "TT", "GG", 4, reverse=True)[0], 4) == ["ACTT"]
