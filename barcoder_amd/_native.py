@@ -32,12 +32,7 @@ ALGO_AUTO, ALGO_HASH, ALGO_SEED, ALGO_BRUTE, ALGO_SEED_CSR = 0, 1, 2, 3, 4
 ALGOS = {"auto": ALGO_AUTO, "hash": ALGO_HASH, "seed": ALGO_SEED, "brute": ALGO_BRUTE, "seed_csr": ALGO_SEED_CSR}
 WIN_OK, WIN_SKIP, WIN_ODD = 0, 1, 2
 
-u8p, u32p, u64p, i32p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32))
 vp = C.c_void_p
-
-
-class Hit(C.Structure):
-    _fields_ = [("query", C.c_uint32), ("guide", C.c_uint32), ("dist", C.c_uint32)]
 
 
 HIT_DTYPE = np.dtype([("query", np.uint32), ("guide", np.uint32), ("dist", np.uint32)])

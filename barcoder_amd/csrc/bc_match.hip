@@ -5,13 +5,21 @@
 // lookup + Counter update) and generalises it to <= d substitutions, which the
 // reference can only obtain from `bowtie -v N` (targets.py:496-509).
 //
-// Three algorithms over the same inputs / outputs:
-//   k_match_hash  : d = 0.  One open-addressing probe sequence per read into a
-//                   table that stays L2-resident (1e5 guides -> 2 MiB).
-//   k_match_seed  : d <= 3. Pigeonhole seed index: d+1 CSR bucket tables in L2;
-//                   every candidate is verified with XOR + popcount.
-//   k_match_brute : any d.  Guide table tiled through LDS, lane = read, all
-//                   pairs XOR + popcount.  VALU-bound; the in-GPU cross-check.
+// Algorithms over the same inputs / outputs (bc_match_dev selects):
+//   k_match_hash   : d = 0.  One open-addressing probe (two-slot buckets, one 16-byte
+//                    load) per read into a table that lives in L2 / Infinity Cache.
+//   k_match_fused  : d = 1..3, the default.  Per 2048-read tile: exact stage through the
+//                    hash table, reads without an exact hit queued in LDS, seed stage
+//                    (pigeonhole slab index, DPP quad per read, staged table rounds).
+//   k_match_slab / k_match_slabq : the same slab index as one kernel / as the second
+//                    kernel of a two-launch pipeline (tuning and fallback variants).
+//   k_match_seed   : CSR form of the seed index, lane = read (k > 28, huge libraries).
+//   k_match_all    : every (query, guide, dist) within d: the Bowtie -a -v N bypass.
+//   k_match_brute  : any d.  Guide table tiled through LDS, lane = read, all pairs
+//                    XOR + popcount.  VALU-bound; the in-GPU cross-check.
+//   k_hist         : per-guide counts + first-seen from best_idx, LDS-privatised.
+// Measured bound of the lookup kernels: ~0.3-0.4 vector-L1 (TCP) accesses per clock
+// per CU, i.e. the number of divergent table visits per read, not HBM or L2.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

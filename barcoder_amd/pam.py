@@ -218,9 +218,7 @@ class PAMFinder(PAMProcessor):
         if strand == 1:
             pam_sequence = seq[row.End:row.End + self.pam_length]
         else:
-            a = row.Start - self.pam_length
-            pam_sequence = seq[a:row.Start] if a >= 0 else seq[a:row.Start]  # python slice semantics
-            pam_sequence = _rc(pam_sequence)
+            pam_sequence = _rc(seq[row.Start - self.pam_length:row.Start])  # python slice semantics, like Bio.Seq
         return str(pam_sequence)
 
     def pam_matches(self, sequence):
