@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <vector>
 
 #include "bc_common.h"
@@ -85,5 +86,7 @@ struct bc_lib {
     uint32_t* q_idx = nullptr;
     uint32_t* q_count = nullptr;       // [MAX_BLOCKS] entries appended per workgroup
     uint64_t q_cap = 0;
+    void* host_slots = nullptr;    // HostSlot[3]: staging of bc_match_host, kept between calls
+    std::mutex host_mutex;
     std::vector<void*> owned;      // every device allocation, for destroy
 };

@@ -24,6 +24,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <type_traits>
 
 #include "bc_device.h"
@@ -1329,6 +1332,29 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
 
 }  // namespace
 
+struct HostSlot {
+    uint64_t cap = 0;
+    uint64_t* d_r = nullptr;
+    uint8_t *d_f = nullptr, *d_bd = nullptr, *d_nb = nullptr;
+    int32_t* d_bi = nullptr;
+    hipStream_t st = nullptr;
+};
+
+static int slot_reserve(HostSlot& s, uint64_t cap) {
+    if (!s.st) BC_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    if (cap <= s.cap) return BC_OK;
+    for (void* p : {(void*)s.d_r, (void*)s.d_f, (void*)s.d_bd, (void*)s.d_nb, (void*)s.d_bi}) if (p) (void)hipFree(p);
+    s.cap = 0;
+    BC_HIP(hipMalloc((void**)&s.d_r, cap * 8));
+    BC_HIP(hipMalloc((void**)&s.d_bi, cap * 4));
+    BC_HIP(hipMalloc((void**)&s.d_f, cap));
+    BC_HIP(hipMalloc((void**)&s.d_bd, cap));
+    BC_HIP(hipMalloc((void**)&s.d_nb, cap));
+    s.cap = cap;
+    return BC_OK;
+}
+
+
 extern "C" {
 
 int bc_device_count(int* n_out) {
@@ -1374,6 +1400,14 @@ int bc_lib_destroy(bc_lib* lib) {
     (void)hipSetDevice(lib->device);
     for (void* p : lib->owned) (void)hipFree(p);
     for (void* p : {(void*)lib->q_reads, (void*)lib->q_idx, (void*)lib->q_count}) if (p) (void)hipFree(p);
+    if (lib->host_slots) {
+        HostSlot* hs = (HostSlot*)lib->host_slots;
+        for (int w = 0; w < 3; ++w) {
+            for (void* p : {(void*)hs[w].d_r, (void*)hs[w].d_f, (void*)hs[w].d_bd, (void*)hs[w].d_nb, (void*)hs[w].d_bi}) if (p) (void)hipFree(p);
+            if (hs[w].st) (void)hipStreamDestroy(hs[w].st);
+        }
+        delete[] hs;
+    }
     delete lib;
     return BC_OK;
 }
@@ -1435,61 +1469,123 @@ int bc_match_all_dev(bc_lib* lib, const uint64_t* d_queries, const uint8_t* d_fl
     return BC_OK;
 }
 
+// Host buffers in, host results out.  The call is cut into chunks that HOST_WORKERS threads
+// take in turn, each with its own HIP stream and device staging slot (kept in the library
+// object between calls): while one worker copies results back, another uploads the next
+// chunk and a third one's kernels run, so H2D, compute and D2H overlap (PCIe is full duplex).
+// Counts / first-seen accumulate on the device across chunks and come back once.
 int bc_match_host(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, uint64_t n,
                   int max_mismatch, int algo, int32_t* h_best_idx, uint8_t* h_best_dist,
                   uint8_t* h_n_best, uint64_t* h_counts, uint64_t* h_first_seen,
                   uint64_t first_index_base) {
     if (!lib || (n && (!h_reads || !h_best_idx))) { set_error("bc_match_host: null argument"); return BC_EINVAL; }
+    if (n == 0) return BC_OK;
     BC_HIP(hipSetDevice(lib->device));
-    const uint64_t CH = 1ull << 24;
-    const uint64_t c = std::min<uint64_t>(std::max<uint64_t>(n, 1), CH);
-    uint64_t *d_r = nullptr, *d_fs = nullptr;
-    uint8_t *d_f = nullptr, *d_bd = nullptr, *d_nb = nullptr;
-    int32_t* d_bi = nullptr;
+    if (n > (1ull << 31)) {  // keep the 32-bit device counters safe: split very long calls
+        const uint64_t half = 1ull << 31;
+        for (uint64_t a = 0; a < n; a += half) {
+            const uint64_t m = std::min(half, n - a);
+            int rc = bc_match_host(lib, h_reads + a, h_flags ? h_flags + a : nullptr, m, max_mismatch, algo,
+                                   h_best_idx + a, h_best_dist ? h_best_dist + a : nullptr,
+                                   h_n_best ? h_n_best + a : nullptr, h_counts, h_first_seen, first_index_base + a);
+            if (rc != BC_OK) return rc;
+        }
+        return BC_OK;
+    }
+    constexpr int HOST_WORKERS = 3;
+    const uint64_t CH = 1ull << 23;  // 8M reads = 64 MB up, 48 MB down per chunk
+    const uint64_t n_chunks = (n + CH - 1) / CH;
+    // the two-kernel tuning variant shares one global miss queue per library: one worker only
+    const int workers = env_int("BC_TWO_STAGE", 1) == 2 ? 1 : (int)std::min<uint64_t>(HOST_WORKERS, n_chunks);
+    if (!lib->host_slots) lib->host_slots = new HostSlot[HOST_WORKERS];
+    HostSlot* slots = (HostSlot*)lib->host_slots;
+    std::lock_guard<std::mutex> guard(lib->host_mutex);  // the staging slots belong to one call at a time
+    for (int w = 0; w < workers; ++w) {
+        int rc = slot_reserve(slots[w], std::min(n, CH));
+        if (rc != BC_OK) return rc;
+    }
     uint32_t* d_c = nullptr;
-    int rc = BC_OK;
-    std::vector<uint32_t> c32;
-    std::vector<uint64_t> fs;
-    auto body = [&]() -> int {
-        BC_HIP(hipMalloc((void**)&d_r, c * 8));
-        BC_HIP(hipMalloc((void**)&d_bi, c * 4));
-        if (h_flags) BC_HIP(hipMalloc((void**)&d_f, c));
-        if (h_best_dist) BC_HIP(hipMalloc((void**)&d_bd, c));
-        if (h_n_best) BC_HIP(hipMalloc((void**)&d_nb, c));
-        if (h_counts) {
-            BC_HIP(hipMalloc((void**)&d_c, (size_t)lib->G * 4));
-            c32.resize(lib->G);
-        }
-        if (h_first_seen) {
-            BC_HIP(hipMalloc((void**)&d_fs, (size_t)lib->G * 8));
-            BC_HIP(hipMemset(d_fs, 0xFF, (size_t)lib->G * 8));
-            fs.resize(lib->G);
-        }
-        for (uint64_t a = 0; a < n; a += c) {
-            uint64_t m = std::min(c, n - a);
-            BC_HIP(hipMemcpy(d_r, h_reads + a, m * 8, hipMemcpyHostToDevice));
-            if (h_flags) BC_HIP(hipMemcpy(d_f, h_flags + a, m, hipMemcpyHostToDevice));
-            if (d_c) BC_HIP(hipMemset(d_c, 0, (size_t)lib->G * 4));
-            MatchOut o{d_bi, d_bd, d_nb, d_c, d_fs, first_index_base + a};
-            int r2 = launch_match(lib, d_r, d_f, m, max_mismatch, algo, o, 0);
-            if (r2 != BC_OK) return r2;
-            BC_HIP(hipDeviceSynchronize());
-            BC_HIP(hipMemcpy(h_best_idx + a, d_bi, m * 4, hipMemcpyDeviceToHost));
-            if (h_best_dist) BC_HIP(hipMemcpy(h_best_dist + a, d_bd, m, hipMemcpyDeviceToHost));
-            if (h_n_best) BC_HIP(hipMemcpy(h_n_best + a, d_nb, m, hipMemcpyDeviceToHost));
-            if (d_c) {
-                BC_HIP(hipMemcpy(c32.data(), d_c, (size_t)lib->G * 4, hipMemcpyDeviceToHost));
-                for (uint32_t g = 0; g < lib->G; ++g) h_counts[g] += c32[g];
+    uint64_t* d_fs = nullptr;
+    if (h_counts) {
+        BC_HIP(hipMalloc((void**)&d_c, (size_t)lib->G * 4));
+        BC_HIP(hipMemset(d_c, 0, (size_t)lib->G * 4));
+    }
+    if (h_first_seen) {
+        BC_HIP(hipMalloc((void**)&d_fs, (size_t)lib->G * 8));
+        BC_HIP(hipMemset(d_fs, 0xFF, (size_t)lib->G * 8));
+    }
+    BC_HIP(hipDeviceSynchronize());
+    // pageable copies serialise inside the runtime; pinning the caller's buffers for the duration of a
+    // large call lets the three workers' transfers really overlap (BC_HOST_PIN=0 disables)
+    std::vector<void*> pinned;
+    if (workers > 1 && env_int("BC_HOST_PIN", 1)) {
+        auto pin = [&](const void* p, size_t bytes) {
+            if (p && hipHostRegister((void*)p, bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back((void*)p);
+            else (void)hipGetLastError();
+        };
+        pin(h_reads, n * 8); pin(h_best_idx, n * 4); pin(h_flags, n); pin(h_best_dist, n); pin(h_n_best, n);
+    }
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> first_rc{BC_OK};
+    std::string err;
+    std::mutex err_mutex;
+    auto work = [&](int w) {
+        HostSlot& s = slots[w];
+        auto fail = [&](int rc) {
+            int expect = BC_OK;
+            if (first_rc.compare_exchange_strong(expect, rc)) {
+                std::lock_guard<std::mutex> g(err_mutex);
+                err = bc_last_error();
             }
+        };
+        if (hipSetDevice(lib->device) != hipSuccess) { set_error("hipSetDevice failed in a worker"); fail(BC_EHIP); return; }
+        auto step = [&](uint64_t a, uint64_t m) -> int {
+            BC_HIP(hipMemcpyAsync(s.d_r, h_reads + a, m * 8, hipMemcpyHostToDevice, s.st));
+            if (h_flags) BC_HIP(hipMemcpyAsync(s.d_f, h_flags + a, m, hipMemcpyHostToDevice, s.st));
+            MatchOut o{s.d_bi, h_best_dist ? s.d_bd : nullptr, h_n_best ? s.d_nb : nullptr, d_c, d_fs, first_index_base + a};
+            int rc = launch_match(lib, s.d_r, h_flags ? s.d_f : nullptr, m, max_mismatch, algo, o, s.st);
+            if (rc != BC_OK) return rc;
+            BC_HIP(hipMemcpyAsync(h_best_idx + a, s.d_bi, m * 4, hipMemcpyDeviceToHost, s.st));
+            if (h_best_dist) BC_HIP(hipMemcpyAsync(h_best_dist + a, s.d_bd, m, hipMemcpyDeviceToHost, s.st));
+            if (h_n_best) BC_HIP(hipMemcpyAsync(h_n_best + a, s.d_nb, m, hipMemcpyDeviceToHost, s.st));
+            BC_HIP(hipStreamSynchronize(s.st));
+            return BC_OK;
+        };
+        for (;;) {
+            const uint64_t c = next.fetch_add(1);
+            if (c >= n_chunks || first_rc.load() != BC_OK) break;
+            const uint64_t a = c * CH, m = std::min(CH, n - a);
+            int rc = step(a, m);
+            if (rc != BC_OK) { fail(rc); break; }
+        }
+    };
+    if (workers == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < workers; ++w) th.emplace_back(work, w);
+        for (auto& t : th) t.join();
+    }
+    int rc = first_rc.load();
+    if (rc != BC_OK) set_error("%s", err.c_str());
+    auto finish = [&]() -> int {
+        BC_HIP(hipDeviceSynchronize());
+        if (d_c) {
+            std::vector<uint32_t> c32(lib->G);
+            BC_HIP(hipMemcpy(c32.data(), d_c, (size_t)lib->G * 4, hipMemcpyDeviceToHost));
+            for (uint32_t g = 0; g < lib->G; ++g) h_counts[g] += c32[g];
         }
         if (d_fs) {
+            std::vector<uint64_t> fs(lib->G);
             BC_HIP(hipMemcpy(fs.data(), d_fs, (size_t)lib->G * 8, hipMemcpyDeviceToHost));
             for (uint32_t g = 0; g < lib->G; ++g) h_first_seen[g] = std::min(h_first_seen[g], fs[g]);
         }
         return BC_OK;
     };
-    rc = body();
-    for (void* p : {(void*)d_r, (void*)d_bi, (void*)d_f, (void*)d_bd, (void*)d_nb, (void*)d_c, (void*)d_fs}) (void)hipFree(p);
+    if (rc == BC_OK) rc = finish();
+    for (void* p : pinned) (void)hipHostUnregister(p);
+    if (d_c) (void)hipFree(d_c);
+    if (d_fs) (void)hipFree(d_fs);
     return rc;
 }
 
