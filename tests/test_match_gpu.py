@@ -121,3 +121,33 @@ def test_synth_device_matches_numpy(gpu_device):
             np.testing.assert_array_equal(out, S.reads(lib, k, 2 + mix, 1000, n, mix))
     finally:
         L.bc_dev_free(d)
+
+
+def test_large_library_and_misaligned_device_pointers(gpu_device):
+    """2e6 guides (longer seeds, bigger slabs) and device pointers that are not
+    16-byte aligned (vector paths must fall back): fast kernels == brute force."""
+    import torch
+    k, G, n = 20, 2_000_000, 60_001
+    lib = S.library(G, k)
+    reads = S.reads(lib, k, 13, 0, n + 1, 1)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    m = GpuMatcher(dl)
+    for d in (0, 2):
+        ref = m.match(reads[:n], None, max_mismatch=d, algo="brute")
+        got = m.match(reads[:n], None, max_mismatch=d, algo="seed" if d else "hash")
+        _check(got, {"best_idx": ref.best_idx, "best_dist": ref.best_dist, "n_best": ref.n_best,
+                     "counts": ref.counts, "first_seen": ref.first_seen})
+    # device path with every buffer offset by one element
+    dev = torch.device("cuda", gpu_device)
+    tr = torch.from_numpy(reads.view(np.int64)).to(dev)
+    bi = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    bd = torch.empty(n + 1, dtype=torch.uint8, device=dev)
+    nb = torch.empty(n + 1, dtype=torch.uint8, device=dev)
+    for d, algo in ((2, "seed"), (0, "hash")):
+        ref = m.match(reads[1:], None, max_mismatch=d, algo="brute")
+        m.match_dev(tr[1:].data_ptr(), n, bi[1:].data_ptr(), max_mismatch=d, algo=algo, d_best_dist=bd[1:].data_ptr(),
+                    d_n_best=nb[1:].data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(bi[1:].cpu().numpy(), ref.best_idx)
+        np.testing.assert_array_equal(bd[1:].cpu().numpy(), ref.best_dist)
+        np.testing.assert_array_equal(nb[1:].cpu().numpy(), ref.n_best)
