@@ -13,8 +13,11 @@ Mirrors (reference file:line):
   row building of parse_sam_output (no annotation join)            targets.py:354-410
   PySamParser.ranges column contract                               PySamParser.py:38-46
 
-Gene annotation (``create_locus_map``, targets.py:76-165) needs GenBank features
-and is not part of this path; rows carry the columns that do not depend on it.
+  create_locus_map as intervals + gene join (annotate)              targets.py:76-165, :412-462
+  drop_duplicates / PAM filter / sort / note / columns / TSV        targets.py:605-701
+
+Gene features come from any source as `Gene` records (tests use the SnapGene
+feature tables of the shipped plasmids; a GenBank reader is not included).
 """
 from __future__ import annotations
 
@@ -210,3 +213,142 @@ def ranges_table(rows):
                     "Strand": "+" if r["sp_dir"] == "F" else "-", "Barcode": r["spacer"],
                     "Mismatches": r["mismatches"]})
     return out
+
+
+# ------------------------------------------------------------------ annotation join + output table
+@dataclass
+class Gene:
+    """One `gene` feature: what create_locus_map (targets.py:76-165) keeps per position."""
+    chrom: str
+    start: int          # 0-based, half-open
+    end: int
+    strand: int         # +1 / -1
+    locus_tag: str | None
+    gene: str | None = None
+
+
+def read_genes_tsv(path, seq_lens=None):
+    """chr, parts ("a-b;c-d", 0-based half-open), strand, locus_tag, gene -> list[Gene].
+    Like create_locus_map: a feature in several parts contributes one Gene per part with that
+    part's own bounds (targets.py:129-148), except a compound location that touches both ends of
+    the record, which becomes ONE interval from the start of its last part to the end of its first
+    part + len(record) (targets.py:105-128).  `seq_lens` ({chr: length}) enables that rule."""
+    genes = []
+    with open(path) as fh:
+        next(fh)
+        for line in fh:
+            c, parts, strand, lt, gn = line.rstrip("\n").split("\t")
+            iv = [tuple(int(x) for x in part.split("-")) for part in parts.split(";")]
+            lt, gn = (None if lt == "None" else lt), (None if gn == "None" else gn)
+            n = (seq_lens or {}).get(c)
+            if len(iv) > 1 and n is not None and any(a == 0 or b == n for a, b in iv):
+                tail = next((p for p in iv if p[1] == n), None)
+                head = next((p for p in iv if p[0] == 0), None)
+                if tail and head:
+                    genes.append(Gene(c, tail[0], head[1] + n, int(strand), lt, gn))
+                    continue
+            genes += [Gene(c, a, b, int(strand), lt, gn) for a, b in iv]
+    return genes
+
+
+def annotate(rows, genes):
+    """The gene join of parse_sam_output (targets.py:412-462): a hit row is repeated for every gene
+    that covers at least one base of [tar_start, tar_end); rows without a gene keep None fields.
+    The reference walks a per-base dict; interval overlap gives the same set."""
+    by_chr = {}
+    for g in genes:
+        by_chr.setdefault(g.chrom, []).append(g)
+    starts = {}
+    for c, lst in by_chr.items():
+        lst.sort(key=lambda g: g.start)
+        starts[c] = np.array([g.start for g in lst])
+    out = []
+    for r in rows:
+        lst = by_chr.get(r["chr"], [])
+        a, b = r["tar_start"], r["tar_end"]
+        hit = []
+        if lst:
+            hi = int(np.searchsorted(starts[r["chr"]], b, side="left"))  # genes starting before tar_end
+            hit = [g for g in lst[:hi] if g.end > a and g.start < b and max(a, g.start) < min(b, g.end)]
+        if not hit:
+            out.append(dict(r, locus_tag=None, gene=None, offset=None, overlap=None, tar_dir=None))
+            continue
+        seen = set()
+        for g in hit:
+            key = (g.locus_tag, g.gene, g.start, g.end, g.strand)
+            if key in seen:
+                continue
+            seen.add(key)
+            tdir = "F" if g.strand == 1 else "R" if g.strand == -1 else None
+            out.append(dict(r, locus_tag=g.locus_tag, gene=g.gene if g.gene else g.locus_tag,
+                            offset=get_offset(tdir, a, b, g.start, g.end), overlap=get_overlap(a, b, g.start, g.end),
+                            tar_dir=tdir))
+    return out
+
+
+def create_note(sites, genes, intergenic):
+    """targets.py:547-557."""
+    if sites <= 0:
+        return "non-targeting"
+    parts = [f"{sites} {'site' if sites == 1 else 'sites'}"]
+    if genes > 0:
+        parts.append(f"{genes} {'gene' if genes == 1 else 'genes'}")
+    if intergenic > 0:
+        parts.append(f"{intergenic} intergenic")
+    return ", ".join(parts)
+
+
+def final_table(rows, seq_lens):
+    """The post-processing of targets.main (targets.py:605-688) on annotated rows:
+    de-duplicate, drop PAM-less rows of spacers that do target, sort by (chr, min_tar, spacer),
+    per-spacer site / gene / intergenic counts -> note, column selection.
+    Returns (columns, list of row dicts)."""
+    def freeze(r, keys):
+        return tuple(r.get(k) for k in keys)
+    all_keys = ["name", "spacer", "len", "target", "mismatches", "chr", "tar_start", "tar_end", "sp_dir", "pam",
+                "coords", "type", "diff", "locus_tag", "gene", "offset", "overlap", "tar_dir"]
+    rows = list({freeze(r, all_keys): r for r in rows}.values())                      # drop_duplicates (:607)
+    targeting = {r["spacer"] for r in rows if r.get("target") is not None}            # filter_offtargets_by_pam
+    rows = [r for r in rows if not (r.get("target") is None and r["spacer"] in targeting)]
+
+    def min_tar(r):                                                                    # :624-628
+        if r.get("tar_start") is None:
+            return float("inf")
+        return r["tar_start"] - seq_lens[r["chr"]] if r["tar_start"] > r["tar_end"] else r["tar_start"]
+    rows.sort(key=lambda r: (r.get("chr") or "", min_tar(r), r["spacer"]))            # :629-630
+    names = {}
+    for r in rows:
+        names.setdefault(r["spacer"], set()).add(r["name"])
+    keys_wo_name = [k for k in all_keys if k != "name"]
+    rows = list({freeze(r, keys_wo_name): r for r in rows}.values())                  # :635
+    sites, genes, inter = {}, {}, {}
+    for r in rows:
+        if r.get("target") is not None:
+            sites.setdefault(r["spacer"], set()).add(f"{r['chr']}_{r['coords']}")
+            if r.get("locus_tag") is None:
+                inter[r["spacer"]] = inter.get(r["spacer"], 0) + 1
+        if r.get("locus_tag") is not None:
+            genes[r["spacer"]] = genes.get(r["spacer"], 0) + 1
+    out = []
+    for r in rows:
+        sp = r["spacer"]
+        out.append(dict(r, count=len(names[sp]),
+                        note=create_note(len(sites.get(sp, ())), genes.get(sp, 0), inter.get(sp, 0))))
+    cols = ["spacer", "locus_tag", "gene", "chr"]
+    if any(r["count"] != 1 for r in out):
+        cols.append("count")
+    pams = {r.get("pam") for r in out if r.get("pam") is not None}
+    if not (not pams or (len(pams) == 1 and all(r.get("pam") is not None for r in out))):
+        cols.append("pam")
+    if any(r.get("mismatches") not in (0, None) for r in out):
+        cols.append("mismatches")
+    cols += ["target", "tar_start", "tar_end", "offset", "overlap", "sp_dir", "tar_dir", "note"]
+    return cols, out
+
+
+def to_tsv(cols, rows) -> str:
+    """DataFrame.to_csv(sep='\\t', index=False, na_rep='None') of targets.py:701."""
+    lines = ["\t".join(cols)]
+    for r in rows:
+        lines.append("\t".join("None" if r.get(c) is None else str(r[c]) for c in cols))
+    return "\n".join(lines) + "\n"

@@ -18,6 +18,7 @@ Outputs
   cn32_plasmid_rows.tsv       rows of Example_Libraries/CN-32-zmo.tsv on those plasmids
   cn32_spacers.txt.gz         the `spacer` column of CN-32-zmo.tsv (library of config 1)
   pam_guidefinder.json.gz     GuideFinder.find_guides_from_pam outputs on the plasmids
+  plasmid_genes.tsv           gene features of the 4 plasmids (SnapGene feature table: reference DATA)
 """
 import contextlib
 import gzip
@@ -256,6 +257,35 @@ def read_snapgene(path):
     raise ValueError("no sequence packet")
 
 
+def read_snapgene_genes(path):
+    """Gene features of a SnapGene file (packet 10 = XML feature table): 0-based half-open
+    interval, strand (+1 / -1 from directionality 1 / 2), locus_tag and gene qualifiers — the
+    fields targets.create_locus_map (targets.py:76-165) takes from the GenBank record."""
+    import xml.etree.ElementTree as ET
+    with open(path, "rb") as f:
+        data = f.read()
+    at, xml = 0, None
+    while at < len(data):
+        t = data[at]
+        (ln,) = struct.unpack(">I", data[at + 1:at + 5])
+        if t == 10:
+            xml = data[at + 5:at + 5 + ln].decode("utf8")
+            break
+        at += 5 + ln
+    genes = []
+    for f in ET.fromstring(xml):
+        if f.get("type") != "gene":
+            continue
+        q = {qq.get("name"): (qq.find("V").get("text") or qq.find("V").get("predef")) for qq in f.findall("Q")}
+        parts = []
+        for seg in f.findall("Segment"):
+            a, b = seg.get("range").split("-")
+            parts.append((int(a) - 1, int(b)))  # a > b: the segment runs across the origin of a circular record
+        strand = {"1": 1, "2": -1}.get(f.get("directionality"), 0)
+        genes.append((parts, strand, q.get("locus_tag"), q.get("gene")))
+    return genes
+
+
 class Rec:
     """Duck-typed record for GuideFinder: .seq supports str() and .reverse_complement()."""
 
@@ -278,6 +308,15 @@ def pam_cases(P):
             f.write(f">{k} circular={int(circ)}\n")
             for i in range(0, len(s), 80):
                 f.write(s[i:i + 80] + "\n")
+    with open(os.path.join(OUT, "plasmid_genes.tsv"), "w") as f:
+        f.write("chr\tparts\tstrand\tlocus_tag\tgene\n")
+        for nme in names:
+            for parts, strand, lt, gn in read_snapgene_genes(os.path.join(REF, "GCA_003054575.1", nme + ".dna")):
+                L = len(seqs[nme + ".1"][0])
+                # an origin-spanning segment becomes the two parts GenBank's join(a..L,1..b) has
+                flat = [q for a, b in parts for q in ([(a, b)] if a < b else [(a, L), (0, b)])]
+                f.write("\t".join([nme + ".1", ";".join(f"{a}-{b}" for a, b in flat), str(strand), lt or "None",
+                                   gn or "None"]) + "\n")
     recs = {k: Rec(s) for k, (s, _) in seqs.items()}
     out = {}
     for pam, L in (("NGG", 20), ("NGNC", 32), ("TTTN", 23), ("GGGGGGG", 20)):

@@ -134,3 +134,38 @@ def test_mismatch_score_on_device_is_bit_exact(gpu_device):
     want = [M.calculate_y_pred(o, v, params["GC_content"], params) for o, v in zip(orig, var)]
     assert got == want
     assert all(f"{a:.4f}" == f"{b:.4f}" for a, b in zip(got, want) if a is not None)
+
+
+def test_annotated_table_matches_shipped_tsv(gpu_device, plasmids):
+    """find_hits -> annotate -> final_table against every column of the reference's shipped rows on
+    the plasmids (locus_tag, gene, offset, overlap, tar_dir included; `note` where all of a spacer's
+    sites lie on the plasmids, since the chromosome's GenBank file is not shipped)."""
+    from collections import Counter
+    from barcoder_amd import targets as T
+    gold = _golden_rows()
+    genes = T.read_genes_tsv(os.path.join(GOLDEN, "plasmid_genes.tsv"), {c.name: len(c.seq) for c in plasmids})
+    assert len(genes) == 160
+    spacers = list(dict.fromkeys(r["spacer"] for r in gold))
+    rows = T.find_hits(spacers, plasmids, pam="NGNC", num_mismatches=0, device=gpu_device)
+    cols, table = T.final_table(T.annotate(rows, genes), {c.name: len(c.seq) for c in plasmids})
+    assert cols == ["spacer", "locus_tag", "gene", "chr", "pam", "target", "tar_start", "tar_end", "offset", "overlap",
+                    "sp_dir", "tar_dir", "note"]  # `mismatches` drops out: all zero in a plasmid-only run (:676-677)
+    common = [c for c in cols if c != "note"]
+    # the shipped library went through design_guides.py --orientation forward (design_guides.py:113-115):
+    # rows whose spacer and gene strands differ were dropped there
+    assert sum(r["sp_dir"] != r["tar_dir"] for r in table) == 3
+    table = [r for r in table if r["sp_dir"] == r["tar_dir"]]
+    got = Counter(tuple(str(r[c]) for c in common) for r in table)
+    want = Counter(tuple(r[c] for c in common) for r in gold)
+    assert got == want and sum(got.values()) == 772
+    # notes: comparable when the reference's site count equals what the plasmids alone show
+    mine = {(r["spacer"], r["chr"], str(r["tar_start"]), r["locus_tag"]): r["note"] for r in table}
+    n_cmp = 0
+    for r in gold:
+        note = mine[(r["spacer"], r["chr"], r["tar_start"], r["locus_tag"])]
+        if note.split(",")[0] == r["note"].split(",")[0]:
+            assert note == r["note"]
+            n_cmp += 1
+    assert n_cmp >= 600
+    text = T.to_tsv(cols, table)
+    assert text.count("\n") == 773 and text.startswith("spacer\tlocus_tag\tgene\tchr\tpam\ttarget")
