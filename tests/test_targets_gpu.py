@@ -169,3 +169,43 @@ def test_annotated_table_matches_shipped_tsv(gpu_device, plasmids):
     assert n_cmp >= 600
     text = T.to_tsv(cols, table)
     assert text.count("\n") == 773 and text.startswith("spacer\tlocus_tag\tgene\tchr\tpam\ttarget")
+
+
+def test_crispri_library_on_gpu_hits(gpu_device, plasmids):
+    """testing_grounds.py:20-43 with the Bowtie / pysam / pyranges stages replaced: hits from the GPU,
+    CRISPRiLibrary views checked against a direct restatement on plain rows.  (The reference's class
+    needs pyranges + Biopython, absent here: this adapter's parity is unpinned by the reference.)"""
+    from barcoder_amd import targets as T
+    from barcoder_amd.crispri import CRISPRiLibrary, joined_frame
+    from barcoder_amd.pam import PAMFinder
+    gold = _golden_rows()
+    lens = {c.name: len(c.seq) for c in plasmids}
+    genes = T.read_genes_tsv(os.path.join(GOLDEN, "plasmid_genes.tsv"), lens)
+    spacers = list(dict.fromkeys(r["spacer"] for r in gold))[:200]
+    rows = T.find_hits(spacers, plasmids, pam="", num_mismatches=1, device=gpu_device)
+    df = joined_frame(rows, genes, lens)
+    assert {"Type", "Targeting", "Mapped", "Barcode", "Start", "End", "Start_b", "End_b", "Strand_b", "Chromosome"} - {"Targeting"} <= set(df.columns)
+    records = {c.name: c.seq + c.seq[:100] for c in plasmids}
+    lib = CRISPRiLibrary(df, PAMFinder(records, "NGNC", "downstream"))
+    # restatement on plain rows
+    targeting = {}
+    for r in rows:
+        a = r["tar_start"] % lens[r["chr"]]
+        topo = records[r["chr"]]
+        pam = topo[a + 32:a + 36] if r["sp_dir"] == "F" else T.rev_comp(topo[a - 4:a] if a >= 4 else topo[a - 4:a])
+        ok = len(pam) == 4 and pam[1] == "G" and pam[3] == "C" and set(pam) <= set("ACGT")
+        targeting[(r["spacer"], r["chr"], a, r["sp_dir"])] = ok
+    good_hits = [k for k, v in targeting.items() if v]
+    assert set(lib.source_unique_targets.Barcode) == {k[0] for k in good_hits}
+    assert len(lib.source_unique_targets) == len({k[0] for k in good_hits})
+    mt = lib.mapped_targets
+    assert (mt["Type"] == "gene").all() and (mt["Overlap"] > 0).all()
+    exp_pairs = 0
+    for (sp, ch, a, sd) in good_hits:
+        exp_pairs += sum(1 for g in genes if g.chrom == ch and g.start < a + 32 and g.end > a)
+    assert len(mt) == exp_pairs
+    r0 = mt.iloc[0]
+    assert r0.Offset == (r0.Start - r0.Start_b if r0.Strand_b == "+" else r0.End_b - r0.End)
+    assert list(lib.unique_targets.sort_values(["Chromosome", "Start", "End"]).index) == list(lib.unique_targets.index)
+    assert not lib.unambiguous_targets.duplicated(subset=["Barcode"]).any()
+    assert len(lib.unambiguous_targets) <= len(lib.unique_targets) <= len(mt)
