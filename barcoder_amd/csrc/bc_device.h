@@ -70,6 +70,7 @@ struct bc_lib {
     int k = 0;
     uint64_t kmask = 0;
     std::vector<uint64_t> h_guides;
+    std::vector<uint8_t> h_nn;     // distance to the nearest other guide (empty = not computed)
     uint64_t* d_guides = nullptr;  // [G] original order (also the brute-force tile source)
     // exact-match open-addressing table
     int log_slots = 0;

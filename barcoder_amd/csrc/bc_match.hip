@@ -517,7 +517,9 @@ __device__ __forceinline__ uint32_t slab_scan_fast(const SlabTable& T, const uin
             const uint32_t x0 = rest ^ v[st].x, x1 = rest ^ v[st].z;
             const uint32_t d0 = __popc((x0 | (x0 >> T.half)) & hmask);
             const uint32_t d1 = __popc((x1 | (x1 >> T.half)) & hmask);
-            const uint32_t k0 = (d0 << 24) | v[st].y, k1 = (d1 << 24) | v[st].w;  // empty / link slots stay 0xFFFFFFFx
+            // key = dist << 24 | isolated << 23 | guide (empty / link slots stay 0xFFFFFFFx)
+            const uint32_t k0 = (d0 << 24) | ((v[st].x >> 8) & 0x00800000u) | v[st].y;
+            const uint32_t k1 = (d1 << 24) | ((v[st].z >> 8) & 0x00800000u) | v[st].w;
             kmin = min(kmin, min(k0, k1));
             kmax = max(kmax, max(k0 + bias, k1 + bias));
             if (st == nstep - 1) { lz = v[st].z; lw = v[st].w; }
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_slabq(const SlabParams* __restr
         const bool hit = (kmin >> 24) <= (uint32_t)max_mm;
         if (hit && (kmax - bias) != kmin) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
         if (sub == 0) {
-            if (hit) emit(o, i, (int32_t)(key & 0xFFFFFFu), key >> 24, nb);
+            if (hit) emit(o, i, (int32_t)(key & 0x7FFFFFu), key >> 24, nb);
             else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0);
         }
     }
@@ -761,7 +763,11 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
                 }
             }
             kmin = grp_min<LPR>(kmin);
-            if (NSEG > 2 && (kmin >> 24) > 1u) {
+            // a single candidate so far that is isolated at radius 2*max_mm is the answer: nothing else can be
+            // within max_mm of this read (k_nn_dist), so the remaining tables are not visited
+            const bool settled = (kmin >> 24) <= (uint32_t)max_mm && (kmin & 0x00800000u) &&
+                                 (grp_max<LPR>(kmax) - bias) == kmin;
+            if (NSEG > 2 && (kmin >> 24) > 1u && !settled) {
                 // round B: the remaining tables can only add guides at distance >= 2
                 constexpr int RB = NSEG > 2 ? NSEG - 2 : 1;
                 uint4 v[RB][MSB];
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
             const bool hit = (kmin >> 24) <= (uint32_t)max_mm;
             if (hit && (kmax - bias) != kmin) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
             if (sub == 0) {  // the entry now carries its result: index | dist << 32 | n_best << 40
-                const uint32_t ri = hit ? (key & 0xFFFFFFu) : (uint32_t)BC_IDX_MISS;
+                const uint32_t ri = hit ? (key & 0x7FFFFFu) : (uint32_t)BC_IDX_MISS;
                 const uint32_t rd = hit ? (key >> 24) : (uint32_t)BC_DIST_NONE;
                 const uint32_t rn_ = hit ? (nb > 255u ? 255u : nb) : 0u;
                 q_slot[qi] = (uint64_t)ri | ((uint64_t)rd << 32) | ((uint64_t)rn_ << 40);
@@ -922,6 +928,34 @@ __global__ __launch_bounds__(BLOCK) void k_match_brute(const uint64_t* __restric
 }
 
 // ---------------------------------------------------------------------------
+// Library preprocessing: distance from every guide to its nearest other guide
+// (LDS-tiled all pairs, the brute-force kernel's inner loop).  A guide whose
+// nearest neighbour is farther than 2 * max_mm is "isolated": once a read is
+// found within max_mm of it, no other guide can be within max_mm of that read
+// (triangle inequality), so the remaining seed tables need not be visited.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_nn_dist(const uint64_t* __restrict__ guides, uint32_t G, uint64_t kmask,
+                                                   uint8_t* __restrict__ out) {
+    __shared__ uint64_t tile[BRUTE_TILE];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t me = (i < G) ? (guides[i] & kmask) : 0;
+    const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
+    uint32_t best = 255u;
+    for (uint32_t t0 = 0; t0 < G; t0 += BRUTE_TILE) {
+        const uint32_t tn = min((uint32_t)BRUTE_TILE, G - t0);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < tn; j += BLOCK) tile[j] = guides[t0 + j] & kmask;
+        __syncthreads();
+        for (uint32_t j = 0; j < tn; ++j) {
+            const uint64_t g = tile[j];
+            const uint32_t d = __popc((lo ^ (uint32_t)g) | (hi ^ (uint32_t)(g >> 32)));
+            best = (t0 + j != i) ? min(best, d) : best;
+        }
+    }
+    if (i < G) out[i] = (uint8_t)best;
+}
+
+// ---------------------------------------------------------------------------
 // synthetic reads (bench / tests)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_synth_reads(const uint64_t* __restrict__ guides, uint32_t G,
@@ -971,7 +1005,7 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     SlabParams& sl = lib->slab[d];
     if (s == 0) { sl.nseg = cs.nseg; lib->slab_ok[d] = true; }
     const int start = cs.start[s], slen = cs.slen[s], half = lib->k - slen;
-    if (2 * half > 32 || lib->G >= (1u << 24) || lib->k > 28) { lib->slab_ok[d] = false; return BC_OK; }  // rest: one dword; index: 24 bits
+    if (2 * half > 31 || lib->G >= (1u << 23) || lib->k > 28) { lib->slab_ok[d] = false; return BC_OK; }  // rest + flag: one dword; index: 23 bits
     if (!lib->slab_ok[d]) return BC_OK;
     const uint32_t nb = 1u << (2 * slen);
     // slab size: 64-byte slabs (7 entries + link) while the mean bucket fits, else 128-byte slabs and
@@ -1008,7 +1042,9 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
                 cur = nxt;
                 pos = 0;
             }
-            slabs[(cur << log2S) + pos++] = make_uint2(rest_of(keys[j]), gidx[j]);
+            // bit 31 = this guide is isolated at radius 2*d (see k_nn_dist); every scan masks it out with hmask
+            const uint32_t iso = (!lib->h_nn.empty() && lib->h_nn[gidx[j]] > 2 * d) ? 0x80000000u : 0u;
+            slabs[(cur << log2S) + pos++] = make_uint2(rest_of(keys[j]) | iso, gidx[j]);
         }
     }
     uint2* d_slabs;
@@ -1070,6 +1106,22 @@ int build_seed_index(bc_lib* lib, int d) {
     }
     return BC_OK;
 }
+
+// nearest-neighbour distances for the isolation flags (all pairs: only for libraries up to 4M guides)
+int compute_nn(bc_lib* lib) {
+    lib->h_nn.clear();
+    if (lib->G < 2 || lib->G > 4000000u || !env_int("BC_ISOLATION", 1)) return BC_OK;
+    uint8_t* d_nn = nullptr;
+    BC_HIP(hipMalloc((void**)&d_nn, lib->G));
+    hipLaunchKernelGGL(k_nn_dist, dim3((lib->G + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, lib->d_guides, lib->G, lib->kmask, d_nn);
+    lib->h_nn.resize(lib->G);
+    hipError_t e = hipMemcpy(lib->h_nn.data(), d_nn, lib->G, hipMemcpyDeviceToHost);
+    (void)hipFree(d_nn);
+    if (e != hipSuccess) { lib->h_nn.clear(); set_error("k_nn_dist: %s", hipGetErrorString(e)); return BC_EHIP; }
+    return BC_OK;
+}
+
+int build_seed_index(bc_lib* lib, int d);
 
 int build_hash(bc_lib* lib) {
     const int k = lib->k;
@@ -1388,6 +1440,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->device = device; lib->G = n_guides; lib->k = k; lib->kmask = km;
     lib->h_guides.assign(h_guides, h_guides + n_guides);
     int rc = dev_upload(lib, lib->h_guides, &lib->d_guides);
+    if (rc == BC_OK) rc = compute_nn(lib);
     if (rc == BC_OK) rc = build_hash(lib);
     for (int d = 0; d < MAX_SEG && rc == BC_OK; ++d) rc = build_seed_index(lib, d);
     if (rc != BC_OK) { bc_lib_destroy(lib); return rc; }
