@@ -632,7 +632,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_slabq(const SlabParams* __restr
 constexpr int FUSED_T = 2048;                 // reads per workgroup
 constexpr int FUSED_IT = FUSED_T / (BLOCK * 4);
 
-template <bool WIDE, int NSEG, int MSA, int MSB>
+template <bool WIDE, int NSEG, int MSA, int MSB, bool SM>
 __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restrict__ spp,
                                                        const uint64_t* __restrict__ reads,
                                                        const uint8_t* __restrict__ flags, uint64_t n,
@@ -645,11 +645,11 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
     // An entry's 8 bytes hold the read until the seed stage has used it, then its result.
     __shared__ uint64_t q_slot[FUSED_T];
     __shared__ uint16_t q_pos[FUSED_T];
-    __shared__ uint32_t q_n;
+    __shared__ uint32_t q_n, q_head;
     const SlabParams& sp = *spp;
     const uint64_t tile0 = (uint64_t)blockIdx.x * FUSED_T;
     const uint32_t tn = (uint32_t)min((uint64_t)FUSED_T, n - tile0);  // reads in this tile
-    if (threadIdx.x == 0) q_n = 0;
+    if (threadIdx.x == 0) { q_n = 0; q_head = 0; }
     __syncthreads();
 
     // ---- phase 1: exact stage; exact hits (and skips) are final and stored at once, coalesced
@@ -724,7 +724,107 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
 
     // ---- phase 2: seed stage over the LDS queue, one DPP quad per read
     const uint32_t qn = q_n;
-    {
+    if constexpr (SM) {
+        // State machine: every quad owns one queued read at a time and, per step, fetches and scans up to
+        // two 64-byte pieces — both first-round slabs of a fresh read, an overflow slab, or the third
+        // table's slab of a read that is not settled yet.  Quads in different stages share the same load
+        // and scan instructions (only addresses and per-quad constants differ), so a wave never idles
+        // through another quad's extra round, and reads are handed out dynamically from the LDS queue.
+        // Geometry handled here: 8-entry slabs for tables 0 and 1, 8- or 16-entry slabs for table 2.
+        constexpr int LPR = 4;
+        const int sub = threadIdx.x & 3;
+        const int last_lane = (threadIdx.x & 63) | 3;
+        const uint32_t bias = (255u - (uint32_t)max_mm) << 24;
+        const SlabTable& T0 = sp.t[0];
+        const SlabTable& T1 = sp.t[NSEG > 1 ? 1 : 0];
+        const SlabTable& T2 = sp.t[NSEG > 2 ? 2 : 0];
+        const bool t2_two = NSEG > 2 && T2.log2S == 4;
+        const uint4 none = make_uint4(0u, SLAB_EMPTY, 0u, SLAB_EMPTY);
+        int state = 0;  // 0 need a read, 1 first round (tables 0,1 + their chains), 2 table 2 (+ chain), 3 no reads left
+        uint32_t qi = 0, rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+        const uint4 *p0 = nullptr, *p1 = nullptr;
+        uint32_t rest0 = 0, rest1 = 0, half0 = 1, half1 = 1;
+        bool link0 = false, link1 = false;  // the piece ends with the slab's link slot
+        for (;;) {
+            if (state == 0) {
+                uint32_t mine = 0;
+                if (sub == 0) mine = atomicAdd(&q_head, 1u);
+                qi = quad_perm<0x00>(mine);
+                if (qi < qn) {
+                    const uint64_t r = q_slot[qi];
+                    rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
+                    kmin = 0xFFFFFFFFu; kmax = 0u;
+                    p0 = reinterpret_cast<const uint4*>(T0.slabs + ((size_t)seed_value(rlo, rhi, T0.start, T0.slen) << 3));
+                    rest0 = slab_rest(T0, rlo, rhi); half0 = T0.half; link0 = true;
+                    if (NSEG > 1) {
+                        p1 = reinterpret_cast<const uint4*>(T1.slabs + ((size_t)seed_value(rlo, rhi, T1.start, T1.slen) << 3));
+                        rest1 = slab_rest(T1, rlo, rhi); half1 = T1.half; link1 = true;
+                    } else { p1 = nullptr; link1 = false; }
+                    state = 1;
+                } else {
+                    state = 3; p0 = nullptr; p1 = nullptr;
+                }
+            }
+            if (__ballot(state != 3) == 0ull) break;
+            // one load instruction per piece for every quad, whatever its stage
+            uint4 v0 = none, v1 = none;
+            if (p0) v0 = p0[sub];
+            if (p1) v1 = p1[sub];
+            {
+                const uint32_t hm0 = (1u << half0) - 1u, hm1 = (1u << half1) - 1u;
+                const uint32_t xa = rest0 ^ v0.x, xb = rest0 ^ v0.z, xc = rest1 ^ v1.x, xd = rest1 ^ v1.z;
+                const uint32_t da = __popc((xa | (xa >> half0)) & hm0), db = __popc((xb | (xb >> half0)) & hm0);
+                const uint32_t dc = __popc((xc | (xc >> half1)) & hm1), dd = __popc((xd | (xd >> half1)) & hm1);
+                const uint32_t ka = (da << 24) | ((v0.x >> 8) & 0x00800000u) | v0.y;
+                const uint32_t kb = (db << 24) | ((v0.z >> 8) & 0x00800000u) | v0.w;
+                const uint32_t kc = (dc << 24) | ((v1.x >> 8) & 0x00800000u) | v1.y;
+                const uint32_t kd = (dd << 24) | ((v1.z >> 8) & 0x00800000u) | v1.w;
+                kmin = min(min(kmin, ka), min(kb, min(kc, kd)));
+                kmax = max(max(kmax, ka + bias), max(kb + bias, max(kc + bias, kd + bias)));
+            }
+            // link slots: the second entry of lane 3 of a piece that ends its slab
+            const uint32_t l0 = link0 ? quad_perm<0xFF>(v0.w == SLAB_LINK ? v0.z : 0u) : 0u;
+            const uint32_t l1 = link1 ? quad_perm<0xFF>(v1.w == SLAB_LINK ? v1.z : 0u) : 0u;
+            bool finish = false;
+            if (state == 1) {
+                if (l0 | l1) {  // overflow slabs of table 0 / 1: same stage, next step
+                    p0 = l0 ? reinterpret_cast<const uint4*>(T0.slabs + ((size_t)l0 << 3)) : nullptr;
+                    p1 = l1 ? reinterpret_cast<const uint4*>(T1.slabs + ((size_t)l1 << 3)) : nullptr;
+                } else {
+                    const uint32_t km = grp_min<LPR>(kmin);
+                    const bool settled = (km >> 24) <= (uint32_t)max_mm && (km & 0x00800000u) &&
+                                         (grp_max<LPR>(kmax) - bias) == km;
+                    if (NSEG > 2 && (km >> 24) > 1u && !settled) {
+                        const uint4* b = reinterpret_cast<const uint4*>(
+                            T2.slabs + ((size_t)seed_value(rlo, rhi, T2.start, T2.slen) << T2.log2S));
+                        p0 = b; p1 = t2_two ? b + 4 : nullptr;
+                        rest0 = rest1 = slab_rest(T2, rlo, rhi); half0 = half1 = T2.half;
+                        link0 = !t2_two; link1 = t2_two;
+                        state = 2;
+                    } else finish = true;
+                }
+            } else if (state == 2) {
+                const uint32_t l = t2_two ? l1 : l0;
+                if (l) {
+                    const uint4* b = reinterpret_cast<const uint4*>(T2.slabs + ((size_t)l << T2.log2S));
+                    p0 = b; p1 = t2_two ? b + 4 : nullptr;
+                } else finish = true;
+            }
+            if (finish) {
+                const uint32_t km = grp_min<LPR>(kmin), kx = grp_max<LPR>(kmax);
+                uint32_t key = km, nb = 1u;
+                const bool hit = (km >> 24) <= (uint32_t)max_mm;
+                if (hit && (kx - bias) != km) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
+                if (sub == 0) {
+                    const uint32_t ri = hit ? (key & 0x7FFFFFu) : (uint32_t)BC_IDX_MISS;
+                    const uint32_t rd = hit ? (key >> 24) : (uint32_t)BC_DIST_NONE;
+                    const uint32_t rn_ = hit ? (nb > 255u ? 255u : nb) : 0u;
+                    q_slot[qi] = (uint64_t)ri | ((uint64_t)rd << 32) | ((uint64_t)rn_ << 40);
+                }
+                state = 0;
+            }
+        }
+    } else {
         const int sub = threadIdx.x & (LPR - 1);
         const int last_lane = (threadIdx.x & 63) | (LPR - 1);
         const uint32_t bias = (255u - (uint32_t)max_mm) << 24;
@@ -1295,7 +1395,11 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     if (s < 2) sa = std::max(sa, st_); else sb = std::max(sb, st_);
                 }
 #define BC_FUSED_LAUNCH(W_, NSEG_, MSA_, MSB_)                                                                   \
-    hipLaunchKernelGGL((k_match_fused<W_, NSEG_, MSA_, MSB_>), dim3(grid), dim3(BLOCK), 0, st, dp, d_reads,      \
+    hipLaunchKernelGGL((k_match_fused<W_, NSEG_, MSA_, MSB_, false>), dim3(grid), dim3(BLOCK), 0, st, dp,        \
+                       d_reads, d_flags, n, lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, \
+                       lib->kmask, max_mm, o)
+#define BC_FUSED_SM(W_, NSEG_)                                                                                   \
+    hipLaunchKernelGGL((k_match_fused<W_, NSEG_, 1, 1, true>), dim3(grid), dim3(BLOCK), 0, st, dp, d_reads,      \
                        d_flags, n, lib->d_slots64, lib->d_slots32, lib->d_guides, lib->k, lib->log_slots,         \
                        lib->kmask, max_mm, o)
 #define BC_FUSED_W(NSEG_, MSA_, MSB_) do { if (lib->wide) BC_FUSED_LAUNCH(true, NSEG_, MSA_, MSB_); else BC_FUSED_LAUNCH(false, NSEG_, MSA_, MSB_); } while (0)
@@ -1306,11 +1410,18 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
         else if (sa <= 2) BC_FUSED_W(NSEG_, 2, 4);                               \
         else BC_FUSED_W(NSEG_, 4, 4);                                            \
     } while (0)
-                switch (nseg) {
+                // the quad state machine handles 8-entry slabs for tables 0,1 and 8/16-entry slabs for table 2
+                const SlabParams& hp = lib->slab[max_mm];
+                const bool sm_ok = env_int("BC_PHASE2_SM", 1) && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
+                                   hp.t[1].log2S == 3 && (nseg == 2 || hp.t[2].log2S == 3 || hp.t[2].log2S == 4);
+                if (sm_ok && nseg == 2) { if (lib->wide) BC_FUSED_SM(true, 2); else BC_FUSED_SM(false, 2); }
+                else if (sm_ok && nseg == 3) { if (lib->wide) BC_FUSED_SM(true, 3); else BC_FUSED_SM(false, 3); }
+                else switch (nseg) {
                     case 2: BC_FUSED_S(2); break;
                     case 3: BC_FUSED_S(3); break;
                     default: BC_FUSED_S(4); break;
                 }
+#undef BC_FUSED_SM
 #undef BC_FUSED_S
 #undef BC_FUSED_W
 #undef BC_FUSED_LAUNCH

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--max-mismatch", type=int, default=MAX_MM)
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = ~15 s worth)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mixture", type=int, default=1, help="synthetic stream: 1 = SURVEY cfg3 mismatch mix (default), 0 = cfg2 exact mix")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +92,7 @@ def main():
     counts64 = torch.zeros(args.guides, dtype=torch.int64, device=dev)
     first_seen = torch.full((args.guides,), -1, dtype=torch.int64, device=dev)  # 0xFFFF.. = unseen
     first = rank * n  # global index of this rank's first read (weak scaling: n per GPU)
-    m.synth_reads_dev(seed, first, n, 1, reads.data_ptr(), stream)
+    m.synth_reads_dev(seed, first, n, args.mixture, reads.data_ptr(), stream)
     torch.cuda.synchronize()
 
     def step():
