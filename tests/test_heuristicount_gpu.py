@@ -113,3 +113,22 @@ def test_config1_cn32_library(gpu_device, oracle):
     assert n == n2 == 10_000
     assert list(got.items()) == list(want.items())
     assert sum(v for k, v in got.items() if not k.endswith("*")) > 8000
+
+
+def test_cli_twin(gpu_device, tmp_path):
+    """`python -m barcoder_amd.heuristicount lib.fasta reads.fastq.gz` prints the reference's stdout."""
+    import subprocess
+    import sys
+    s = next(x for x in _load("heuristicount_main.json.gz") if x["name"] == "fwd_single")
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">bc{i}\n{b}\n" for i, b in enumerate(s["barcodes"])))
+    fq = tmp_path / "reads.fastq.gz"
+    with gzip.open(fq, "wt") as f:
+        for i, r in enumerate(s["reads1"]):
+            f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "barcoder_amd.heuristicount", str(fa), str(fq)], cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout == s["stdout"]
+    assert "Total Reads" in out.stderr and "Documented Barcode Reads" in out.stderr
