@@ -49,8 +49,16 @@ struct SeedParams {
 // neither an offset lookup nor a separate index lookup.  The last entry of a
 // slab is a link {next slab, LINK} to an overflow slab appended after the
 // primaries.  Requires 2*(k - slen) <= 32 so that the rest fits one dword.
+// Entry = {rest, giw}: giw = guide index (22 bits) | isolation flags.  With d = the table's max_mismatch and nn =
+// distance to the guide's nearest other guide (k_nn_dist): SLAB_F_ISO = nn > 2*d, SLAB_F_ISO1 = nn > 2*(d-1).
+// A read whose best guide g lies at distance e <= d has no second guide within e when nn(g) > 2*e, so the flags
+// prove n_best = 1 without looking any further.
 constexpr uint32_t SLAB_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t SLAB_LINK = 0xFFFFFFFEu;
+constexpr int SLAB_GIDX_BITS = 22;
+constexpr uint32_t SLAB_GIDX_MASK = (1u << SLAB_GIDX_BITS) - 1u;
+constexpr uint32_t SLAB_F_ISO1 = 1u << 22;
+constexpr uint32_t SLAB_F_ISO = 1u << 23;
 struct SlabTable {
     const uint2* slabs;
     uint32_t start, slen, half;   // seed position / length; half = k - slen

@@ -395,12 +395,13 @@ __device__ __forceinline__ uint32_t slab_scan(const SlabTable& T, const uint4 (&
         if (st < nstep) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const uint32_t er = e ? v[st].z : v[st].x, gi = e ? v[st].w : v[st].y;
+                const uint32_t er = e ? v[st].z : v[st].x, gw = e ? v[st].w : v[st].y;
                 const uint32_t x = rest ^ er;
                 const uint32_t mm = (x | (x >> T.half)) & hmask;
                 const uint32_t d = __popc(mm);
                 if (d <= b.cur) {
-                    bool ok = gi < SLAB_LINK;
+                    bool ok = gw < SLAB_LINK;
+                    const uint32_t gi = gw & SLAB_GIDX_MASK;
 #pragma unroll
                     for (int t = 0; t < S; ++t) ok = ok && ((mm & T.dmask[t]) != 0u);  // not met through an earlier seed
                     if (ok) {
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_slab(const SlabParams* __restri
         const uint32_t mine = (md <= 3u) ? (uint32_t)((b.cnt >> (16 * (md & 3u))) & 0xFFFFu) : 0u;
         const uint32_t nb = grp_sum<LPR>(mine);
         if (sub == 0) {
-            if (key != 0xFFFFFFFFu) emit(o, i, (int32_t)(key & 0xFFFFFFu), md, nb);
+            if (key != 0xFFFFFFFFu) emit(o, i, (int32_t)(key & SLAB_GIDX_MASK), md, nb);
             else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0);
         }
     }
@@ -517,9 +518,9 @@ __device__ __forceinline__ uint32_t slab_scan_fast(const SlabTable& T, const uin
             const uint32_t x0 = rest ^ v[st].x, x1 = rest ^ v[st].z;
             const uint32_t d0 = __popc((x0 | (x0 >> T.half)) & hmask);
             const uint32_t d1 = __popc((x1 | (x1 >> T.half)) & hmask);
-            // key = dist << 24 | isolated << 23 | guide (empty / link slots stay 0xFFFFFFFx)
-            const uint32_t k0 = (d0 << 24) | ((v[st].x >> 8) & 0x00800000u) | v[st].y;
-            const uint32_t k1 = (d1 << 24) | ((v[st].z >> 8) & 0x00800000u) | v[st].w;
+            // key = dist << 24 | flags | guide (empty / link slots stay 0xFFFFFFFx)
+            const uint32_t k0 = (d0 << 24) | v[st].y;
+            const uint32_t k1 = (d1 << 24) | v[st].w;
             kmin = min(kmin, min(k0, k1));
             kmax = max(kmax, max(k0 + bias, k1 + bias));
             if (st == nstep - 1) { lz = v[st].z; lw = v[st].w; }
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_slabq(const SlabParams* __restr
         const bool hit = (kmin >> 24) <= (uint32_t)max_mm;
         if (hit && (kmax - bias) != kmin) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
         if (sub == 0) {
-            if (hit) emit(o, i, (int32_t)(key & 0x7FFFFFu), key >> 24, nb);
+            if (hit) emit(o, i, (int32_t)(key & SLAB_GIDX_MASK), key >> 24, nb);
             else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0);
         }
     }
@@ -775,10 +776,10 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
                 const uint32_t xa = rest0 ^ v0.x, xb = rest0 ^ v0.z, xc = rest1 ^ v1.x, xd = rest1 ^ v1.z;
                 const uint32_t da = __popc((xa | (xa >> half0)) & hm0), db = __popc((xb | (xb >> half0)) & hm0);
                 const uint32_t dc = __popc((xc | (xc >> half1)) & hm1), dd = __popc((xd | (xd >> half1)) & hm1);
-                const uint32_t ka = (da << 24) | ((v0.x >> 8) & 0x00800000u) | v0.y;
-                const uint32_t kb = (db << 24) | ((v0.z >> 8) & 0x00800000u) | v0.w;
-                const uint32_t kc = (dc << 24) | ((v1.x >> 8) & 0x00800000u) | v1.y;
-                const uint32_t kd = (dd << 24) | ((v1.z >> 8) & 0x00800000u) | v1.w;
+                const uint32_t ka = (da << 24) | v0.y;
+                const uint32_t kb = (db << 24) | v0.w;
+                const uint32_t kc = (dc << 24) | v1.y;
+                const uint32_t kd = (dd << 24) | v1.w;
                 kmin = min(min(kmin, ka), min(kb, min(kc, kd)));
                 kmax = max(max(kmax, ka + bias), max(kb + bias, max(kc + bias, kd + bias)));
             }
@@ -792,7 +793,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
                     p1 = l1 ? reinterpret_cast<const uint4*>(T1.slabs + ((size_t)l1 << 3)) : nullptr;
                 } else {
                     const uint32_t km = grp_min<LPR>(kmin);
-                    const bool settled = (km >> 24) <= (uint32_t)max_mm && (km & 0x00800000u) &&
+                    const bool settled = (km >> 24) <= (uint32_t)max_mm && (km & SLAB_F_ISO) &&
                                          (grp_max<LPR>(kmax) - bias) == km;
                     if (NSEG > 2 && (km >> 24) > 1u && !settled) {
                         const uint4* b = reinterpret_cast<const uint4*>(
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
                 const bool hit = (km >> 24) <= (uint32_t)max_mm;
                 if (hit && (kx - bias) != km) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
                 if (sub == 0) {
-                    const uint32_t ri = hit ? (key & 0x7FFFFFu) : (uint32_t)BC_IDX_MISS;
+                    const uint32_t ri = hit ? (key & SLAB_GIDX_MASK) : (uint32_t)BC_IDX_MISS;
                     const uint32_t rd = hit ? (key >> 24) : (uint32_t)BC_DIST_NONE;
                     const uint32_t rn_ = hit ? (nb > 255u ? 255u : nb) : 0u;
                     q_slot[qi] = (uint64_t)ri | ((uint64_t)rd << 32) | ((uint64_t)rn_ << 40);
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
             kmin = grp_min<LPR>(kmin);
             // a single candidate so far that is isolated at radius 2*max_mm is the answer: nothing else can be
             // within max_mm of this read (k_nn_dist), so the remaining tables are not visited
-            const bool settled = (kmin >> 24) <= (uint32_t)max_mm && (kmin & 0x00800000u) &&
+            const bool settled = (kmin >> 24) <= (uint32_t)max_mm && (kmin & SLAB_F_ISO) &&
                                  (grp_max<LPR>(kmax) - bias) == kmin;
             if (NSEG > 2 && (kmin >> 24) > 1u && !settled) {
                 // round B: the remaining tables can only add guides at distance >= 2
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
             const bool hit = (kmin >> 24) <= (uint32_t)max_mm;
             if (hit && (kmax - bias) != kmin) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
             if (sub == 0) {  // the entry now carries its result: index | dist << 32 | n_best << 40
-                const uint32_t ri = hit ? (key & 0x7FFFFFu) : (uint32_t)BC_IDX_MISS;
+                const uint32_t ri = hit ? (key & SLAB_GIDX_MASK) : (uint32_t)BC_IDX_MISS;
                 const uint32_t rd = hit ? (key >> 24) : (uint32_t)BC_DIST_NONE;
                 const uint32_t rn_ = hit ? (nb > 255u ? 255u : nb) : 0u;
                 q_slot[qi] = (uint64_t)ri | ((uint64_t)rd << 32) | ((uint64_t)rn_ << 40);
@@ -901,6 +902,293 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
             for (int s = 0; s < RA; ++s)
 #pragma unroll
                 for (int st = 0; st < MSA; ++st) v[s][st] = vn[s][st];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: queued reads' results over the placeholders phase 1 left (same lines, still in L2)
+    for (uint32_t qi = threadIdx.x; qi < qn; qi += BLOCK) {
+        const uint64_t e = q_slot[qi];
+        const int32_t idx = (int32_t)(uint32_t)e;
+        if (idx == BC_IDX_MISS) continue;  // the placeholder already says so
+        const uint64_t i = tile0 + q_pos[qi];
+        o.best_idx[i] = idx;
+        if (o.best_dist) o.best_dist[i] = (uint8_t)(e >> 32);
+        if (o.n_best) o.n_best[i] = (uint8_t)(e >> 40);
+        tally(o, i, idx);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2+K3 lane form (default for d = 1, 2): ONE LANE PER READ, no hash table.
+// The quad kernel above spends 88 % of the VALU issue slots (SQ_INSTS_VALU,
+// profiles/prof_insts.sh) — 11.6 wave-instructions per read, most of them state
+// handling shared by only 16 reads per wave — and its 7.4 MB of tables overflow
+// the 4 MB L2 (41 % misses -> Infinity-Fabric bound at the same time).  Here:
+//   * table 0 doubles as the exact-match table (a guide equal to the read sits in
+//     the read's seed-0 bucket), so the 4 MB hash table is gone: 3.7 MB of slabs;
+//   * a lane fetches a whole 64-byte piece (4 x 16 B, one line) and scans its 8
+//     entries itself: xor, shift, and-or, popcount, shift-or, min — 5.5 VALU
+//     per entry, nothing cross-lane, 64 reads per wave-instruction;
+//   * n_best = 1 is proven by the isolation flags of the best guide instead of a
+//     second (max) reduction; only a best guide with a close neighbour takes the
+//     exact quad path (slab_slow), through its own compacted list.
+// Per 1024-read tile: phase 1 scans every read's primary slab of table 0 (exact
+// hits final, coalesced stores); the others are queued in LDS with the partial
+// minimum and the overflow link.  Phase 2a: table 1 + overflow slabs of tables
+// 0/1, then the decision (after tables 0..j every guide within distance j has
+// been seen).  Phase 2b: the reads that still need table 2, compacted so that
+// the wave is full again.  Phase 2c: exact path for ambiguous reads.  Phase 3:
+// queued reads' results over the placeholders.
+// ---------------------------------------------------------------------------
+constexpr int LANE_T = 1024;  // reads per workgroup (4 per lane)
+
+// minimum of key = dist << 24 | flags | guide over the 8 entries of one 64-byte piece
+__device__ __forceinline__ uint32_t scan_piece(const uint4 (&v)[4], uint32_t rest, uint32_t half, uint32_t hmask,
+                                               uint32_t kmin) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t x0 = rest ^ v[e].x, x1 = rest ^ v[e].z;
+        const uint32_t d0 = __popc((x0 & hmask) | (x0 >> half));
+        const uint32_t d1 = __popc((x1 & hmask) | (x1 >> half));
+        kmin = min(kmin, min((d0 << 24) | v[e].y, (d1 << 24) | v[e].w));
+    }
+    return kmin;
+}
+
+// is the best candidate provably the only guide at its distance?
+__device__ __forceinline__ bool lane_unique(uint32_t key, uint32_t max_mm) {
+    const uint32_t d = key >> 24;
+    return d == 0u || (key & (d == max_mm ? SLAB_F_ISO : SLAB_F_ISO1)) != 0u;
+}
+
+__device__ __forceinline__ uint64_t pack_result(uint32_t idx, uint32_t dist, uint32_t nb) {
+    return (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)nb << 40);
+}
+
+template <int NSEG>
+__global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restrict__ spp,
+                                                      const uint64_t* __restrict__ reads,
+                                                      const uint8_t* __restrict__ flags, uint64_t n, int k,
+                                                      uint64_t kmask, int max_mm_, MatchOut o) {
+    static_assert(NSEG == 2 || NSEG == 3, "lane kernel: d = 1 or 2");
+    __shared__ uint64_t q_slot[LANE_T];   // queued read; later its result
+    __shared__ uint32_t q_key[LANE_T];    // best key so far (table 0's primary slab)
+    __shared__ uint32_t q_link[LANE_T];   // overflow slab of table 0 (0 = none)
+    __shared__ uint16_t q_pos[LANE_T];    // position in the tile
+    __shared__ uint16_t l_t2[LANE_T];     // queue entries that need table 2
+    __shared__ uint16_t l_slow[LANE_T];   // queue entries that need the exact path
+    __shared__ uint32_t q_n, t2_n, slow_n;
+    const SlabParams& sp = *spp;
+    const uint32_t max_mm = (uint32_t)max_mm_;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * LANE_T;
+    const uint32_t tn = (uint32_t)min((uint64_t)LANE_T, n - tile0);
+    if (threadIdx.x == 0) { q_n = 0; t2_n = 0; slow_n = 0; }
+    __syncthreads();
+    const SlabTable& T0 = sp.t[0];
+    const SlabTable& T1 = sp.t[1];
+    const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
+    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
+    const uint32_t lane = threadIdx.x & 63;
+
+    // ---- phase 1: table 0, primary slab, every read
+    {
+        const uint32_t p0 = threadIdx.x * 4u;
+        uint64_t r[4] = {0, 0, 0, 0};
+        const bool full = p0 + 3 < tn;
+        if (full) {
+            load_reads4(reads + tile0 + p0, r);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) r[j] = reads[tile0 + p0 + j];
+        }
+        int32_t idx[4];
+        uint32_t key[4], link[4];
+        bool push[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = p0 + j < tn;
+            idx[j] = BC_IDX_SKIP; push[j] = false; key[j] = 0xFFFFFFFFu; link[j] = 0u;
+            if (in && !read_skipped(r[j], flags, tile0 + p0 + j, k)) {
+                r[j] &= kmask;
+                const uint32_t rlo = (uint32_t)r[j], rhi = (uint32_t)(r[j] >> 32);
+                const uint4* p = reinterpret_cast<const uint4*>(T0.slabs + ((size_t)seed_value(rlo, rhi, T0.start, T0.slen) << 3));
+                uint4 v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = p[c];
+                key[j] = scan_piece(v, slab_rest(T0, rlo, rhi), half0, hm0, 0xFFFFFFFFu);
+                link[j] = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
+                if ((key[j] >> 24) == 0u) idx[j] = (int32_t)(key[j] & SLAB_GIDX_MASK);  // the guide itself: final
+                else { idx[j] = BC_IDX_MISS; push[j] = true; }
+            }
+        }
+        if (full) {
+            reinterpret_cast<int4*>(o.best_idx + tile0)[p0 >> 2] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            if (o.best_dist) {
+                uchar4 d;
+                d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
+                d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
+                reinterpret_cast<uchar4*>(o.best_dist + tile0)[p0 >> 2] = d;
+            }
+            if (o.n_best) {
+                uchar4 c;
+                c.x = idx[0] >= 0; c.y = idx[1] >= 0; c.z = idx[2] >= 0; c.w = idx[3] >= 0;
+                reinterpret_cast<uchar4*>(o.n_best + tile0)[p0 >> 2] = c;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) {
+                    o.best_idx[tile0 + p0 + j] = idx[j];
+                    if (o.best_dist) o.best_dist[tile0 + p0 + j] = idx[j] >= 0 ? 0 : BC_DIST_NONE;
+                    if (o.n_best) o.n_best[tile0 + p0 + j] = idx[j] >= 0;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
+        // wave-aggregated append to the LDS queue
+        unsigned long long mask[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mask[j] = __ballot(push[j]); total += (uint32_t)__popcll(mask[j]); }
+        if (total) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&q_n, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (push[j]) {
+                    const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[j] >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask[j], 0u));
+                    q_slot[at] = r[j];
+                    q_key[at] = key[j];
+                    q_link[at] = link[j];
+                    q_pos[at] = (uint16_t)(p0 + j);
+                }
+                base += (uint32_t)__popcll(mask[j]);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t qn = q_n;
+
+    // ---- phase 2a: table 1, overflow slabs of tables 0 and 1, decision
+    for (uint32_t qb = 0; qb < qn; qb += BLOCK) {
+        const uint32_t qi = qb + threadIdx.x;
+        const bool have = qi < qn;
+        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, c0 = 0, c1 = 0, rest1 = 0;
+        if (have) {
+            const uint64_t r = q_slot[qi];
+            rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
+            kmin = q_key[qi]; c0 = q_link[qi];
+            const uint4* p = reinterpret_cast<const uint4*>(T1.slabs + ((size_t)seed_value(rlo, rhi, T1.start, T1.slen) << 3));
+            uint4 v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = p[c];
+            rest1 = slab_rest(T1, rlo, rhi);
+            kmin = scan_piece(v, rest1, half1, hm1, kmin);
+            c1 = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
+        }
+        while (__ballot((c0 | c1) != 0u) != 0ull) {  // overflow chains, one slab per lane and turn
+            if ((c0 | c1) != 0u) {
+                const bool t0 = c0 != 0u;
+                const uint2* base = t0 ? T0.slabs : T1.slabs;
+                const uint32_t half = t0 ? half0 : half1, hm = t0 ? hm0 : hm1;
+                const uint32_t rest = t0 ? slab_rest(T0, rlo, rhi) : rest1;
+                const uint4* p = reinterpret_cast<const uint4*>(base + ((size_t)(t0 ? c0 : c1) << 3));
+                uint4 v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = p[c];
+                kmin = scan_piece(v, rest, half, hm, kmin);
+                const uint32_t nx = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
+                if (t0) c0 = nx; else c1 = nx;
+            }
+        }
+        // decision.  Seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1
+        // (NSEG = 3) / within max_mm (NSEG = 2).
+        const uint32_t d = kmin >> 24;
+        const bool inrange = have && d <= max_mm;
+        const bool uniq = lane_unique(kmin, max_mm);
+        // final: a unique best.  (NSEG = 3, d = 2: unseen guides are at distance >= 2, and the flag excludes a tie.)
+        const bool fin = inrange && uniq;
+        const bool slow = inrange && !uniq;
+        const bool t2 = have && !inrange && NSEG == 3;
+        const bool miss = have && !inrange && NSEG != 3;
+        if (fin) q_slot[qi] = pack_result(kmin & SLAB_GIDX_MASK, d, 1u);
+        if (miss) q_slot[qi] = pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+        if (NSEG == 3) {
+            const unsigned long long m = __ballot(t2);
+            if (m) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&t2_n, (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (t2) l_t2[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)qi;
+            }
+        }
+        if (slow) l_slow[atomicAdd(&slow_n, 1u)] = (uint16_t)qi;  // rare
+    }
+
+    // ---- phase 2b: table 2 for the reads with nothing in range yet (compacted: full waves again)
+    if constexpr (NSEG == 3) {
+        __syncthreads();
+        const SlabTable& T2 = sp.t[2];
+        const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u;
+        const uint32_t ppl = 1u << (T2.log2S - 3u);  // 64-byte pieces per slab
+        const uint32_t t2n = t2_n;
+        for (uint32_t tb = 0; tb < t2n; tb += BLOCK) {
+            const uint32_t ti = tb + threadIdx.x;
+            bool live = ti < t2n;
+            uint32_t qi = 0, rest = 0, slab = 0, piece = 0, kmin = 0xFFFFFFFFu;
+            if (live) {
+                qi = l_t2[ti];
+                const uint64_t r = q_slot[qi];
+                const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+                rest = slab_rest(T2, rlo, rhi);
+                slab = seed_value(rlo, rhi, T2.start, T2.slen);
+            }
+            const bool mine = live;
+            while (__ballot(live) != 0ull) {
+                if (live) {
+                    const uint4* p = reinterpret_cast<const uint4*>(T2.slabs + ((size_t)slab << T2.log2S) + piece * 8u);
+                    uint4 v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = p[c];
+                    kmin = scan_piece(v, rest, half2, hm2, kmin);
+                    if (++piece == ppl) {  // the slab's last piece carries the link
+                        slab = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
+                        piece = 0;
+                        live = slab != 0u;
+                    }
+                }
+            }
+            // every guide within max_mm of these reads has segments 0 and 1 dirty, hence a clean segment 2: all seen
+            const uint32_t d = kmin >> 24;
+            const bool inrange = mine && d <= max_mm;
+            const bool uniq = lane_unique(kmin, max_mm);
+            if (inrange && uniq) q_slot[qi] = pack_result(kmin & SLAB_GIDX_MASK, d, 1u);
+            if (mine && !inrange) q_slot[qi] = pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+            if (inrange && !uniq) l_slow[atomicAdd(&slow_n, 1u)] = (uint16_t)qi;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2c: exact evaluation (every table, chains, duplicates removed, per-distance counts) by DPP quads
+    {
+        const uint32_t sn = slow_n;
+        const int sub = threadIdx.x & 3;
+        const int last_lane = (int)(lane | 3u);
+        for (uint32_t si = threadIdx.x >> 2; si < sn; si += BLOCK / 4) {
+            const uint32_t qi = l_slow[si];
+            const uint64_t r = q_slot[qi];
+            uint32_t key, nb;
+            slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), max_mm_, sub, last_lane, key, nb);
+            if (sub == 0) {
+                const bool hit = (key >> 24) <= max_mm;
+                q_slot[qi] = hit ? pack_result(key & SLAB_GIDX_MASK, key >> 24, nb > 255u ? 255u : nb)
+                                 : pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+            }
         }
     }
     __syncthreads();
@@ -1105,7 +1393,7 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     SlabParams& sl = lib->slab[d];
     if (s == 0) { sl.nseg = cs.nseg; lib->slab_ok[d] = true; }
     const int start = cs.start[s], slen = cs.slen[s], half = lib->k - slen;
-    if (2 * half > 31 || lib->G >= (1u << 23) || lib->k > 28) { lib->slab_ok[d] = false; return BC_OK; }  // rest + flag: one dword; index: 23 bits
+    if (2 * half > 31 || lib->G >= (1u << SLAB_GIDX_BITS) || lib->k > 28) { lib->slab_ok[d] = false; return BC_OK; }  // rest: one dword; index: 22 bits + 2 flags
     if (!lib->slab_ok[d]) return BC_OK;
     const uint32_t nb = 1u << (2 * slen);
     // slab size: 64-byte slabs (7 entries + link) while the mean bucket fits, else 128-byte slabs and
@@ -1142,9 +1430,14 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
                 cur = nxt;
                 pos = 0;
             }
-            // bit 31 = this guide is isolated at radius 2*d (see k_nn_dist); every scan masks it out with hmask
-            const uint32_t iso = (!lib->h_nn.empty() && lib->h_nn[gidx[j]] > 2 * d) ? 0x80000000u : 0u;
-            slabs[(cur << log2S) + pos++] = make_uint2(rest_of(keys[j]) | iso, gidx[j]);
+            // isolation flags ride in the index word (see bc_device.h)
+            uint32_t fl = 0;
+            if (!lib->h_nn.empty()) {
+                const int nn = lib->h_nn[gidx[j]];
+                if (nn > 2 * d) fl |= SLAB_F_ISO;
+                if (nn > 2 * (d - 1)) fl |= SLAB_F_ISO1;
+            }
+            slabs[(cur << log2S) + pos++] = make_uint2(rest_of(keys[j]), gidx[j] | fl);
         }
     }
     uint2* d_slabs;
@@ -1412,6 +1705,20 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
     } while (0)
                 // the quad state machine handles 8-entry slabs for tables 0,1 and 8/16-entry slabs for table 2
                 const SlabParams& hp = lib->slab[max_mm];
+                // default: the lane-per-read kernel (no hash table); BC_LANE=0 selects the quad kernels
+                const bool lane_ok = env_int("BC_LANE", 1) && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
+                                     hp.t[1].log2S == 3 && !lib->h_nn.empty();
+                if (lane_ok) {
+                    const int lgrid = (int)((n + LANE_T - 1) / LANE_T);
+                    if (nseg == 2)
+                        hipLaunchKernelGGL((k_match_lane<2>), dim3(lgrid), dim3(BLOCK), 0, st, dp, d_reads, d_flags, n,
+                                           lib->k, lib->kmask, max_mm, o);
+                    else
+                        hipLaunchKernelGGL((k_match_lane<3>), dim3(lgrid), dim3(BLOCK), 0, st, dp, d_reads, d_flags, n,
+                                           lib->k, lib->kmask, max_mm, o);
+                    BC_HIP(hipGetLastError());
+                    return BC_OK;
+                }
                 const bool sm_ok = env_int("BC_PHASE2_SM", 1) && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
                                    hp.t[1].log2S == 3 && (nseg == 2 || hp.t[2].log2S == 3 || hp.t[2].log2S == 4);
                 if (sm_ok && nseg == 2) { if (lib->wide) BC_FUSED_SM(true, 2); else BC_FUSED_SM(false, 2); }
