@@ -65,9 +65,18 @@ struct SlabTable {
     uint32_t log2S;               // entries per slab (incl. the link entry)
     uint32_t dmask[MAX_SEG];      // dmask[t]: seed t's bases in rest coordinates (t < this table)
 };
+// Neighbour lists: for a guide with another guide within NBR_RADIUS substitutions, the (at most NBR_CAP) guides
+// that close, as {key lo, key hi, index, 1}.  Any guide tying with g at distance e <= NBR_RADIUS/2 from a read is
+// within 2e of g, hence in g's list: ties are resolved with one small lookup instead of a full re-evaluation.
+constexpr int NBR_CAP = 8;
+constexpr int NBR_RADIUS = 4;
+constexpr uint32_t NBR_NONE = 0xFFFFFFFFu;  // no guide within NBR_RADIUS
+constexpr uint32_t NBR_OVER = 0xFFFFFFFEu;  // more than NBR_CAP of them: take the exact path
 struct SlabParams {
     int nseg;
     SlabTable t[MAX_SEG];
+    const uint32_t* nbr_slot;  // [G] list number, NBR_NONE or NBR_OVER (NULL = no lists)
+    const uint4* nbr;          // [lists][NBR_CAP]
 };
 
 }  // namespace bc
@@ -79,6 +88,8 @@ struct bc_lib {
     uint64_t kmask = 0;
     std::vector<uint64_t> h_guides;
     std::vector<uint8_t> h_nn;     // distance to the nearest other guide (empty = not computed)
+    uint32_t* d_nbr_slot = nullptr;  // neighbour lists (see SlabParams)
+    uint4* d_nbr = nullptr;
     uint64_t* d_guides = nullptr;  // [G] original order (also the brute-force tile source)
     // exact-match open-addressing table
     int log_slots = 0;
@@ -87,7 +98,7 @@ struct bc_lib {
     uint32_t* d_slots32 = nullptr;
     // seed indices, entry d for max_mismatch = d
     bc::SeedParams seed[bc::MAX_SEG];
-    bc::SlabParams slab[bc::MAX_SEG];
+    bc::SlabParams slab[bc::MAX_SEG] = {};
     bool slab_ok[bc::MAX_SEG] = {false, false, false, false};
     const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
     // miss queue between the exact stage and the seed stage (grown on demand)

@@ -956,6 +956,18 @@ __device__ __forceinline__ uint32_t scan_piece(const uint4 (&v)[4], uint32_t res
     return kmin;
 }
 
+// the four 16-byte quarters of a 64-byte piece (global address space: the table pointer comes out of a descriptor
+// in memory, and a generic pointer would make these flat loads that also wait on the LDS counter)
+typedef const u32x4 __attribute__((address_space(1)))* gpiece_t;
+__device__ __forceinline__ void load_piece(const uint2* p, uint4 (&v)[4]) {
+    gpiece_t g = (gpiece_t)(uintptr_t)p;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const u32x4 t = g[c];
+        v[c] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+}
+
 // is the best candidate provably the only guide at its distance?
 __device__ __forceinline__ bool lane_unique(uint32_t key, uint32_t max_mm) {
     const uint32_t d = key >> 24;
@@ -966,7 +978,9 @@ __device__ __forceinline__ uint64_t pack_result(uint32_t idx, uint32_t dist, uin
     return (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)nb << 40);
 }
 
-template <int NSEG>
+__device__ unsigned long long g_phase_cycles[8];  // BC_PHASE_PROF=1: summed wall-clock cycles per phase (wave 0 of every tile)
+
+template <int NSEG, bool PROF>
 __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restrict__ spp,
                                                       const uint64_t* __restrict__ reads,
                                                       const uint8_t* __restrict__ flags, uint64_t n, int k,
@@ -985,6 +999,14 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
     const uint32_t tn = (uint32_t)min((uint64_t)LANE_T, n - tile0);
     if (threadIdx.x == 0) { q_n = 0; t2_n = 0; slow_n = 0; }
     __syncthreads();
+    unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull;
+    auto phase_mark = [&](int ph) {
+        if (PROF && threadIdx.x == 0) {
+            const unsigned long long t = (unsigned long long)clock64();
+            atomicAdd(&g_phase_cycles[ph], t - t_prev);
+            t_prev = t;
+        }
+    };
     const SlabTable& T0 = sp.t[0];
     const SlabTable& T1 = sp.t[1];
     const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
@@ -1005,23 +1027,29 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
         }
         int32_t idx[4];
         uint32_t key[4], link[4];
-        bool push[4];
+        bool push[4], ok[4];
+        const uint2* pp[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool in = p0 + j < tn;
-            idx[j] = BC_IDX_SKIP; push[j] = false; key[j] = 0xFFFFFFFFu; link[j] = 0u;
-            if (in && !read_skipped(r[j], flags, tile0 + p0 + j, k)) {
-                r[j] &= kmask;
-                const uint32_t rlo = (uint32_t)r[j], rhi = (uint32_t)(r[j] >> 32);
-                const uint4* p = reinterpret_cast<const uint4*>(T0.slabs + ((size_t)seed_value(rlo, rhi, T0.start, T0.slen) << 3));
-                uint4 v[4];
+            ok[j] = p0 + j < tn && !read_skipped(r[j], flags, tile0 + p0 + j, k);
+            r[j] &= kmask;
+            // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
+            pp[j] = T0.slabs + (ok[j] ? ((size_t)seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << 3) : 0);
+        }
+        // one slab in flight per lane: more (a software pipeline over the lane's four reads) measured 9 % slower —
+        // the four quarter loads of a slab only merge into one L2 request while the line's first miss is pending
+        auto finish = [&](int j, const uint4 (&v)[4]) {
+            key[j] = scan_piece(v, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, 0xFFFFFFFFu);
+            link[j] = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
+            const bool exact = (key[j] >> 24) == 0u;  // the guide itself: final
+            idx[j] = !ok[j] ? BC_IDX_SKIP : exact ? (int32_t)(key[j] & SLAB_GIDX_MASK) : BC_IDX_MISS;
+            push[j] = ok[j] && !exact;
+        };
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = p[c];
-                key[j] = scan_piece(v, slab_rest(T0, rlo, rhi), half0, hm0, 0xFFFFFFFFu);
-                link[j] = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
-                if ((key[j] >> 24) == 0u) idx[j] = (int32_t)(key[j] & SLAB_GIDX_MASK);  // the guide itself: final
-                else { idx[j] = BC_IDX_MISS; push[j] = true; }
-            }
+        for (int j = 0; j < 4; ++j) {
+            uint4 v[4];
+            load_piece(pp[j], v);
+            finish(j, v);
         }
         if (full) {
             reinterpret_cast<int4*>(o.best_idx + tile0)[p0 >> 2] = make_int4(idx[0], idx[1], idx[2], idx[3]);
@@ -1072,6 +1100,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
         }
     }
     __syncthreads();
+    phase_mark(0);
     const uint32_t qn = q_n;
 
     // ---- phase 2a: table 1, overflow slabs of tables 0 and 1, decision
@@ -1083,10 +1112,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
             const uint64_t r = q_slot[qi];
             rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
             kmin = q_key[qi]; c0 = q_link[qi];
-            const uint4* p = reinterpret_cast<const uint4*>(T1.slabs + ((size_t)seed_value(rlo, rhi, T1.start, T1.slen) << 3));
             uint4 v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = p[c];
+            load_piece(T1.slabs + ((size_t)seed_value(rlo, rhi, T1.start, T1.slen) << 3), v);
             rest1 = slab_rest(T1, rlo, rhi);
             kmin = scan_piece(v, rest1, half1, hm1, kmin);
             c1 = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
@@ -1097,10 +1124,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
                 const uint2* base = t0 ? T0.slabs : T1.slabs;
                 const uint32_t half = t0 ? half0 : half1, hm = t0 ? hm0 : hm1;
                 const uint32_t rest = t0 ? slab_rest(T0, rlo, rhi) : rest1;
-                const uint4* p = reinterpret_cast<const uint4*>(base + ((size_t)(t0 ? c0 : c1) << 3));
                 uint4 v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = p[c];
+                load_piece(base + ((size_t)(t0 ? c0 : c1) << 3), v);
                 kmin = scan_piece(v, rest, half, hm, kmin);
                 const uint32_t nx = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
                 if (t0) c0 = nx; else c1 = nx;
@@ -1133,6 +1158,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
     // ---- phase 2b: table 2 for the reads with nothing in range yet (compacted: full waves again)
     if constexpr (NSEG == 3) {
         __syncthreads();
+        phase_mark(1);
         const SlabTable& T2 = sp.t[2];
         const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u;
         const uint32_t ppl = 1u << (T2.log2S - 3u);  // 64-byte pieces per slab
@@ -1151,10 +1177,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
             const bool mine = live;
             while (__ballot(live) != 0ull) {
                 if (live) {
-                    const uint4* p = reinterpret_cast<const uint4*>(T2.slabs + ((size_t)slab << T2.log2S) + piece * 8u);
                     uint4 v[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = p[c];
+                    load_piece(T2.slabs + ((size_t)slab << T2.log2S) + piece * 8u, v);
                     kmin = scan_piece(v, rest, half2, hm2, kmin);
                     if (++piece == ppl) {  // the slab's last piece carries the link
                         slab = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
@@ -1173,6 +1197,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
         }
     }
     __syncthreads();
+    phase_mark(2);
 
     // ---- phase 2c: exact evaluation (every table, chains, duplicates removed, per-distance counts) by DPP quads
     {
@@ -1192,6 +1217,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
         }
     }
     __syncthreads();
+    phase_mark(3);
 
     // ---- phase 3: queued reads' results over the placeholders phase 1 left (same lines, still in L2)
     for (uint32_t qi = threadIdx.x; qi < qn; qi += BLOCK) {
@@ -1204,6 +1230,338 @@ __global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restri
         if (o.n_best) o.n_best[i] = (uint8_t)(e >> 40);
         tally(o, i, idx);
     }
+    phase_mark(5);
+    if (PROF && threadIdx.x == 0) atomicAdd(&g_phase_cycles[7], 1ull);
+}
+
+// ---------------------------------------------------------------------------
+// K2+K3 wave form: the lane kernel's work split, but
+//   * a wave owns its tile of 256 reads outright (64-thread workgroups): no
+//     workgroup barrier ever waits for another wave's long chain;
+//   * slabs are fetched QUAD-COOPERATIVELY: for the four reads owned by the four
+//     lanes of a quad, load j brings read j's slab with lane s taking quarter s
+//     (one vector-L1 access per slab instead of four, and nothing depends on the
+//     L1 merging four quarter loads into one request); lane s scans its quarter
+//     of all four reads (rest of read j by DPP broadcast) and a transposed DPP
+//     min-reduction hands every owner its read's minimum;
+//   * ties / close neighbours are settled from the best guide's neighbour list
+//     (SlabParams::nbr) by the owning lane; the quad exact path (slab_slow) is
+//     left for guides with more than NBR_CAP close neighbours.
+// ---------------------------------------------------------------------------
+constexpr int WAVE_T = 256;  // reads per wave (4 per lane)
+constexpr uint32_t NOSLAB = 0xFFFFFFFFu;
+
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return quad_perm<J * 0x55>(v); }
+
+// lane s of every quad returns min over the quad's lanes of their a[s]
+__device__ __forceinline__ uint32_t quad_tmin(const uint32_t (&a)[4], int s) {
+    const bool odd = (s & 1) != 0, hi = (s & 2) != 0;
+    const uint32_t b0 = min(odd ? a[1] : a[0], quad_perm<0xB1>(odd ? a[0] : a[1]));
+    const uint32_t b1 = min(odd ? a[3] : a[2], quad_perm<0xB1>(odd ? a[2] : a[3]));
+    return min(hi ? b1 : b0, quad_perm<0x4E>(hi ? b0 : b1));
+}
+
+__device__ __forceinline__ uint4 load16(const uint2* p) {
+    const u32x4 t = *(gpiece_t)(uintptr_t)p;
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+// request the slabs of the quad's four reads: NQ quarters per lane and read (1: 64-byte slabs, 2: 128-byte, 4: 256)
+template <int NQ, bool COND>
+__device__ __forceinline__ void visit_issue(const uint2* base, uint32_t log2S, uint32_t slab, int s, uint4 (&w)[4][NQ]) {
+    auto one = [&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        const uint32_t sj = quad_bcast<j>(slab);
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            if (!COND || sj != NOSLAB) w[j][h] = load16(base + ((size_t)sj << log2S) + (uint32_t)(s + 4 * h) * 2u);
+            else w[j][h] = make_uint4(0u, SLAB_EMPTY, 0u, SLAB_EMPTY);
+        }
+    };
+    one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+    one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+}
+
+// scan them: kmin = min(kmin, this read's best key); link = this read's overflow slab (0 = none)
+template <int NQ>
+__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], uint32_t rest, uint32_t half, uint32_t hmask, int s,
+                                           uint32_t& kmin, uint32_t& link) {
+    uint32_t a[4], l[4];
+    auto one = [&](auto jt) {
+        constexpr int j = decltype(jt)::value;
+        const uint32_t rj = quad_bcast<j>(rest);
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            const uint32_t x0 = rj ^ w[j][h].x, x1 = rj ^ w[j][h].z;
+            const uint32_t d0 = __popc((x0 & hmask) | (x0 >> half));
+            const uint32_t d1 = __popc((x1 & hmask) | (x1 >> half));
+            m = min(m, min((d0 << 24) | w[j][h].y, (d1 << 24) | w[j][h].w));
+        }
+        a[j] = m;
+        l[j] = (w[j][NQ - 1].w == SLAB_LINK) ? w[j][NQ - 1].z : 0u;  // the slab's last entry: lane 3's last quarter
+    };
+    one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+    one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+    kmin = min(kmin, quad_tmin(a, s));
+    const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
+    link = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;
+}
+
+// the best guide g (at distance d1) may tie with close neighbours: count them from g's neighbour list.
+// false: the list is not available (more than NBR_CAP neighbours) -> exact path.
+__device__ __forceinline__ bool resolve_ties(const SlabParams& sp, uint32_t rlo, uint32_t rhi, uint32_t d1,
+                                             uint32_t& idx, uint32_t& nb) {
+    const uint32_t slot = sp.nbr_slot[idx];
+    nb = 1u;
+    if (slot == NBR_NONE) return true;
+    if (slot == NBR_OVER) return false;
+    bool ok = true;
+    uint32_t best = idx;
+    for (int i = 0; i < NBR_CAP; ++i) {
+        const uint4 e = sp.nbr[(size_t)slot * NBR_CAP + i];
+        if (e.w == 0u) break;
+        const uint32_t d = __popc((rlo ^ e.x) | (rhi ^ e.y));
+        if (d == d1) { ++nb; best = min(best, e.z); }
+        if (d < d1) ok = false;  // cannot happen (every closer guide has been seen); never trust it silently
+    }
+    idx = best;
+    return ok;
+}
+
+template <int NSEG, int NQ2, bool PROF>
+__global__ __launch_bounds__(64) void k_match_wave(const SlabParams* __restrict__ spp,
+                                                   const uint64_t* __restrict__ reads,
+                                                   const uint8_t* __restrict__ flags, uint64_t n, int k,
+                                                   uint64_t kmask, int max_mm_, MatchOut o) {
+    static_assert(NSEG == 2 || NSEG == 3, "wave kernel: d = 1 or 2");
+    __shared__ uint64_t q_slot[WAVE_T];   // queued read; later its result
+    __shared__ uint32_t q_key[WAVE_T];    // best key so far (table 0's primary slab)
+    __shared__ uint32_t q_link[WAVE_T];   // overflow slab of table 0 (0 = none)
+    __shared__ uint16_t q_pos[WAVE_T];    // position in the tile
+    __shared__ uint16_t l_t2[WAVE_T];     // queue entries that need table 2
+    __shared__ uint16_t l_slow[WAVE_T];   // queue entries that need the exact path
+    const SlabParams& sp = *spp;
+    const uint32_t max_mm = (uint32_t)max_mm_;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * WAVE_T;
+    const uint32_t tn = (uint32_t)min((uint64_t)WAVE_T, n - tile0);
+    const SlabTable& T0 = sp.t[0];
+    const SlabTable& T1 = sp.t[1];
+    const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
+    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
+    const uint32_t lane = threadIdx.x;
+    const int s = (int)(lane & 3u);
+    unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull;
+    auto phase_mark = [&](int ph) {
+        if (PROF && threadIdx.x == 0) {
+            const unsigned long long t = (unsigned long long)clock64();
+            atomicAdd(&g_phase_cycles[ph], t - t_prev);
+            t_prev = t;
+        }
+    };
+    uint32_t qn = 0, t2n = 0, sn = 0;  // wave-uniform list lengths
+
+    // ---- phase 1: table 0, primary slab, every read (exact hits are final)
+    {
+        const uint32_t p0 = lane * 4u;
+        uint64_t r[4] = {0, 0, 0, 0};
+        const bool full = p0 + 3 < tn;
+        if (full) {
+            load_reads4(reads + tile0 + p0, r);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) r[j] = reads[tile0 + p0 + j];
+        }
+        int32_t idx[4];
+        uint32_t key[4], link[4];
+        bool push[4], ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ok[j] = p0 + j < tn && !read_skipped(r[j], flags, tile0 + p0 + j, k);
+            r[j] &= kmask;
+        }
+        // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
+        auto slab0 = [&](int j) { return ok[j] ? seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) : 0u; };
+        auto finish = [&](int j, const uint4 (&w)[4][1]) {
+            key[j] = 0xFFFFFFFFu;
+            visit_scan<1>(w, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key[j], link[j]);
+            const bool exact = (key[j] >> 24) == 0u;  // the guide itself
+            idx[j] = !ok[j] ? BC_IDX_SKIP : exact ? (int32_t)(key[j] & SLAB_GIDX_MASK) : BC_IDX_MISS;
+            push[j] = ok[j] && !exact;
+        };
+        uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
+        visit_issue<1, false>(T0.slabs, 3u, slab0(0), s, wa);
+        visit_issue<1, false>(T0.slabs, 3u, slab0(1), s, wb);
+        finish(0, wa);
+        visit_issue<1, false>(T0.slabs, 3u, slab0(2), s, wa);
+        finish(1, wb);
+        visit_issue<1, false>(T0.slabs, 3u, slab0(3), s, wb);
+        finish(2, wa);
+        finish(3, wb);
+        if (full) {
+            reinterpret_cast<int4*>(o.best_idx + tile0)[p0 >> 2] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            if (o.best_dist) {
+                uchar4 d;
+                d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
+                d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
+                reinterpret_cast<uchar4*>(o.best_dist + tile0)[p0 >> 2] = d;
+            }
+            if (o.n_best) {
+                uchar4 c;
+                c.x = idx[0] >= 0; c.y = idx[1] >= 0; c.z = idx[2] >= 0; c.w = idx[3] >= 0;
+                reinterpret_cast<uchar4*>(o.n_best + tile0)[p0 >> 2] = c;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) {
+                    o.best_idx[tile0 + p0 + j] = idx[j];
+                    if (o.best_dist) o.best_dist[tile0 + p0 + j] = idx[j] >= 0 ? 0 : BC_DIST_NONE;
+                    if (o.n_best) o.n_best[tile0 + p0 + j] = idx[j] >= 0;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
+        // append the rest to the wave's LDS queue
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long m = __ballot(push[j]);
+            if (push[j]) {
+                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                q_slot[at] = r[j];
+                q_key[at] = key[j];
+                q_link[at] = link[j];
+                q_pos[at] = (uint16_t)(p0 + j);
+            }
+            qn += (uint32_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+    phase_mark(0);
+
+    // ---- phase 2a: table 1, overflow slabs of tables 0 and 1, decision
+    for (uint32_t qb = 0; qb < qn; qb += 64) {
+        const uint32_t qi = qb + lane;
+        const bool have = qi < qn;
+        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, c0 = 0, c1 = 0, rest0 = 0, rest1 = 0;
+        uint4 wa[4][1], wb[4][1];
+        if (have) {
+            const uint64_t r = q_slot[qi];
+            rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
+            kmin = q_key[qi]; c0 = q_link[qi];
+            rest0 = slab_rest(T0, rlo, rhi);
+            rest1 = slab_rest(T1, rlo, rhi);
+        }
+        visit_issue<1, true>(T1.slabs, 3u, have ? seed_value(rlo, rhi, T1.start, T1.slen) : NOSLAB, s, wa);
+        bool any0 = __ballot(c0 != 0u) != 0ull;
+        if (any0) visit_issue<1, true>(T0.slabs, 3u, c0 ? c0 : NOSLAB, s, wb);
+        visit_scan<1>(wa, rest1, half1, hm1, s, kmin, c1);
+        if (any0) visit_scan<1>(wb, rest0, half0, hm0, s, kmin, c0);
+        for (;;) {  // further overflow slabs
+            any0 = __ballot(c0 != 0u) != 0ull;
+            const bool any1 = __ballot(c1 != 0u) != 0ull;
+            if (!any0 && !any1) break;
+            if (any0) visit_issue<1, true>(T0.slabs, 3u, c0 ? c0 : NOSLAB, s, wb);
+            if (any1) visit_issue<1, true>(T1.slabs, 3u, c1 ? c1 : NOSLAB, s, wa);
+            if (any0) visit_scan<1>(wb, rest0, half0, hm0, s, kmin, c0);
+            if (any1) visit_scan<1>(wa, rest1, half1, hm1, s, kmin, c1);
+        }
+        // decision.  Seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1
+        // (NSEG = 3) / within max_mm (NSEG = 2); unseen guides are at distance >= 2.
+        const uint32_t d = kmin >> 24;
+        const bool inrange = have && d <= max_mm;
+        uint32_t ridx = kmin & SLAB_GIDX_MASK, rnb = 1u;
+        bool slow = false;
+        if (inrange && !lane_unique(kmin, max_mm)) slow = !sp.nbr_slot || !resolve_ties(sp, rlo, rhi, d, ridx, rnb);
+        if (inrange && !slow) q_slot[qi] = pack_result(ridx, d, rnb > 255u ? 255u : rnb);
+        if (have && !inrange && NSEG != 3) q_slot[qi] = pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+        if (NSEG == 3) {
+            const bool t2 = have && !inrange;
+            const unsigned long long m = __ballot(t2);
+            if (t2) l_t2[t2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)qi;
+            t2n += (uint32_t)__popcll(m);
+        }
+        {
+            const unsigned long long m = __ballot(slow);
+            if (slow) l_slow[sn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)qi;
+            sn += (uint32_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+    phase_mark(1);
+
+    // ---- phase 2b: table 2 for the reads with nothing in range yet (compacted: full waves again)
+    if constexpr (NSEG == 3) {
+        const SlabTable& T2 = sp.t[2];
+        const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u;
+        for (uint32_t tb = 0; tb < t2n; tb += 64) {
+            const uint32_t ti = tb + lane;
+            const bool mine = ti < t2n;
+            uint32_t qi = 0, rlo = 0, rhi = 0, rest = 0, slab = NOSLAB, kmin = 0xFFFFFFFFu;
+            if (mine) {
+                qi = l_t2[ti];
+                const uint64_t r = q_slot[qi];
+                rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
+                rest = slab_rest(T2, rlo, rhi);
+                slab = seed_value(rlo, rhi, T2.start, T2.slen);
+            }
+            while (__ballot(slab != NOSLAB) != 0ull) {
+                uint4 w[4][NQ2];
+                visit_issue<NQ2, true>(T2.slabs, T2.log2S, slab, s, w);
+                uint32_t nx;
+                visit_scan<NQ2>(w, rest, half2, hm2, s, kmin, nx);
+                slab = (slab != NOSLAB && nx != 0u) ? nx : NOSLAB;
+            }
+            // every guide within max_mm of these reads has segments 0 and 1 dirty, hence a clean segment 2: all seen
+            const uint32_t d = kmin >> 24;
+            const bool inrange = mine && d <= max_mm;
+            uint32_t ridx = kmin & SLAB_GIDX_MASK, rnb = 1u;
+            bool slow = false;
+            if (inrange && !lane_unique(kmin, max_mm)) slow = !sp.nbr_slot || !resolve_ties(sp, rlo, rhi, d, ridx, rnb);
+            if (inrange && !slow) q_slot[qi] = pack_result(ridx, d, rnb > 255u ? 255u : rnb);
+            if (mine && !inrange) q_slot[qi] = pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+            const unsigned long long m = __ballot(slow);
+            if (slow) l_slow[sn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)qi;
+            sn += (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+    }
+    phase_mark(2);
+
+    // ---- phase 2c: exact evaluation by DPP quads (guides with more than NBR_CAP close neighbours only)
+    if (sn) {
+        const int last_lane = (int)(lane | 3u);
+        for (uint32_t si = lane >> 2; si < sn; si += 16) {
+            const uint32_t qi = l_slow[si];
+            const uint64_t r = q_slot[qi];
+            uint32_t key, nb;
+            slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), max_mm_, s, last_lane, key, nb);
+            if (s == 0) {
+                const bool hit = (key >> 24) <= max_mm;
+                q_slot[qi] = hit ? pack_result(key & SLAB_GIDX_MASK, key >> 24, nb > 255u ? 255u : nb)
+                                 : pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+            }
+        }
+        __syncthreads();
+    }
+    phase_mark(3);
+
+    // ---- phase 3: queued reads' results over the placeholders phase 1 left (same lines, still in L2)
+    for (uint32_t qi = lane; qi < qn; qi += 64) {
+        const uint64_t e = q_slot[qi];
+        const int32_t idx = (int32_t)(uint32_t)e;
+        if (idx == BC_IDX_MISS) continue;  // the placeholder already says so
+        const uint64_t i = tile0 + q_pos[qi];
+        o.best_idx[i] = idx;
+        if (o.best_dist) o.best_dist[i] = (uint8_t)(e >> 32);
+        if (o.n_best) o.n_best[i] = (uint8_t)(e >> 40);
+        tally(o, i, idx);
+    }
+    phase_mark(5);
+    if (PROF && threadIdx.x == 0) atomicAdd(&g_phase_cycles[7], 1ull);
 }
 
 // ---------------------------------------------------------------------------
@@ -1343,6 +1701,28 @@ __global__ __launch_bounds__(BLOCK) void k_nn_dist(const uint64_t* __restrict__ 
     if (i < G) out[i] = (uint8_t)best;
 }
 
+// neighbour lists of the guides listed in cand[] (those with another guide within NBR_RADIUS): one thread per
+// candidate walks the whole library (the same address in every lane: broadcast loads)
+__global__ __launch_bounds__(64) void k_nn_list(const uint64_t* __restrict__ guides, uint32_t G, uint64_t kmask,
+                                                const uint32_t* __restrict__ cand, uint32_t ncand,
+                                                uint4* __restrict__ nbr, uint32_t* __restrict__ count) {
+    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= ncand) return;
+    const uint32_t i = cand[c];
+    const uint64_t me = guides[i] & kmask;
+    const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
+    uint32_t cnt = 0;
+    for (uint32_t j = 0; j < G; ++j) {
+        const uint64_t g = guides[j] & kmask;
+        const uint32_t d = __popc((lo ^ (uint32_t)g) | (hi ^ (uint32_t)(g >> 32)));
+        if (d <= (uint32_t)NBR_RADIUS && j != i) {
+            if (cnt < (uint32_t)NBR_CAP) nbr[(size_t)c * NBR_CAP + cnt] = make_uint4((uint32_t)g, (uint32_t)(g >> 32), j, 1u);
+            ++cnt;
+        }
+    }
+    count[c] = cnt;
+}
+
 // ---------------------------------------------------------------------------
 // synthetic reads (bench / tests)
 // ---------------------------------------------------------------------------
@@ -1449,6 +1829,8 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
         T.dmask[t] = (t < s) ? (((1u << cs.slen[t]) - 1u) << cs.start[t]) : 0u;
     if (s == cs.nseg - 1) {  // descriptor block for the kernel (read through scalar loads)
+        sl.nbr_slot = lib->h_nn.empty() ? nullptr : lib->d_nbr_slot;
+        sl.nbr = lib->h_nn.empty() ? nullptr : lib->d_nbr;
         std::vector<SlabParams> one(1, sl);
         SlabParams* d_sp;
         if ((rc = dev_upload(lib, one, &d_sp)) != BC_OK) return rc;
@@ -1511,7 +1893,35 @@ int compute_nn(bc_lib* lib) {
     hipError_t e = hipMemcpy(lib->h_nn.data(), d_nn, lib->G, hipMemcpyDeviceToHost);
     (void)hipFree(d_nn);
     if (e != hipSuccess) { lib->h_nn.clear(); set_error("k_nn_dist: %s", hipGetErrorString(e)); return BC_EHIP; }
-    return BC_OK;
+    // neighbour lists for the guides that are not isolated at NBR_RADIUS
+    std::vector<uint32_t> cand;
+    for (uint32_t i = 0; i < lib->G; ++i)
+        if (lib->h_nn[i] <= NBR_RADIUS) cand.push_back(i);
+    std::vector<uint32_t> slot(lib->G, NBR_NONE);
+    std::vector<uint4> lists(cand.size() * (size_t)NBR_CAP, make_uint4(0u, 0u, 0u, 0u));
+    if (!cand.empty()) {
+        uint32_t* d_cand = nullptr; uint32_t* d_cnt = nullptr; uint4* d_l = nullptr;
+        const uint32_t nc = (uint32_t)cand.size();
+        hipError_t e2 = hipMalloc((void**)&d_cand, nc * sizeof(uint32_t));
+        if (e2 == hipSuccess) e2 = hipMalloc((void**)&d_cnt, nc * sizeof(uint32_t));
+        if (e2 == hipSuccess) e2 = hipMalloc((void**)&d_l, lists.size() * sizeof(uint4));
+        if (e2 == hipSuccess) e2 = hipMemcpy(d_cand, cand.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e2 == hipSuccess) e2 = hipMemset(d_l, 0, lists.size() * sizeof(uint4));
+        std::vector<uint32_t> cnt(nc, 0);
+        if (e2 == hipSuccess) {
+            hipLaunchKernelGGL(k_nn_list, dim3((nc + 63) / 64), dim3(64), 0, 0, lib->d_guides, lib->G, lib->kmask, d_cand, nc, d_l, d_cnt);
+            e2 = hipMemcpy(cnt.data(), d_cnt, nc * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        }
+        if (e2 == hipSuccess) e2 = hipMemcpy(lists.data(), d_l, lists.size() * sizeof(uint4), hipMemcpyDeviceToHost);
+        if (d_cand) (void)hipFree(d_cand);
+        if (d_cnt) (void)hipFree(d_cnt);
+        if (d_l) (void)hipFree(d_l);
+        if (e2 != hipSuccess) { lib->h_nn.clear(); set_error("k_nn_list: %s", hipGetErrorString(e2)); return BC_EHIP; }
+        for (uint32_t c = 0; c < nc; ++c) slot[cand[c]] = (cnt[c] > (uint32_t)NBR_CAP) ? NBR_OVER : c;
+    }
+    int rc = dev_upload(lib, slot, &lib->d_nbr_slot);
+    if (rc == BC_OK) rc = dev_upload(lib, lists, &lib->d_nbr);
+    return rc;
 }
 
 int build_seed_index(bc_lib* lib, int d);
@@ -1705,18 +2115,46 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
     } while (0)
                 // the quad state machine handles 8-entry slabs for tables 0,1 and 8/16-entry slabs for table 2
                 const SlabParams& hp = lib->slab[max_mm];
-                // default: the lane-per-read kernel (no hash table); BC_LANE=0 selects the quad kernels
-                const bool lane_ok = env_int("BC_LANE", 1) && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
+                // default: the wave kernel (lane-owned reads, quad-cooperative loads, no hash table);
+                // BC_LANE=1 the workgroup-tiled lane kernel, BC_LANE=0 the quad kernels
+                const int lane_mode = env_int("BC_LANE", 2);
+                const bool lane_ok = lane_mode && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
                                      hp.t[1].log2S == 3 && !lib->h_nn.empty();
                 if (lane_ok) {
-                    const int lgrid = (int)((n + LANE_T - 1) / LANE_T);
-                    if (nseg == 2)
-                        hipLaunchKernelGGL((k_match_lane<2>), dim3(lgrid), dim3(BLOCK), 0, st, dp, d_reads, d_flags, n,
-                                           lib->k, lib->kmask, max_mm, o);
-                    else
-                        hipLaunchKernelGGL((k_match_lane<3>), dim3(lgrid), dim3(BLOCK), 0, st, dp, d_reads, d_flags, n,
-                                           lib->k, lib->kmask, max_mm, o);
+                    const bool prof = env_int("BC_PHASE_PROF", 0) != 0;  // tuning aid: per-phase cycle sums on stderr
+                    const bool wave = lane_mode == 2;
+                    const int nq2 = nseg == 3 ? (1 << (hp.t[2].log2S - 3)) : 1;
+                    if (wave) {
+                        const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
+#define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_)                                                                         \
+    hipLaunchKernelGGL((k_match_wave<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n,   \
+                       lib->k, lib->kmask, max_mm, o)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false); } while (0)
+                        if (nseg == 2) BC_WAVE_P(2, 1);
+                        else if (nq2 == 1) BC_WAVE_P(3, 1);
+                        else if (nq2 == 2) BC_WAVE_P(3, 2);
+                        else BC_WAVE_P(3, 4);
+#undef BC_WAVE_P
+#undef BC_WAVE_LAUNCH
+                    } else {
+                        const int lgrid = (int)((n + LANE_T - 1) / LANE_T);
+#define BC_LANE_LAUNCH(NSEG_, PROF_)                                                                              \
+    hipLaunchKernelGGL((k_match_lane<NSEG_, PROF_>), dim3(lgrid), dim3(BLOCK), 0, st, dp, d_reads, d_flags, n,    \
+                       lib->k, lib->kmask, max_mm, o)
+                        if (nseg == 2) { if (prof) BC_LANE_LAUNCH(2, true); else BC_LANE_LAUNCH(2, false); }
+                        else { if (prof) BC_LANE_LAUNCH(3, true); else BC_LANE_LAUNCH(3, false); }
+#undef BC_LANE_LAUNCH
+                    }
                     BC_HIP(hipGetLastError());
+                    if (prof) {
+                        unsigned long long c[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        BC_HIP(hipStreamSynchronize(st));
+                        BC_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof(c)));
+                        BC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
+                        fprintf(stderr, "match phases (cycles/tile): p1 %.0f  2a %.0f  2b %.0f  2c %.0f  p3 %.0f  tiles %llu\n",
+                                (double)c[0] / c[7], (double)c[1] / c[7], (double)c[2] / c[7], (double)c[3] / c[7],
+                                (double)c[5] / c[7], c[7]);
+                    }
                     return BC_OK;
                 }
                 const bool sm_ok = env_int("BC_PHASE2_SM", 1) && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
