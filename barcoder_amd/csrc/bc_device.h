@@ -63,6 +63,7 @@ struct SlabTable {
     const uint2* slabs;
     uint32_t start, slen, half;   // seed position / length; half = k - slen
     uint32_t log2S;               // entries per slab (incl. the link entry)
+    uint32_t empty;               // index of an all-empty slab appended after the overflow slabs
     uint32_t dmask[MAX_SEG];      // dmask[t]: seed t's bases in rest coordinates (t < this table)
 };
 // Neighbour lists: for a guide with another guide within NBR_RADIUS substitutions, the (at most NBR_CAP) guides

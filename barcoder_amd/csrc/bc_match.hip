@@ -920,336 +920,46 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
 }
 
 // ---------------------------------------------------------------------------
-// K2+K3 lane form (default for d = 1, 2): ONE LANE PER READ, no hash table.
-// The quad kernel above spends 88 % of the VALU issue slots (SQ_INSTS_VALU,
-// profiles/prof_insts.sh) — 11.6 wave-instructions per read, most of them state
-// handling shared by only 16 reads per wave — and its 7.4 MB of tables overflow
-// the 4 MB L2 (41 % misses -> Infinity-Fabric bound at the same time).  Here:
-//   * table 0 doubles as the exact-match table (a guide equal to the read sits in
-//     the read's seed-0 bucket), so the 4 MB hash table is gone: 3.7 MB of slabs;
-//   * a lane fetches a whole 64-byte piece (4 x 16 B, one line) and scans its 8
-//     entries itself: xor, shift, and-or, popcount, shift-or, min — 5.5 VALU
-//     per entry, nothing cross-lane, 64 reads per wave-instruction;
-//   * n_best = 1 is proven by the isolation flags of the best guide instead of a
-//     second (max) reduction; only a best guide with a close neighbour takes the
-//     exact quad path (slab_slow), through its own compacted list.
-// Per 1024-read tile: phase 1 scans every read's primary slab of table 0 (exact
-// hits final, coalesced stores); the others are queued in LDS with the partial
-// minimum and the overflow link.  Phase 2a: table 1 + overflow slabs of tables
-// 0/1, then the decision (after tables 0..j every guide within distance j has
-// been seen).  Phase 2b: the reads that still need table 2, compacted so that
-// the wave is full again.  Phase 2c: exact path for ambiguous reads.  Phase 3:
-// queued reads' results over the placeholders.
+// K2+K3 wave form (default for d = 1, 2).  History of the bound, measured with
+// profiles/prof_insts.sh, profiles/prof_valu.sh and profiles/gather_bench.hip:
+//   quad state machine (k_match_fused): 11.6 VALU wave-instructions per read =
+//     88 % of the issue slots, and 7.4 MB of tables against a 4 MB L2 (41 % L2
+//     misses, Infinity-Fabric bound at the same time): 2.33 ms per 1e8 reads;
+//   one lane per read, slabs fetched as 4 x 16 B by the lane: VALU 47 %, but
+//     four vector-L1 accesses per slab and ~25 dependent memory round trips per
+//     workgroup tile held together by barriers: 1.95 ms.
+// This kernel (1.45 ms; 2.3 L2 requests per read at 160 G requests/s, which is what
+// the stream + gather microbenchmark reaches with a 4 MB table; VALU 86 %):
+//   * no hash table: a guide equal to the read sits in the read's seed-0 bucket, so
+//     table 0 doubles as the exact-match table; 3.7 MB of slabs, 93 % L2 hits;
+//   * a wave works alone (64-thread workgroups) on 256 consecutive reads and keeps
+//     its own LDS lists; nothing ever waits on a workgroup barrier;
+//   * reads are owned by lanes, slabs are fetched QUAD-COOPERATIVELY: for the four
+//     reads owned by the lanes of a quad, load j brings read j's slab with lane s
+//     taking quarter s — one L1 access per slab; lane s scans its quarter for all
+//     four reads (rest of read j by DPP broadcast; xor, shift, and-or, popcount,
+//     shift-or, min per entry) and a transposed DPP min-reduction hands every
+//     owner its minimum; overflow links are followed straight from lane 3, and
+//     only the quads that have one issue the load (every L1 access counts);
+//   * stages run on compacted lists: reads without an exact hit (table 1 + overflow
+//     slabs, then the decision), then the ones that still need table 2;
+//   * n_best = 1 is proven by the best guide's isolation flags; otherwise the
+//     owning lane counts ties from the guide's neighbour list; the quad exact
+//     path (slab_slow) is left for guides with more than NBR_CAP close neighbours;
+//   * results are staged in the list entries and leave as full-width coalesced
+//     stores by the lane that owns the read: nothing is patched afterwards.
+// Tried and dropped (slower): persistent waves draining the lists
+// across tiles (fewer VALU, worse memory behaviour), unconditional loads from an
+// all-empty slab (fewer VALU, 60 % more L1 accesses), direct scattered result
+// stores over placeholders (0.5 ms of partial-line writes).
 // ---------------------------------------------------------------------------
-constexpr int LANE_T = 1024;  // reads per workgroup (4 per lane)
-
-// minimum of key = dist << 24 | flags | guide over the 8 entries of one 64-byte piece
-__device__ __forceinline__ uint32_t scan_piece(const uint4 (&v)[4], uint32_t rest, uint32_t half, uint32_t hmask,
-                                               uint32_t kmin) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t x0 = rest ^ v[e].x, x1 = rest ^ v[e].z;
-        const uint32_t d0 = __popc((x0 & hmask) | (x0 >> half));
-        const uint32_t d1 = __popc((x1 & hmask) | (x1 >> half));
-        kmin = min(kmin, min((d0 << 24) | v[e].y, (d1 << 24) | v[e].w));
-    }
-    return kmin;
-}
-
-// the four 16-byte quarters of a 64-byte piece (global address space: the table pointer comes out of a descriptor
-// in memory, and a generic pointer would make these flat loads that also wait on the LDS counter)
-typedef const u32x4 __attribute__((address_space(1)))* gpiece_t;
-__device__ __forceinline__ void load_piece(const uint2* p, uint4 (&v)[4]) {
-    gpiece_t g = (gpiece_t)(uintptr_t)p;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const u32x4 t = g[c];
-        v[c] = make_uint4(t.x, t.y, t.z, t.w);
-    }
-}
+constexpr int WAVE_T = 256;  // reads per wave (4 per lane)
 
 // is the best candidate provably the only guide at its distance?
-__device__ __forceinline__ bool lane_unique(uint32_t key, uint32_t max_mm) {
+__device__ __forceinline__ bool key_unique(uint32_t key, uint32_t max_mm) {
     const uint32_t d = key >> 24;
     return d == 0u || (key & (d == max_mm ? SLAB_F_ISO : SLAB_F_ISO1)) != 0u;
 }
-
-__device__ __forceinline__ uint64_t pack_result(uint32_t idx, uint32_t dist, uint32_t nb) {
-    return (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)nb << 40);
-}
-
-__device__ unsigned long long g_phase_cycles[8];  // BC_PHASE_PROF=1: summed wall-clock cycles per phase (wave 0 of every tile)
-
-template <int NSEG, bool PROF>
-__global__ __launch_bounds__(BLOCK) void k_match_lane(const SlabParams* __restrict__ spp,
-                                                      const uint64_t* __restrict__ reads,
-                                                      const uint8_t* __restrict__ flags, uint64_t n, int k,
-                                                      uint64_t kmask, int max_mm_, MatchOut o) {
-    static_assert(NSEG == 2 || NSEG == 3, "lane kernel: d = 1 or 2");
-    __shared__ uint64_t q_slot[LANE_T];   // queued read; later its result
-    __shared__ uint32_t q_key[LANE_T];    // best key so far (table 0's primary slab)
-    __shared__ uint32_t q_link[LANE_T];   // overflow slab of table 0 (0 = none)
-    __shared__ uint16_t q_pos[LANE_T];    // position in the tile
-    __shared__ uint16_t l_t2[LANE_T];     // queue entries that need table 2
-    __shared__ uint16_t l_slow[LANE_T];   // queue entries that need the exact path
-    __shared__ uint32_t q_n, t2_n, slow_n;
-    const SlabParams& sp = *spp;
-    const uint32_t max_mm = (uint32_t)max_mm_;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * LANE_T;
-    const uint32_t tn = (uint32_t)min((uint64_t)LANE_T, n - tile0);
-    if (threadIdx.x == 0) { q_n = 0; t2_n = 0; slow_n = 0; }
-    __syncthreads();
-    unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull;
-    auto phase_mark = [&](int ph) {
-        if (PROF && threadIdx.x == 0) {
-            const unsigned long long t = (unsigned long long)clock64();
-            atomicAdd(&g_phase_cycles[ph], t - t_prev);
-            t_prev = t;
-        }
-    };
-    const SlabTable& T0 = sp.t[0];
-    const SlabTable& T1 = sp.t[1];
-    const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
-    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
-    const uint32_t lane = threadIdx.x & 63;
-
-    // ---- phase 1: table 0, primary slab, every read
-    {
-        const uint32_t p0 = threadIdx.x * 4u;
-        uint64_t r[4] = {0, 0, 0, 0};
-        const bool full = p0 + 3 < tn;
-        if (full) {
-            load_reads4(reads + tile0 + p0, r);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (p0 + j < tn) r[j] = reads[tile0 + p0 + j];
-        }
-        int32_t idx[4];
-        uint32_t key[4], link[4];
-        bool push[4], ok[4];
-        const uint2* pp[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ok[j] = p0 + j < tn && !read_skipped(r[j], flags, tile0 + p0 + j, k);
-            r[j] &= kmask;
-            // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
-            pp[j] = T0.slabs + (ok[j] ? ((size_t)seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << 3) : 0);
-        }
-        // one slab in flight per lane: more (a software pipeline over the lane's four reads) measured 9 % slower —
-        // the four quarter loads of a slab only merge into one L2 request while the line's first miss is pending
-        auto finish = [&](int j, const uint4 (&v)[4]) {
-            key[j] = scan_piece(v, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, 0xFFFFFFFFu);
-            link[j] = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
-            const bool exact = (key[j] >> 24) == 0u;  // the guide itself: final
-            idx[j] = !ok[j] ? BC_IDX_SKIP : exact ? (int32_t)(key[j] & SLAB_GIDX_MASK) : BC_IDX_MISS;
-            push[j] = ok[j] && !exact;
-        };
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint4 v[4];
-            load_piece(pp[j], v);
-            finish(j, v);
-        }
-        if (full) {
-            reinterpret_cast<int4*>(o.best_idx + tile0)[p0 >> 2] = make_int4(idx[0], idx[1], idx[2], idx[3]);
-            if (o.best_dist) {
-                uchar4 d;
-                d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
-                d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
-                reinterpret_cast<uchar4*>(o.best_dist + tile0)[p0 >> 2] = d;
-            }
-            if (o.n_best) {
-                uchar4 c;
-                c.x = idx[0] >= 0; c.y = idx[1] >= 0; c.z = idx[2] >= 0; c.w = idx[3] >= 0;
-                reinterpret_cast<uchar4*>(o.n_best + tile0)[p0 >> 2] = c;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (p0 + j < tn) {
-                    o.best_idx[tile0 + p0 + j] = idx[j];
-                    if (o.best_dist) o.best_dist[tile0 + p0 + j] = idx[j] >= 0 ? 0 : BC_DIST_NONE;
-                    if (o.n_best) o.n_best[tile0 + p0 + j] = idx[j] >= 0;
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
-        // wave-aggregated append to the LDS queue
-        unsigned long long mask[4];
-        uint32_t total = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { mask[j] = __ballot(push[j]); total += (uint32_t)__popcll(mask[j]); }
-        if (total) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&q_n, total);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (push[j]) {
-                    const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[j] >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask[j], 0u));
-                    q_slot[at] = r[j];
-                    q_key[at] = key[j];
-                    q_link[at] = link[j];
-                    q_pos[at] = (uint16_t)(p0 + j);
-                }
-                base += (uint32_t)__popcll(mask[j]);
-            }
-        }
-    }
-    __syncthreads();
-    phase_mark(0);
-    const uint32_t qn = q_n;
-
-    // ---- phase 2a: table 1, overflow slabs of tables 0 and 1, decision
-    for (uint32_t qb = 0; qb < qn; qb += BLOCK) {
-        const uint32_t qi = qb + threadIdx.x;
-        const bool have = qi < qn;
-        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, c0 = 0, c1 = 0, rest1 = 0;
-        if (have) {
-            const uint64_t r = q_slot[qi];
-            rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
-            kmin = q_key[qi]; c0 = q_link[qi];
-            uint4 v[4];
-            load_piece(T1.slabs + ((size_t)seed_value(rlo, rhi, T1.start, T1.slen) << 3), v);
-            rest1 = slab_rest(T1, rlo, rhi);
-            kmin = scan_piece(v, rest1, half1, hm1, kmin);
-            c1 = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
-        }
-        while (__ballot((c0 | c1) != 0u) != 0ull) {  // overflow chains, one slab per lane and turn
-            if ((c0 | c1) != 0u) {
-                const bool t0 = c0 != 0u;
-                const uint2* base = t0 ? T0.slabs : T1.slabs;
-                const uint32_t half = t0 ? half0 : half1, hm = t0 ? hm0 : hm1;
-                const uint32_t rest = t0 ? slab_rest(T0, rlo, rhi) : rest1;
-                uint4 v[4];
-                load_piece(base + ((size_t)(t0 ? c0 : c1) << 3), v);
-                kmin = scan_piece(v, rest, half, hm, kmin);
-                const uint32_t nx = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
-                if (t0) c0 = nx; else c1 = nx;
-            }
-        }
-        // decision.  Seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1
-        // (NSEG = 3) / within max_mm (NSEG = 2).
-        const uint32_t d = kmin >> 24;
-        const bool inrange = have && d <= max_mm;
-        const bool uniq = lane_unique(kmin, max_mm);
-        // final: a unique best.  (NSEG = 3, d = 2: unseen guides are at distance >= 2, and the flag excludes a tie.)
-        const bool fin = inrange && uniq;
-        const bool slow = inrange && !uniq;
-        const bool t2 = have && !inrange && NSEG == 3;
-        const bool miss = have && !inrange && NSEG != 3;
-        if (fin) q_slot[qi] = pack_result(kmin & SLAB_GIDX_MASK, d, 1u);
-        if (miss) q_slot[qi] = pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-        if (NSEG == 3) {
-            const unsigned long long m = __ballot(t2);
-            if (m) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&t2_n, (uint32_t)__popcll(m));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (t2) l_t2[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)qi;
-            }
-        }
-        if (slow) l_slow[atomicAdd(&slow_n, 1u)] = (uint16_t)qi;  // rare
-    }
-
-    // ---- phase 2b: table 2 for the reads with nothing in range yet (compacted: full waves again)
-    if constexpr (NSEG == 3) {
-        __syncthreads();
-        phase_mark(1);
-        const SlabTable& T2 = sp.t[2];
-        const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u;
-        const uint32_t ppl = 1u << (T2.log2S - 3u);  // 64-byte pieces per slab
-        const uint32_t t2n = t2_n;
-        for (uint32_t tb = 0; tb < t2n; tb += BLOCK) {
-            const uint32_t ti = tb + threadIdx.x;
-            bool live = ti < t2n;
-            uint32_t qi = 0, rest = 0, slab = 0, piece = 0, kmin = 0xFFFFFFFFu;
-            if (live) {
-                qi = l_t2[ti];
-                const uint64_t r = q_slot[qi];
-                const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
-                rest = slab_rest(T2, rlo, rhi);
-                slab = seed_value(rlo, rhi, T2.start, T2.slen);
-            }
-            const bool mine = live;
-            while (__ballot(live) != 0ull) {
-                if (live) {
-                    uint4 v[4];
-                    load_piece(T2.slabs + ((size_t)slab << T2.log2S) + piece * 8u, v);
-                    kmin = scan_piece(v, rest, half2, hm2, kmin);
-                    if (++piece == ppl) {  // the slab's last piece carries the link
-                        slab = (v[3].w == SLAB_LINK) ? v[3].z : 0u;
-                        piece = 0;
-                        live = slab != 0u;
-                    }
-                }
-            }
-            // every guide within max_mm of these reads has segments 0 and 1 dirty, hence a clean segment 2: all seen
-            const uint32_t d = kmin >> 24;
-            const bool inrange = mine && d <= max_mm;
-            const bool uniq = lane_unique(kmin, max_mm);
-            if (inrange && uniq) q_slot[qi] = pack_result(kmin & SLAB_GIDX_MASK, d, 1u);
-            if (mine && !inrange) q_slot[qi] = pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-            if (inrange && !uniq) l_slow[atomicAdd(&slow_n, 1u)] = (uint16_t)qi;
-        }
-    }
-    __syncthreads();
-    phase_mark(2);
-
-    // ---- phase 2c: exact evaluation (every table, chains, duplicates removed, per-distance counts) by DPP quads
-    {
-        const uint32_t sn = slow_n;
-        const int sub = threadIdx.x & 3;
-        const int last_lane = (int)(lane | 3u);
-        for (uint32_t si = threadIdx.x >> 2; si < sn; si += BLOCK / 4) {
-            const uint32_t qi = l_slow[si];
-            const uint64_t r = q_slot[qi];
-            uint32_t key, nb;
-            slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), max_mm_, sub, last_lane, key, nb);
-            if (sub == 0) {
-                const bool hit = (key >> 24) <= max_mm;
-                q_slot[qi] = hit ? pack_result(key & SLAB_GIDX_MASK, key >> 24, nb > 255u ? 255u : nb)
-                                 : pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-            }
-        }
-    }
-    __syncthreads();
-    phase_mark(3);
-
-    // ---- phase 3: queued reads' results over the placeholders phase 1 left (same lines, still in L2)
-    for (uint32_t qi = threadIdx.x; qi < qn; qi += BLOCK) {
-        const uint64_t e = q_slot[qi];
-        const int32_t idx = (int32_t)(uint32_t)e;
-        if (idx == BC_IDX_MISS) continue;  // the placeholder already says so
-        const uint64_t i = tile0 + q_pos[qi];
-        o.best_idx[i] = idx;
-        if (o.best_dist) o.best_dist[i] = (uint8_t)(e >> 32);
-        if (o.n_best) o.n_best[i] = (uint8_t)(e >> 40);
-        tally(o, i, idx);
-    }
-    phase_mark(5);
-    if (PROF && threadIdx.x == 0) atomicAdd(&g_phase_cycles[7], 1ull);
-}
-
-// ---------------------------------------------------------------------------
-// K2+K3 wave form: the lane kernel's work split, but
-//   * a wave owns its tile of 256 reads outright (64-thread workgroups): no
-//     workgroup barrier ever waits for another wave's long chain;
-//   * slabs are fetched QUAD-COOPERATIVELY: for the four reads owned by the four
-//     lanes of a quad, load j brings read j's slab with lane s taking quarter s
-//     (one vector-L1 access per slab instead of four, and nothing depends on the
-//     L1 merging four quarter loads into one request); lane s scans its quarter
-//     of all four reads (rest of read j by DPP broadcast) and a transposed DPP
-//     min-reduction hands every owner its read's minimum;
-//   * ties / close neighbours are settled from the best guide's neighbour list
-//     (SlabParams::nbr) by the owning lane; the quad exact path (slab_slow) is
-//     left for guides with more than NBR_CAP close neighbours.
-// ---------------------------------------------------------------------------
-constexpr int WAVE_T = 256;  // reads per wave (4 per lane)
-constexpr uint32_t NOSLAB = 0xFFFFFFFFu;
 
 template <int J>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return quad_perm<J * 0x55>(v); }
@@ -1262,32 +972,42 @@ __device__ __forceinline__ uint32_t quad_tmin(const uint32_t (&a)[4], int s) {
     return min(hi ? b1 : b0, quad_perm<0x4E>(hi ? b0 : b1));
 }
 
-__device__ __forceinline__ uint4 load16(const uint2* p) {
-    const u32x4 t = *(gpiece_t)(uintptr_t)p;
+// 16-byte load, global address space (the table pointer comes out of a descriptor in memory; a generic pointer
+// would make this a flat load that also waits on the LDS counter), uniform base + 32-bit lane offset
+typedef const u32x4 __attribute__((address_space(1)))* gquarter_t;
+__device__ __forceinline__ uint4 load16(const char* base, uint32_t off) {
+    const u32x4 t = *(gquarter_t)(uintptr_t)(base + off);
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
-// request the slabs of the quad's four reads: NQ quarters per lane and read (1: 64-byte slabs, 2: 128-byte, 4: 256)
-template <int NQ, bool COND>
-__device__ __forceinline__ void visit_issue(const uint2* base, uint32_t log2S, uint32_t slab, int s, uint4 (&w)[4][NQ]) {
+// request the slabs of the quad's four reads, NQ quarters per lane and read (1: 64-byte slabs, 2: 128, 4: 256).
+// off = byte offset of the slab wanted by the read this lane owns (FROM3: by read j, held in lane 3 as off4[j]);
+// NOSLAB = none: the load is skipped (every vector-L1 access counts) and w[j] keeps what it held; v[j] says
+// whether read j's slab was requested.
+constexpr uint32_t NOSLAB = 0xFFFFFFFFu;
+template <int NQ, bool FROM3, bool COND>
+__device__ __forceinline__ void visit_issue(const char* base, uint32_t off, const uint32_t (&off4)[4], int s,
+                                            uint4 (&w)[4][NQ], bool (&v)[4]) {
     auto one = [&](auto jt) {
         constexpr int j = decltype(jt)::value;
-        const uint32_t sj = quad_bcast<j>(slab);
+        const uint32_t oj = FROM3 ? quad_bcast<3>(off4[j]) : quad_bcast<j>(off);
+        v[j] = !COND || oj != NOSLAB;
+        if (v[j]) {
 #pragma unroll
-        for (int h = 0; h < NQ; ++h) {
-            if (!COND || sj != NOSLAB) w[j][h] = load16(base + ((size_t)sj << log2S) + (uint32_t)(s + 4 * h) * 2u);
-            else w[j][h] = make_uint4(0u, SLAB_EMPTY, 0u, SLAB_EMPTY);
+            for (int h = 0; h < NQ; ++h) w[j][h] = load16(base, oj + (uint32_t)(s + 4 * h) * 16u);
         }
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
 }
 
-// scan them: kmin = min(kmin, this read's best key); link = this read's overflow slab (0 = none)
-template <int NQ>
-__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], uint32_t rest, uint32_t half, uint32_t hmask, int s,
-                                           uint32_t& kmin, uint32_t& link) {
-    uint32_t a[4], l[4];
+// scan them: kmin = min(kmin, best key of the read this lane owns); l[j] = last slot's first word of read j's
+// slab as seen by this lane — in lane 3 that is the overflow link (0 = none: the slot is link-or-empty).
+// A slab that was not requested contributes nothing (its registers hold stale data).
+template <int NQ, bool COND>
+__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], const bool (&v)[4], uint32_t rest, uint32_t half,
+                                           uint32_t hmask, int s, uint32_t& kmin, uint32_t (&l)[4]) {
+    uint32_t a[4];
     auto one = [&](auto jt) {
         constexpr int j = decltype(jt)::value;
         const uint32_t rj = quad_bcast<j>(rest);
@@ -1299,14 +1019,12 @@ __device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], uint32_t res
             const uint32_t d1 = __popc((x1 & hmask) | (x1 >> half));
             m = min(m, min((d0 << 24) | w[j][h].y, (d1 << 24) | w[j][h].w));
         }
-        a[j] = m;
-        l[j] = (w[j][NQ - 1].w == SLAB_LINK) ? w[j][NQ - 1].z : 0u;  // the slab's last entry: lane 3's last quarter
+        a[j] = (!COND || v[j]) ? m : 0xFFFFFFFFu;
+        l[j] = (!COND || v[j]) ? w[j][NQ - 1].z : 0u;
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
     kmin = min(kmin, quad_tmin(a, s));
-    const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
-    link = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;
 }
 
 // the best guide g (at distance d1) may tie with close neighbours: count them from g's neighbour list.
@@ -1330,43 +1048,81 @@ __device__ __forceinline__ bool resolve_ties(const SlabParams& sp, uint32_t rlo,
     return ok;
 }
 
+__device__ unsigned long long g_phase_cycles[8];  // BC_PHASE_PROF=1: summed cycles per stage over all waves
+
+// single-wave workgroups: LDS operations of one wave execute in issue order, so making another lane's list
+// entry visible only takes a compiler barrier and the LDS counter — not __syncthreads(), whose fence also waits
+// for every outstanding global load and store
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <int NSEG, int NQ2, bool PROF>
 __global__ __launch_bounds__(64) void k_match_wave(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,
                                                    const uint8_t* __restrict__ flags, uint64_t n, int k,
                                                    uint64_t kmask, int max_mm_, MatchOut o) {
     static_assert(NSEG == 2 || NSEG == 3, "wave kernel: d = 1 or 2");
-    __shared__ uint64_t q_slot[WAVE_T];   // queued read; later its result
-    __shared__ uint32_t q_key[WAVE_T];    // best key so far (table 0's primary slab)
-    __shared__ uint32_t q_link[WAVE_T];   // overflow slab of table 0 (0 = none)
-    __shared__ uint16_t q_pos[WAVE_T];    // position in the tile
-    __shared__ uint16_t l_t2[WAVE_T];     // queue entries that need table 2
-    __shared__ uint16_t l_slow[WAVE_T];   // queue entries that need the exact path
+    // list of reads without an exact hit: read, best key so far, table 0's overflow slab (byte offset), position
+    __shared__ uint64_t q_read[WAVE_T];
+    __shared__ uint32_t q_key[WAVE_T], q_off[WAVE_T];
+    __shared__ uint16_t l_t2[WAVE_T];     // list entries that need table 2
+    __shared__ uint16_t l_slow[WAVE_T];   // list entries that need the exact path
     const SlabParams& sp = *spp;
     const uint32_t max_mm = (uint32_t)max_mm_;
     const uint64_t tile0 = (uint64_t)blockIdx.x * WAVE_T;
     const uint32_t tn = (uint32_t)min((uint64_t)WAVE_T, n - tile0);
     const SlabTable& T0 = sp.t[0];
     const SlabTable& T1 = sp.t[1];
-    const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
-    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
+    const SlabTable& T2 = sp.t[NSEG - 1];
+    const char* const b0 = reinterpret_cast<const char*>(T0.slabs);
+    const char* const b1 = reinterpret_cast<const char*>(T1.slabs);
+    const char* const b2 = reinterpret_cast<const char*>(T2.slabs);
     const uint32_t lane = threadIdx.x;
+    const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
+    const uint32_t empty1 = T1.empty << 6, empty2 = T2.empty << (T2.log2S + 3u);  // what idle lanes fetch
+    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
+    const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u, sh2 = T2.log2S + 3u;
     const int s = (int)(lane & 3u);
-    unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull;
+    const uint32_t none4[4] = {0u, 0u, 0u, 0u};
+    unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull, t_acc[4] = {0ull, 0ull, 0ull, 0ull};
     auto phase_mark = [&](int ph) {
-        if (PROF && threadIdx.x == 0) {
+        if (PROF) {
             const unsigned long long t = (unsigned long long)clock64();
-            atomicAdd(&g_phase_cycles[ph], t - t_prev);
+            t_acc[ph] += t - t_prev;
             t_prev = t;
         }
     };
+    auto rank_of = [&](unsigned long long m) {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
+    // a listed read's result replaces the read in its list entry (index | dist << 32 | n_best << 40); the lane that
+    // owns the read in phase 1 collects it at the end: every result leaves in full-width coalesced stores
+    auto put = [&](uint32_t qi, uint32_t idx, uint32_t dist, uint32_t nb) {
+        q_read[qi] = (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)(nb > 255u ? 255u : nb) << 40);
+    };
     uint32_t qn = 0, t2n = 0, sn = 0;  // wave-uniform list lengths
 
+    // hit / tie / exact-path decision for the lane's read once every guide that can matter has been seen
+    auto decide = [&](bool mine, bool final_miss, uint32_t qi, uint32_t kmin, uint32_t rlo, uint32_t rhi) {
+        const uint32_t d = kmin >> 24;
+        const bool inrange = mine && d <= max_mm;
+        uint32_t ridx = kmin & SLAB_GIDX_MASK, rnb = 1u;
+        bool slow = false;
+        if (inrange && !key_unique(kmin, max_mm)) slow = !sp.nbr_slot || !resolve_ties(sp, rlo, rhi, d, ridx, rnb);
+        if (inrange && !slow) put(qi, ridx, d, rnb);
+        if (mine && !inrange && final_miss) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+        const unsigned long long m = __ballot(slow);
+        if (slow) l_slow[sn + rank_of(m)] = (uint16_t)qi;
+        sn += (uint32_t)__popcll(m);
+        return inrange;
+    };
+
     // ---- phase 1: table 0, primary slab, every read (exact hits are final)
+    const uint32_t p0 = lane * 4u;
+    const bool full = p0 + 3 < tn;
+    int32_t idx[4];
+    uint32_t at[4];  // list entry of the lane's reads that were listed
     {
-        const uint32_t p0 = lane * 4u;
         uint64_t r[4] = {0, 0, 0, 0};
-        const bool full = p0 + 3 < tn;
         if (full) {
             load_reads4(reads + tile0 + p0, r);
         } else {
@@ -1374,160 +1130,124 @@ __global__ __launch_bounds__(64) void k_match_wave(const SlabParams* __restrict_
             for (int j = 0; j < 4; ++j)
                 if (p0 + j < tn) r[j] = reads[tile0 + p0 + j];
         }
-        int32_t idx[4];
-        uint32_t key[4], link[4];
-        bool push[4], ok[4];
+        bool ok[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             ok[j] = p0 + j < tn && !read_skipped(r[j], flags, tile0 + p0 + j, k);
             r[j] &= kmask;
         }
         // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
-        auto slab0 = [&](int j) { return ok[j] ? seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) : 0u; };
-        auto finish = [&](int j, const uint4 (&w)[4][1]) {
-            key[j] = 0xFFFFFFFFu;
-            visit_scan<1>(w, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key[j], link[j]);
-            const bool exact = (key[j] >> 24) == 0u;  // the guide itself
-            idx[j] = !ok[j] ? BC_IDX_SKIP : exact ? (int32_t)(key[j] & SLAB_GIDX_MASK) : BC_IDX_MISS;
-            push[j] = ok[j] && !exact;
-        };
-        uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
-        visit_issue<1, false>(T0.slabs, 3u, slab0(0), s, wa);
-        visit_issue<1, false>(T0.slabs, 3u, slab0(1), s, wb);
-        finish(0, wa);
-        visit_issue<1, false>(T0.slabs, 3u, slab0(2), s, wa);
-        finish(1, wb);
-        visit_issue<1, false>(T0.slabs, 3u, slab0(3), s, wb);
-        finish(2, wa);
-        finish(3, wb);
-        if (full) {
-            reinterpret_cast<int4*>(o.best_idx + tile0)[p0 >> 2] = make_int4(idx[0], idx[1], idx[2], idx[3]);
-            if (o.best_dist) {
-                uchar4 d;
-                d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
-                d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
-                reinterpret_cast<uchar4*>(o.best_dist + tile0)[p0 >> 2] = d;
-            }
-            if (o.n_best) {
-                uchar4 c;
-                c.x = idx[0] >= 0; c.y = idx[1] >= 0; c.z = idx[2] >= 0; c.w = idx[3] >= 0;
-                reinterpret_cast<uchar4*>(o.n_best + tile0)[p0 >> 2] = c;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (p0 + j < tn) {
-                    o.best_idx[tile0 + p0 + j] = idx[j];
-                    if (o.best_dist) o.best_dist[tile0 + p0 + j] = idx[j] >= 0 ? 0 : BC_DIST_NONE;
-                    if (o.n_best) o.n_best[tile0 + p0 + j] = idx[j] >= 0;
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
-        // append the rest to the wave's LDS queue
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned long long m = __ballot(push[j]);
-            if (push[j]) {
-                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                q_slot[at] = r[j];
-                q_key[at] = key[j];
-                q_link[at] = link[j];
-                q_pos[at] = (uint16_t)(p0 + j);
+        auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << 6) : 0u; };
+        auto finish = [&](int j, const uint4 (&w)[4][1], const bool (&v)[4]) {
+            uint32_t l[4], key = 0xFFFFFFFFu;
+            visit_scan<1, false>(w, v, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key, l);
+            const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
+            const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner needs its link for the list
+            const bool exact = (key >> 24) == 0u;  // the guide itself
+            idx[j] = !ok[j] ? BC_IDX_SKIP : exact ? (int32_t)(key & SLAB_GIDX_MASK) : BC_IDX_MISS;
+            const bool push = ok[j] && !exact;
+            const unsigned long long m = __ballot(push);
+            at[j] = push ? qn + rank_of(m) : 0xFFFFFFFFu;
+            if (push) {
+                q_read[at[j]] = r[j];
+                q_key[at[j]] = key;
+                q_off[at[j]] = lnk ? (lnk << 6) : NOSLAB;
             }
             qn += (uint32_t)__popcll(m);
-        }
+        };
+        uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
+        bool va[4], vb[4];
+        visit_issue<1, false, false>(b0, off0(0), none4, s, wa, va);
+        visit_issue<1, false, false>(b0, off0(1), none4, s, wb, vb);
+        finish(0, wa, va);
+        visit_issue<1, false, false>(b0, off0(2), none4, s, wa, va);
+        finish(1, wb, vb);
+        visit_issue<1, false, false>(b0, off0(3), none4, s, wb, vb);
+        finish(2, wa, va);
+        finish(3, wb, vb);
     }
-    __syncthreads();
+    wave_lds_sync();
     phase_mark(0);
 
-    // ---- phase 2a: table 1, overflow slabs of tables 0 and 1, decision
+    // ---- phase 2a: table 1 + overflow slabs of tables 0 and 1, 64 listed reads at a time, then the decision
     for (uint32_t qb = 0; qb < qn; qb += 64) {
         const uint32_t qi = qb + lane;
-        const bool have = qi < qn;
-        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, c0 = 0, c1 = 0, rest0 = 0, rest1 = 0;
-        uint4 wa[4][1], wb[4][1];
-        if (have) {
-            const uint64_t r = q_slot[qi];
+        const bool mine = qi < qn;
+        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, rest0 = 0, rest1 = 0, off0 = NOSLAB, off1 = empty1;
+        if (mine) {
+            const uint64_t r = q_read[qi];
             rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
-            kmin = q_key[qi]; c0 = q_link[qi];
+            kmin = q_key[qi]; off0 = q_off[qi];
             rest0 = slab_rest(T0, rlo, rhi);
             rest1 = slab_rest(T1, rlo, rhi);
+            off1 = seed_value(rlo, rhi, T1.start, T1.slen) << 6;
         }
-        visit_issue<1, true>(T1.slabs, 3u, have ? seed_value(rlo, rhi, T1.start, T1.slen) : NOSLAB, s, wa);
-        bool any0 = __ballot(c0 != 0u) != 0ull;
-        if (any0) visit_issue<1, true>(T0.slabs, 3u, c0 ? c0 : NOSLAB, s, wb);
-        visit_scan<1>(wa, rest1, half1, hm1, s, kmin, c1);
-        if (any0) visit_scan<1>(wb, rest0, half0, hm0, s, kmin, c0);
-        for (;;) {  // further overflow slabs
-            any0 = __ballot(c0 != 0u) != 0ull;
-            const bool any1 = __ballot(c1 != 0u) != 0ull;
+        uint4 wa[4][1], wb[4][1];
+        bool va[4], vb[4];
+        uint32_t l0[4] = {0u, 0u, 0u, 0u}, l1[4];
+        bool any0 = __ballot(off0 != NOSLAB) != 0ull;
+        visit_issue<1, false, false>(b1, off1, none4, s, wa, va);
+        if (any0) visit_issue<1, false, true>(b0, off0, none4, s, wb, vb);
+        visit_scan<1, false>(wa, va, rest1, half1, hm1, s, kmin, l1);
+        if (any0) visit_scan<1, true>(wb, vb, rest0, half0, hm0, s, kmin, l0);
+        for (;;) {  // further overflow slabs, straight from lane 3 (one table at a time: registers)
+            any0 = __ballot(s == 3 && (l0[0] | l0[1] | l0[2] | l0[3]) != 0u) != 0ull;
+            const bool any1 = __ballot(s == 3 && (l1[0] | l1[1] | l1[2] | l1[3]) != 0u) != 0ull;
             if (!any0 && !any1) break;
-            if (any0) visit_issue<1, true>(T0.slabs, 3u, c0 ? c0 : NOSLAB, s, wb);
-            if (any1) visit_issue<1, true>(T1.slabs, 3u, c1 ? c1 : NOSLAB, s, wa);
-            if (any0) visit_scan<1>(wb, rest0, half0, hm0, s, kmin, c0);
-            if (any1) visit_scan<1>(wa, rest1, half1, hm1, s, kmin, c1);
+            if (any0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) l0[j] = l0[j] ? (l0[j] << 6) : NOSLAB;
+                visit_issue<1, true, true>(b0, 0u, l0, s, wa, va);
+                visit_scan<1, true>(wa, va, rest0, half0, hm0, s, kmin, l0);
+            }
+            if (any1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) l1[j] = l1[j] ? (l1[j] << 6) : NOSLAB;
+                visit_issue<1, true, true>(b1, 0u, l1, s, wa, va);
+                visit_scan<1, true>(wa, va, rest1, half1, hm1, s, kmin, l1);
+            }
         }
-        // decision.  Seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1
-        // (NSEG = 3) / within max_mm (NSEG = 2); unseen guides are at distance >= 2.
-        const uint32_t d = kmin >> 24;
-        const bool inrange = have && d <= max_mm;
-        uint32_t ridx = kmin & SLAB_GIDX_MASK, rnb = 1u;
-        bool slow = false;
-        if (inrange && !lane_unique(kmin, max_mm)) slow = !sp.nbr_slot || !resolve_ties(sp, rlo, rhi, d, ridx, rnb);
-        if (inrange && !slow) q_slot[qi] = pack_result(ridx, d, rnb > 255u ? 255u : rnb);
-        if (have && !inrange && NSEG != 3) q_slot[qi] = pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+        // seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1 (NSEG = 3) /
+        // within max_mm (NSEG = 2); unseen guides are at distance >= 2
+        const bool inrange = decide(mine, NSEG != 3, qi, kmin, rlo, rhi);
         if (NSEG == 3) {
-            const bool t2 = have && !inrange;
+            const bool t2 = mine && !inrange;
             const unsigned long long m = __ballot(t2);
-            if (t2) l_t2[t2n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)qi;
+            if (t2) l_t2[t2n + rank_of(m)] = (uint16_t)qi;
             t2n += (uint32_t)__popcll(m);
         }
-        {
-            const unsigned long long m = __ballot(slow);
-            if (slow) l_slow[sn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)qi;
-            sn += (uint32_t)__popcll(m);
-        }
     }
-    __syncthreads();
+    wave_lds_sync();
     phase_mark(1);
 
     // ---- phase 2b: table 2 for the reads with nothing in range yet (compacted: full waves again)
     if constexpr (NSEG == 3) {
-        const SlabTable& T2 = sp.t[2];
-        const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u;
         for (uint32_t tb = 0; tb < t2n; tb += 64) {
             const uint32_t ti = tb + lane;
             const bool mine = ti < t2n;
-            uint32_t qi = 0, rlo = 0, rhi = 0, rest = 0, slab = NOSLAB, kmin = 0xFFFFFFFFu;
+            uint32_t qi = 0, rlo = 0, rhi = 0, rest = 0, off = empty2, kmin = 0xFFFFFFFFu;
             if (mine) {
                 qi = l_t2[ti];
-                const uint64_t r = q_slot[qi];
+                const uint64_t r = q_read[qi];
                 rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
                 rest = slab_rest(T2, rlo, rhi);
-                slab = seed_value(rlo, rhi, T2.start, T2.slen);
+                off = seed_value(rlo, rhi, T2.start, T2.slen) << sh2;
             }
-            while (__ballot(slab != NOSLAB) != 0ull) {
-                uint4 w[4][NQ2];
-                visit_issue<NQ2, true>(T2.slabs, T2.log2S, slab, s, w);
-                uint32_t nx;
-                visit_scan<NQ2>(w, rest, half2, hm2, s, kmin, nx);
-                slab = (slab != NOSLAB && nx != 0u) ? nx : NOSLAB;
+            uint4 w[4][NQ2];
+            bool v[4];
+            uint32_t l[4];
+            visit_issue<NQ2, false, false>(b2, off, none4, s, w, v);
+            visit_scan<NQ2, false>(w, v, rest, half2, hm2, s, kmin, l);
+            while (__ballot(s == 3 && (l[0] | l[1] | l[2] | l[3]) != 0u) != 0ull) {  // overflow slabs, from lane 3
+#pragma unroll
+                for (int j = 0; j < 4; ++j) l[j] = l[j] ? (l[j] << sh2) : NOSLAB;
+                visit_issue<NQ2, true, true>(b2, 0u, l, s, w, v);
+                visit_scan<NQ2, true>(w, v, rest, half2, hm2, s, kmin, l);
             }
             // every guide within max_mm of these reads has segments 0 and 1 dirty, hence a clean segment 2: all seen
-            const uint32_t d = kmin >> 24;
-            const bool inrange = mine && d <= max_mm;
-            uint32_t ridx = kmin & SLAB_GIDX_MASK, rnb = 1u;
-            bool slow = false;
-            if (inrange && !lane_unique(kmin, max_mm)) slow = !sp.nbr_slot || !resolve_ties(sp, rlo, rhi, d, ridx, rnb);
-            if (inrange && !slow) q_slot[qi] = pack_result(ridx, d, rnb > 255u ? 255u : rnb);
-            if (mine && !inrange) q_slot[qi] = pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-            const unsigned long long m = __ballot(slow);
-            if (slow) l_slow[sn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)qi;
-            sn += (uint32_t)__popcll(m);
+            decide(mine, true, qi, kmin, rlo, rhi);
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     phase_mark(2);
 
@@ -1536,32 +1256,59 @@ __global__ __launch_bounds__(64) void k_match_wave(const SlabParams* __restrict_
         const int last_lane = (int)(lane | 3u);
         for (uint32_t si = lane >> 2; si < sn; si += 16) {
             const uint32_t qi = l_slow[si];
-            const uint64_t r = q_slot[qi];
+            const uint64_t r = q_read[qi];
             uint32_t key, nb;
             slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), max_mm_, s, last_lane, key, nb);
             if (s == 0) {
-                const bool hit = (key >> 24) <= max_mm;
-                q_slot[qi] = hit ? pack_result(key & SLAB_GIDX_MASK, key >> 24, nb > 255u ? 255u : nb)
-                                 : pack_result((uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+                if ((key >> 24) <= max_mm) put(qi, key & SLAB_GIDX_MASK, key >> 24, nb);
+                else put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
+    }
+
+    // ---- phase 3: every lane collects its four reads' results; full-width coalesced stores, nothing is patched
+    {
+        uint32_t dist[4], nb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dist[j] = idx[j] >= 0 ? 0u : (uint32_t)BC_DIST_NONE;
+            nb[j] = idx[j] >= 0 ? 1u : 0u;
+            if (at[j] != 0xFFFFFFFFu) {
+                const uint64_t e = q_read[at[j]];
+                idx[j] = (int32_t)(uint32_t)e; dist[j] = (uint32_t)(e >> 32) & 0xFFu; nb[j] = (uint32_t)(e >> 40) & 0xFFu;
+            }
+        }
+        if (full) {
+            reinterpret_cast<int4*>(o.best_idx + tile0)[p0 >> 2] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            if (o.best_dist) {
+                uchar4 d;
+                d.x = (uint8_t)dist[0]; d.y = (uint8_t)dist[1]; d.z = (uint8_t)dist[2]; d.w = (uint8_t)dist[3];
+                reinterpret_cast<uchar4*>(o.best_dist + tile0)[p0 >> 2] = d;
+            }
+            if (o.n_best) {
+                uchar4 c;
+                c.x = (uint8_t)nb[0]; c.y = (uint8_t)nb[1]; c.z = (uint8_t)nb[2]; c.w = (uint8_t)nb[3];
+                reinterpret_cast<uchar4*>(o.n_best + tile0)[p0 >> 2] = c;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) {
+                    o.best_idx[tile0 + p0 + j] = idx[j];
+                    if (o.best_dist) o.best_dist[tile0 + p0 + j] = (uint8_t)dist[j];
+                    if (o.n_best) o.n_best[tile0 + p0 + j] = (uint8_t)nb[j];
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
     }
     phase_mark(3);
-
-    // ---- phase 3: queued reads' results over the placeholders phase 1 left (same lines, still in L2)
-    for (uint32_t qi = lane; qi < qn; qi += 64) {
-        const uint64_t e = q_slot[qi];
-        const int32_t idx = (int32_t)(uint32_t)e;
-        if (idx == BC_IDX_MISS) continue;  // the placeholder already says so
-        const uint64_t i = tile0 + q_pos[qi];
-        o.best_idx[i] = idx;
-        if (o.best_dist) o.best_dist[i] = (uint8_t)(e >> 32);
-        if (o.n_best) o.n_best[i] = (uint8_t)(e >> 40);
-        tally(o, i, idx);
+    if (PROF && threadIdx.x == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_phase_cycles[i], t_acc[i]);
+        atomicAdd(&g_phase_cycles[7], 1ull);
     }
-    phase_mark(5);
-    if (PROF && threadIdx.x == 0) atomicAdd(&g_phase_cycles[7], 1ull);
 }
 
 // ---------------------------------------------------------------------------
@@ -1820,10 +1567,14 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
             slabs[(cur << log2S) + pos++] = make_uint2(rest_of(keys[j]), gidx[j] | fl);
         }
     }
+    const uint32_t empty_slab = (uint32_t)(slabs.size() >> log2S);
+    slabs.resize(slabs.size() + S, make_uint2(0u, SLAB_EMPTY));
+    if ((slabs.size() * sizeof(uint2)) >> 32) { lib->slab_ok[d] = false; return BC_OK; }  // 32-bit byte offsets
     uint2* d_slabs;
     int rc = dev_upload(lib, slabs, &d_slabs);
     if (rc != BC_OK) return rc;
     SlabTable& T = sl.t[s];
+    T.empty = empty_slab;
     T.slabs = d_slabs; T.start = (uint32_t)start; T.slen = (uint32_t)slen; T.half = (uint32_t)half;
     T.log2S = (uint32_t)log2S;
     for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
@@ -2116,44 +1867,31 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                 // the quad state machine handles 8-entry slabs for tables 0,1 and 8/16-entry slabs for table 2
                 const SlabParams& hp = lib->slab[max_mm];
                 // default: the wave kernel (lane-owned reads, quad-cooperative loads, no hash table);
-                // BC_LANE=1 the workgroup-tiled lane kernel, BC_LANE=0 the quad kernels
-                const int lane_mode = env_int("BC_LANE", 2);
-                const bool lane_ok = lane_mode && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
+                // BC_LANE=0 selects the quad kernels
+                const bool wave_ok = env_int("BC_LANE", 1) && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
                                      hp.t[1].log2S == 3 && !lib->h_nn.empty();
-                if (lane_ok) {
-                    const bool prof = env_int("BC_PHASE_PROF", 0) != 0;  // tuning aid: per-phase cycle sums on stderr
-                    const bool wave = lane_mode == 2;
+                if (wave_ok) {
+                    const bool prof = env_int("BC_PHASE_PROF", 0) != 0;  // tuning aid: per-stage cycle sums on stderr
                     const int nq2 = nseg == 3 ? (1 << (hp.t[2].log2S - 3)) : 1;
-                    if (wave) {
-                        const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
+                    const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_)                                                                         \
     hipLaunchKernelGGL((k_match_wave<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n,   \
                        lib->k, lib->kmask, max_mm, o)
 #define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false); } while (0)
-                        if (nseg == 2) BC_WAVE_P(2, 1);
-                        else if (nq2 == 1) BC_WAVE_P(3, 1);
-                        else if (nq2 == 2) BC_WAVE_P(3, 2);
-                        else BC_WAVE_P(3, 4);
+                    if (nseg == 2) BC_WAVE_P(2, 1);
+                    else if (nq2 == 1) BC_WAVE_P(3, 1);
+                    else if (nq2 == 2) BC_WAVE_P(3, 2);
+                    else BC_WAVE_P(3, 4);
 #undef BC_WAVE_P
 #undef BC_WAVE_LAUNCH
-                    } else {
-                        const int lgrid = (int)((n + LANE_T - 1) / LANE_T);
-#define BC_LANE_LAUNCH(NSEG_, PROF_)                                                                              \
-    hipLaunchKernelGGL((k_match_lane<NSEG_, PROF_>), dim3(lgrid), dim3(BLOCK), 0, st, dp, d_reads, d_flags, n,    \
-                       lib->k, lib->kmask, max_mm, o)
-                        if (nseg == 2) { if (prof) BC_LANE_LAUNCH(2, true); else BC_LANE_LAUNCH(2, false); }
-                        else { if (prof) BC_LANE_LAUNCH(3, true); else BC_LANE_LAUNCH(3, false); }
-#undef BC_LANE_LAUNCH
-                    }
                     BC_HIP(hipGetLastError());
                     if (prof) {
                         unsigned long long c[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                         BC_HIP(hipStreamSynchronize(st));
                         BC_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof(c)));
                         BC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
-                        fprintf(stderr, "match phases (cycles/tile): p1 %.0f  2a %.0f  2b %.0f  2c %.0f  p3 %.0f  tiles %llu\n",
-                                (double)c[0] / c[7], (double)c[1] / c[7], (double)c[2] / c[7], (double)c[3] / c[7],
-                                (double)c[5] / c[7], c[7]);
+                        fprintf(stderr, "match stages (cycles/wave): 1 %.0f  2a %.0f  2b %.0f  2c %.0f  waves %llu\n",
+                                (double)c[0] / c[7], (double)c[1] / c[7], (double)c[2] / c[7], (double)c[3] / c[7], c[7]);
                     }
                     return BC_OK;
                 }

@@ -150,7 +150,7 @@ def main():
                        "parallelism": f"reads sharded x{world}, counts all-reduced"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": {"seed": "match pass = k_match_fused (exact stage + seed-index stage) + k_hist (tally)",
+                         "kernel": {"seed": "match pass = k_match_wave (table 0 = exact stage, tables 1-2 on compacted lists) + k_hist (tally)",
                                     "seed_csr": "k_match_seed", "brute": "k_match_brute", "hash": "k_match_hash + k_hist",
                                     "auto": "auto"}[args.algo],
                          "kernel_ms": k_ms, "algorithmic_bytes_per_read": ALGO_BYTES,

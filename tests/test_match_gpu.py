@@ -78,6 +78,57 @@ def test_dense_library_ties(gpu_device, oracle):
     assert res is not None
 
 
+def _mutate(rng, codes, nsub):
+    """codes: (n, k) array of 0..3; substitute nsub[i] distinct positions of row i by a different base"""
+    out = codes.copy()
+    n, k = codes.shape
+    for i in range(n):
+        pos = rng.choice(k, size=nsub[i], replace=False)
+        out[i, pos] = (out[i, pos] + rng.integers(1, 4, size=nsub[i])) % 4
+    return out
+
+
+@pytest.mark.parametrize("slab", ["3,3,3", "3,3,4", "3,3,5"])
+@pytest.mark.parametrize("cluster", [0, 3, 12])
+def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, monkeypatch):
+    """The default d = 1, 2 kernel (k_match_wave) on every table-2 slab size, with libraries from isolated guides
+    to tight clusters: isolation flags, tie counting from neighbour lists (cluster = 3: lists of <= 8), the quad
+    exact path (cluster = 12: more than 8 close neighbours), overflow chains, skip flags, a ragged last tile —
+    against the oracle and against the quad kernels (BC_LANE=0)."""
+    k, n = 20, 10007
+    rng = np.random.default_rng(17 + cluster)
+    if cluster:
+        centres = rng.integers(0, 4, size=(400, k))
+        fam = np.repeat(centres, cluster, axis=0)
+        fam = _mutate(rng, fam, rng.integers(0, 3, size=fam.shape[0]))
+        fam = np.unique(fam, axis=0)
+        codes = fam[rng.permutation(fam.shape[0])]
+    else:
+        codes = np.unique(rng.integers(0, 4, size=(6000, k)), axis=0)
+        codes = codes[rng.permutation(codes.shape[0])]
+    G = codes.shape[0]
+    letters = np.array(list("ACGT"))
+    lib_s = ["".join(letters[r]) for r in codes]
+    src = rng.integers(0, G, size=n)
+    nsub = rng.choice([0, 1, 2, 3], size=n, p=[0.4, 0.3, 0.2, 0.1])
+    rd = _mutate(rng, codes[src], nsub)
+    rd[rng.random(n) < 0.05] = rng.integers(0, 4, size=k)
+    reads_s = ["".join(letters[r]) for r in rd]
+    lib, _ = E.pack_kmers(lib_s, k)
+    reads, _ = E.pack_kmers(reads_s, k)
+    flags = (rng.random(n) < 0.02).astype(np.uint8)
+    monkeypatch.setenv("BC_SLAB_LOG2S", slab)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    for d in (1, 2):
+        ref = oracle.best_hit(lib_s, reads_s, d, skip=flags, base=3)
+        monkeypatch.setenv("BC_LANE", "1")
+        _check(GpuMatcher(dl).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
+        monkeypatch.setenv("BC_LANE", "0")
+        _check(GpuMatcher(dl).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
+    if cluster:
+        assert (ref["n_best"] > 1).sum() > 50
+
+
 def test_all_hits(gpu_device, oracle):
     k = 20
     lib, reads, flags = _case(2000, 5000, k, 1, seed=21)
