@@ -7,9 +7,9 @@ the bytes of a 16-byte-per-lane coalesced streaming read, WRITE_SIZE is exact.
 k_hist (and the stand-alone k_match_hash) stream their input with 16-byte-per-lane
 loads, so their FETCH_SIZE is doubled (calibration on known byte counts: k_match_hash
 raw 436 MB for an 800 MB read array, k_hist raw 1.0 GB for 5 x 400 MB).
-k_match_fused / k_match_slabq mix the 16-byte-per-lane read stream with table
-pieces served from L2 / Infinity Cache (FETCH_SIZE counts Infinity-Cache hits);
-their FETCH_SIZE is recorded raw (a lower bound) and flagged as such.
+k_match_wave / k_match_fused / k_match_slabq mix the 16-byte-per-lane read stream
+(8 B per read, counted at half: + 4 B per read added back) with table pieces served
+from L2 / Infinity Cache (FETCH_SIZE counts Infinity-Cache hits as fetches).
 usage: python profiles/collect_traffic.py profiles/r01_rocprof_summary.json reads algo max_mm
 """
 import json, sys
@@ -22,10 +22,12 @@ for name, e in d.items():
     f = e.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0) * 1024
     w = e.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0) * 1024
     corr = 2.0 if name.startswith(("k_match_hash", "k_hist")) else 1.0
-    rows[name] = {"fetch_raw_bytes": f, "fetch_correction": corr, "write_bytes": w, "hbm_bytes": f * corr + w}
-    total += f * corr + w
+    add = 4.0 * reads if name.startswith(("k_match_wave", "k_match_fused", "k_match_slabq")) else 0.0
+    rows[name] = {"fetch_raw_bytes": f, "fetch_correction": corr, "fetch_added_bytes": add, "write_bytes": w,
+                  "hbm_bytes": f * corr + add + w}
+    total += f * corr + add + w
 out = {"reads": reads, "algo": algo, "max_mismatch": mm, "hbm_bytes_per_pass": total, "per_kernel": rows,
        "algorithmic_bytes_per_pass": 13 * reads, "source": src,
-       "note": "FETCH_SIZE counts Infinity-Cache hits too; the fused / slabq kernels' fetch is uncorrected (lower bound)"}
+       "note": "FETCH_SIZE counts Infinity-Cache hits too; the match kernel's table misses are included as fetched bytes"}
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
