@@ -1528,6 +1528,10 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     // (16,16,32) 3.13 ms — short chained slabs beat long ones (smaller tables, fewer bytes per visit).
     const double mu = (double)lib->G / nb;
     int log2S = (mu <= 7.0) ? 3 : 4;
+    // tables 0 and 1 of the d = 1, 2 indexes keep 64-byte slabs up to ~16 guides per bucket: that is the geometry
+    // k_match_wave is built for (one quad-cooperative load per slab; fuller buckets chain).  Measured, 1e8 reads,
+    // d <= 2: G = 2e4 77 vs 57 G reads/s (quad kernels), 2e5 27 vs 23; at 1e6 (61 per bucket) the quad kernels win.
+    if ((cs.nseg == 2 || cs.nseg == 3) && s < 2 && mu <= 16.0) log2S = 3;
     log2S = std::max(log2S, env_int("BC_SLAB_MIN_LOG2S", 3));
     log2S = std::min(std::min(SLAB_MAX_LOG2S, env_int("BC_SLAB_MAX_LOG2S", SLAB_MAX_LOG2S)), log2S);
     if (const char* spec = getenv("BC_SLAB_LOG2S")) {  // tuning aid: explicit per-table sizes "a,b,c"
