@@ -189,17 +189,20 @@ __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict
             queue_push<VEC>(q, &q_n, push, rr, ii);
         }
         if constexpr (VEC == 4) {
-            reinterpret_cast<int4*>(o.best_idx)[g] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+            {   // results are final: non-temporal stores keep the table in the L2
+                const u32x4 t = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2], (uint32_t)idx[3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(o.best_idx) + g);
+            }
             if (o.best_dist) {
                 uchar4 d;
                 d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
                 d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
-                reinterpret_cast<uchar4*>(o.best_dist)[g] = d;
+                __builtin_nontemporal_store((uint32_t)d.x | ((uint32_t)d.y << 8) | ((uint32_t)d.z << 16) | ((uint32_t)d.w << 24), reinterpret_cast<uint32_t*>(o.best_dist) + g);
             }
             if (o.n_best) {
                 uchar4 d;
                 d.x = idx[0] >= 0; d.y = idx[1] >= 0; d.z = idx[2] >= 0; d.w = idx[3] >= 0;
-                reinterpret_cast<uchar4*>(o.n_best)[g] = d;
+                __builtin_nontemporal_store((uint32_t)d.x | ((uint32_t)d.y << 8) | ((uint32_t)d.z << 16) | ((uint32_t)d.w << 24), reinterpret_cast<uint32_t*>(o.n_best) + g);
             }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) tally(o, g * VEC + j, idx[j]);
