@@ -129,6 +129,31 @@ def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, monkeypatch):
         assert (ref["n_best"] > 1).sum() > 50
 
 
+def test_tally_hot_guides(gpu_device):
+    """Per-guide counts in the millions through the LDS histogram (k_hist), first-seen intact."""
+    k, G, n = 20, 300, 3_000_003
+    lib = S.library(G, k)
+    rng = np.random.default_rng(5)
+    pick = rng.choice(G, size=n, p=np.r_[0.6, 0.3, np.full(G - 2, 0.1 / (G - 2))])
+    pick[:5] = [17, 17, 3, 0, 1]
+    reads = lib[pick].copy()
+    miss = rng.random(n) < 0.01
+    reads[miss] ^= np.uint64(0x5A5A5)  # a few non-matching reads
+    dl = DeviceLibrary(lib, k, gpu_device)
+    res = GpuMatcher(dl).match(reads, None, max_mismatch=0, algo="hash", first_index=100)
+    hit = res.best_idx >= 0
+    np.testing.assert_array_equal(res.best_idx[~miss], pick[~miss])
+    np.testing.assert_array_equal(res.counts, np.bincount(res.best_idx[hit], minlength=G))
+    assert res.counts.max() > 1_000_000
+    first = np.full(G, np.iinfo(np.uint64).max, np.uint64)
+    idx_hit = np.flatnonzero(hit)
+    order = np.argsort(res.best_idx[idx_hit], kind="stable")
+    g_sorted = res.best_idx[idx_hit][order]
+    starts = np.r_[0, np.flatnonzero(np.diff(g_sorted)) + 1]
+    first[g_sorted[starts]] = idx_hit[order][starts].astype(np.uint64) + np.uint64(100)
+    np.testing.assert_array_equal(res.first_seen.astype(np.uint64), first)
+
+
 def test_all_hits(gpu_device, oracle):
     k = 20
     lib, reads, flags = _case(2000, 5000, k, 1, seed=21)
