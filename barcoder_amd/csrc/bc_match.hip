@@ -1121,11 +1121,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         return inrange;
     };
 
-    // ---- phase 1: table 0, primary slab, every read (exact hits are final)
+    // ---- phase 1: table 0, primary slab, every read (exact hits and isolated near hits are final)
     const uint32_t p0 = lane * 4u;
     const bool full = p0 + 3 < tn;
     int32_t idx[4];
-    uint32_t at[4];  // list entry of the lane's reads that were listed
+    uint32_t at[4];     // list entry of the lane's reads that were listed
+    uint32_t dist4 = 0; // distances of the reads settled in phase 1, one byte each
     {
         uint64_t r[4] = {0, 0, 0, 0};
         if (full) {
@@ -1148,9 +1149,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             visit_scan<1, false>(w, v, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key, l);
             const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
             const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner needs its link for the list
-            const bool exact = (key >> 24) == 0u;  // the guide itself
-            idx[j] = !ok[j] ? BC_IDX_SKIP : exact ? (int32_t)(key & SLAB_GIDX_MASK) : BC_IDX_MISS;
-            const bool push = ok[j] && !exact;
+            // final already: the guide itself (d = 0), or a guide within max_mm whose isolation flag rules out any
+            // other guide that close to the read (nn > 2d: a second guide within d of the read would be within 2d of
+            // this one) — whatever the other tables and the overflow slabs hold
+            const uint32_t d = key >> 24;
+            const bool fin = ok[j] && d <= max_mm && key_unique(key, max_mm);
+            idx[j] = !ok[j] ? BC_IDX_SKIP : fin ? (int32_t)(key & SLAB_GIDX_MASK) : BC_IDX_MISS;
+            dist4 |= (fin ? d : 0u) << (8 * j);
+            const bool push = ok[j] && !fin;
             const unsigned long long m = __ballot(push);
             at[j] = push ? qn + rank_of(m) : 0xFFFFFFFFu;
             if (push) {
@@ -1277,7 +1283,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         uint32_t dist[4], nb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            dist[j] = idx[j] >= 0 ? 0u : (uint32_t)BC_DIST_NONE;
+            dist[j] = idx[j] >= 0 ? ((dist4 >> (8 * j)) & 0xFFu) : (uint32_t)BC_DIST_NONE;
             nb[j] = idx[j] >= 0 ? 1u : 0u;
             if (at[j] != 0xFFFFFFFFu) {
                 const uint64_t e = q_read[at[j]];
