@@ -931,8 +931,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
 //   one lane per read, slabs fetched as 4 x 16 B by the lane: VALU 47 %, but
 //     four vector-L1 accesses per slab and ~25 dependent memory round trips per
 //     workgroup tile held together by barriers: 1.95 ms.
-// This kernel (1.31 ms; 2.3 L2 requests per read at 175 G requests/s, which is what
-// the stream + gather microbenchmark reaches with a 4 MB table; VALU ~90 %):
+// This kernel (1.30 ms; 2.1 L2 requests per read at 160 G requests/s — the stream +
+// gather microbenchmark reaches 142-184 G/s with a table this size — and VALU 93 %):
 //   * no hash table: a guide equal to the read sits in the read's seed-0 bucket, so
 //     table 0 doubles as the exact-match table; 3.7 MB of slabs, 93 % L2 hits;
 //   * a wave works alone (64-thread workgroups) on 256 consecutive reads and keeps
