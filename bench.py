@@ -28,26 +28,51 @@ MAX_MM = 2
 G = 100_000
 
 
+def ascii_from_packed(packed, k):
+    """plane-form uint64 k-mers -> (n, k) uint8 ASCII array (what the string-based oracle reads)"""
+    p = np.ascontiguousarray(packed, np.uint64)
+    sh = np.arange(k, dtype=np.uint64)
+    out = np.empty((p.size, k), np.uint8)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    for a in range(0, p.size, 1 << 20):  # bounded temporaries
+        q = p[a:a + (1 << 20), None]
+        lo = ((q >> sh) & np.uint64(1)).astype(np.uint8)
+        hi = ((q >> (sh + np.uint64(32))) & np.uint64(1)).astype(np.uint8)
+        out[a:a + q.shape[0]] = letters[lo | (hi << 1)]
+    return out
+
+
 def cpu_baseline(lib_packed, n_sample, seed, max_mm):
-    """Oracle C brute force (string based, OpenMP) on the first reads of the same
-    stream; the sample is sized from a short probe so that it runs ~15 s."""
-    from barcoder_amd import encoding as E, synth as S
+    """The CPU port of the same job on the first reads of the same stream: oracle.c's pigeonhole-indexed best-hit
+    search (strings, OpenMP, all host cores), sized from a probe to ~10 s of CPU work; the brute-force sweep the
+    oracle is defined by runs on a prefix (~5 s) and must agree with it."""
+    from barcoder_amd import synth as S
     from oracle import oracle as orc
-    ls = E.unpack_kmers(lib_packed, K)
-    probe = E.unpack_kmers(S.reads(lib_packed, K, seed, 0, 2000, 1), K)
+    la = ascii_from_packed(lib_packed, K)
+    probe = ascii_from_packed(S.reads(lib_packed, K, seed, 0, 200_000, 1), K)
     t0 = time.perf_counter()
-    orc.best_hit(ls, probe, max_mm)
-    rate = 2000 / max(time.perf_counter() - t0, 1e-6)
+    orc.best_hit_arrays(la, probe, max_mm, indexed=True)
+    rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
+    t0 = time.perf_counter()
+    orc.best_hit_arrays(la, probe[:2000], max_mm, indexed=False)
+    brate = 2000 / max(time.perf_counter() - t0, 1e-6)
     if n_sample <= 0:
-        n_sample = int(min(2_000_000, max(20_000, rate * 15)))
+        n_sample = int(min(40_000_000, max(200_000, rate * 10)))
     reads = S.reads(lib_packed, K, seed, 0, n_sample, 1)
-    rs = E.unpack_kmers(reads, K)
+    ra = ascii_from_packed(reads, K)
     t0 = time.perf_counter()
-    ref = orc.best_hit(ls, rs, max_mm)
+    ref = orc.best_hit_arrays(la, ra, max_mm, indexed=True)
     dt = time.perf_counter() - t0
+    nb = int(min(n_sample, max(20_000, brate * 5)))
+    t0 = time.perf_counter()
+    brute = orc.best_hit_arrays(la, ra[:nb], max_mm, indexed=False)
+    bdt = time.perf_counter() - t0
+    same = all(np.array_equal(brute[k_], ref[k_][:nb]) for k_ in ("best_idx", "best_dist", "n_best"))
     return ref, reads, dict(value=n_sample / dt / 1e6, unit="Mreads/s", cores=orc.threads(), kind="port",
-                            sample=f"first {n_sample} reads of the same stream vs the full {len(ls)}-guide library, "
-                                   f"{dt:.1f} s, oracle/oracle.c brute force")
+                            sample=f"first {n_sample} reads of the same stream vs the full {la.shape[0]}-guide library, "
+                                   f"{dt:.2f} s, oracle/oracle.c pigeonhole-indexed search (strings, OpenMP)",
+                            brute_force_value=nb / bdt / 1e6, brute_force_sample=nb,
+                            indexed_equals_brute_force_on_prefix=bool(same))
 
 
 def main():
@@ -175,8 +200,10 @@ def main():
                 pass
         if world == 1 and not args.no_cpu:
             ref, sample_reads, cb = cpu_baseline(lib_packed, args.cpu_sample, seed, args.max_mismatch)
-            got = best_idx[:len(sample_reads)].cpu().numpy()
-            cb["parity_on_sample"] = bool(np.array_equal(got, ref["best_idx"]))
+            m_ = len(sample_reads)
+            cb["parity_on_sample"] = bool(np.array_equal(best_idx[:m_].cpu().numpy(), ref["best_idx"]) and
+                                          np.array_equal(best_dist[:m_].cpu().numpy(), ref["best_dist"]) and
+                                          np.array_equal(n_best[:m_].cpu().numpy(), ref["n_best"]))
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -5,8 +5,10 @@ leg may import this module; the product package ``barcoder_amd`` never does.
 
 Two layers:
 
-* ``liboracle.so`` (``oracle.c``): string-based brute-force C restatement, used
-  for sizes up to ~1e5 reads x 1e5 guides and as the timed CPU baseline.
+* ``liboracle.so`` (``oracle.c``): string-based C restatement — the brute-force
+  sweep that defines the results (sizes up to ~1e5 reads x 1e5 guides) and a
+  pigeonhole-indexed search with the same outputs (tests hold the two against
+  each other) for read-by-read checks at 1e8 reads and as the timed CPU baseline.
 * pure-Python restatements of the reference's per-read / per-position
   semantics for small cases, each citing the reference lines it follows.
 
@@ -43,6 +45,7 @@ def lib():
     if _LIB is None:
         L = C.CDLL(build())
         L.orc_best_hit.restype = None
+        L.orc_best_hit_indexed.restype = None
         L.orc_all_hits.restype = C.c_uint64
         L.orc_process_chunk_single.restype = None
         L.orc_pam_scan.restype = None
@@ -95,6 +98,27 @@ def best_hit(lib_seqs, read_seqs, max_mm: int, skip=None, base: int = 0):
     lib().orc_best_hit(_p(la, C.c_char), C.c_uint32(G), C.c_int(k), _p(ra, C.c_char), _p(sk, C.c_uint8),
                        C.c_uint64(n), C.c_int(max_mm), _p(bi, C.c_int32), _p(bd, C.c_uint8),
                        _p(nb, C.c_uint8), _p(counts, C.c_uint64), _p(fs, C.c_uint64), C.c_uint64(base))
+    return dict(best_idx=bi, best_dist=bd, n_best=nb, counts=counts, first_seen=fs)
+
+
+def best_hit_arrays(la, ra, max_mm: int, skip=None, base: int = 0, indexed: bool = True):
+    """Best hit on ASCII byte arrays ((G, k) and (n, k) uint8): the brute-force sweep (indexed=False, oracle.c
+    orc_best_hit) or the pigeonhole-indexed search with the same definition (orc_best_hit_indexed, ~1000x faster;
+    tests/test_oracle_golden.py holds the two against each other)."""
+    la = np.ascontiguousarray(la, np.uint8)
+    ra = np.ascontiguousarray(ra, np.uint8)
+    G, k = la.shape
+    n = ra.shape[0]
+    bi = np.empty(n, np.int32)
+    bd = np.empty(n, np.uint8)
+    nb = np.empty(n, np.uint8)
+    counts = np.zeros(G, np.uint64)
+    fs = np.full(G, np.iinfo(np.uint64).max, np.uint64)
+    sk = None if skip is None else np.ascontiguousarray(skip, np.uint8)
+    fn = lib().orc_best_hit_indexed if indexed else lib().orc_best_hit
+    fn(_p(la, C.c_char), C.c_uint32(G), C.c_int(k), _p(ra, C.c_char), _p(sk, C.c_uint8), C.c_uint64(n),
+       C.c_int(max_mm), _p(bi, C.c_int32), _p(bd, C.c_uint8), _p(nb, C.c_uint8), _p(counts, C.c_uint64),
+       _p(fs, C.c_uint64), C.c_uint64(base))
     return dict(best_idx=bi, best_dist=bd, n_best=nb, counts=counts, first_seen=fs)
 
 

@@ -1,6 +1,8 @@
-"""GPU, BASELINE full sizes (1e5 guides, 1e8 reads): the oracle cannot run here, so
-results are checked through size-independent properties computed independently
-with torch on the device, plus agreement between algorithms."""
+"""GPU, BASELINE full sizes (1e5 guides, 1e8 reads): the brute-force oracle cannot run
+here, so results are checked through size-independent properties computed
+independently with torch on the device, by agreement between algorithms, and read
+by read against the pigeonhole-indexed oracle (itself held against the brute-force
+one in tests/test_oracle_golden.py) on all 1e8 reads."""
 import numpy as np
 import pytest
 
@@ -85,3 +87,34 @@ def test_algorithms_agree_at_full_size(full_run):
     e = out[("hash", 0)]
     z = a[1] == 0
     assert bool((z == (e[0] >= 0)).all()) and bool((a[0][z] == e[0][z]).all())
+
+
+def test_against_indexed_oracle_at_scale(full_run, oracle):
+    """ALL 1e8 reads of the run, every per-read output array, d <= 2 and d = 0, against oracle.c's indexed search
+    on strings (2e7 reads at a time; ~1 s of 128 host threads each)."""
+    dev, lib, reads, out = full_run
+    import torch
+    from barcoder_amd import synth as S
+
+    def ascii_of(packed):
+        p = np.ascontiguousarray(packed).view(np.uint64)
+        sh = np.arange(K, dtype=np.uint64)
+        res = np.empty((p.size, K), np.uint8)
+        letters = np.frombuffer(b"ACGT", np.uint8)
+        for a in range(0, p.size, 1 << 20):
+            q = p[a:a + (1 << 20), None]
+            lo = ((q >> sh) & np.uint64(1)).astype(np.uint8)
+            hi = ((q >> (sh + np.uint64(32))) & np.uint64(1)).astype(np.uint8)
+            res[a:a + q.shape[0]] = letters[lo | (hi << 1)]
+        return res
+
+    la = ascii_of(S.library(G, K))
+    n_check = N_READS if oracle.threads() >= 64 else 40_000_000  # keep the run in minutes on a small host share
+    for a, m_ in [(a_, min(20_000_000, n_check - a_)) for a_ in range(0, n_check, 20_000_000)]:
+        ra = ascii_of(reads[a:a + m_].cpu().numpy())
+        for key in (("seed", 2), ("hash", 0)):
+            bi, bd, nb, cnt, fs = out[key]
+            ref = oracle.best_hit_arrays(la, ra, key[1], indexed=True)
+            np.testing.assert_array_equal(bi[a:a + m_].cpu().numpy(), ref["best_idx"])
+            np.testing.assert_array_equal(bd[a:a + m_].cpu().numpy(), ref["best_dist"])
+            np.testing.assert_array_equal(nb[a:a + m_].cpu().numpy(), ref["n_best"])

@@ -79,6 +79,37 @@ def test_best_hit_c_vs_py_and_exact_lookup(oracle, chunks):
     assert mine == doc
 
 
+@pytest.mark.parametrize("k,G,cluster", [(20, 3000, 0), (20, 300, 8), (6, 1500, 0), (13, 800, 4), (32, 500, 3)])
+def test_indexed_oracle_equals_brute_force(oracle, k, G, cluster):
+    """orc_best_hit_indexed (pigeonhole index over string segments) returns exactly what the brute-force sweep
+    returns — index, distance, tie count, counts, first-seen — on isolated, clustered and dense libraries, with
+    skipped reads, for 0..3 substitutions.  It is the checker for million-read GPU comparisons."""
+    rng = np.random.default_rng(k * 1000 + G + cluster)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    codes = rng.integers(0, 4, size=(G, k))
+    if cluster:
+        fam = np.repeat(codes[: G // cluster], cluster, axis=0)
+        for i in range(fam.shape[0]):
+            pos = rng.choice(k, size=rng.integers(0, 3), replace=False)
+            fam[i, pos] = (fam[i, pos] + rng.integers(1, 4, size=pos.size)) % 4
+        codes = fam
+    codes = np.unique(codes, axis=0)
+    codes = codes[rng.permutation(codes.shape[0])]
+    n = 4000
+    rd = codes[rng.integers(0, codes.shape[0], size=n)].copy()
+    for i in range(n):
+        pos = rng.choice(k, size=rng.choice([0, 1, 2, 3, 4], p=[0.35, 0.25, 0.2, 0.1, 0.1]), replace=False)
+        rd[i, pos] = (rd[i, pos] + rng.integers(1, 4, size=pos.size)) % 4
+    la, ra = letters[codes], letters[rd]
+    skip = (rng.random(n) < 0.03).astype(np.uint8)
+    for d in (0, 1, 2, 3):
+        a = oracle.best_hit_arrays(la, ra, d, skip=skip, base=9, indexed=False)
+        b = oracle.best_hit_arrays(la, ra, d, skip=skip, base=9, indexed=True)
+        for key in ("best_idx", "best_dist", "n_best", "counts", "first_seen"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"{key} d={d}")
+    assert (a["n_best"] > 1).any() or cluster == 0
+
+
 def test_guidefinder_py_matches_reference(oracle):
     gold = _load("pam_guidefinder.json.gz")
     from barcoder_amd.library import read_fasta_records
