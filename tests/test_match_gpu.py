@@ -129,6 +129,29 @@ def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, monkeypatch):
         assert (ref["n_best"] > 1).sum() > 50
 
 
+@pytest.mark.parametrize("k,G", [(12, 5000), (16, 20000), (18, 60000), (20, 20000), (20, 150000), (22, 60000)])
+def test_wave_kernel_geometries_at_scale(gpu_device, oracle, k, G):
+    """Default d = 1, 2 path over k-mer lengths and library sizes (different seed / rest widths, bucket loads from
+    1 to 16 per slab, neighbour densities from none to dense), 300 k reads each, every per-read output against the
+    indexed oracle; counts and first-seen against numpy."""
+    lib = S.library(G, k, seed=S.LIB_SEED + 7 * k + G)
+    n = 300_007
+    reads = S.reads(lib, k, 11 + k, 0, n, 1)
+    sh = np.arange(k, dtype=np.uint64)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+
+    def ascii_of(p):
+        q = np.ascontiguousarray(p, np.uint64)[:, None]
+        return letters[((q >> sh) & np.uint64(1)).astype(np.uint8) | (((q >> (sh + np.uint64(32))) & np.uint64(1)).astype(np.uint8) << 1)]
+
+    la, ra = ascii_of(lib), ascii_of(reads & E.kmer_mask(k))
+    dl = DeviceLibrary(lib, k, gpu_device)
+    for d in (1, 2):
+        res = GpuMatcher(dl).match(reads, None, max_mismatch=d, algo="seed", first_index=0)
+        ref = oracle.best_hit_arrays(la, ra, d, indexed=True)
+        _check(res, ref)
+
+
 def test_tally_hot_guides(gpu_device):
     """Per-guide counts in the millions through the LDS histogram (k_hist), first-seen intact."""
     k, G, n = 20, 300, 3_000_003
