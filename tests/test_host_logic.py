@@ -307,3 +307,45 @@ def test_c_abi_error_mapping():
     assert E.unpack_kmers(packed_r[:1], 4) == ["ACGT"]  # ACGT is its own reverse complement
     text, off = E.reads_to_text(["TTAAGTGG"])
     assert E.unpack_kmers(E.pack_windows(text, off, 0, "TT", "GG", 4, reverse=True)[0], 4) == ["ACTT"]
+
+
+def test_design_filters():
+    """design_guides.py:108-310 on a hand-made table: every filter, the NaN rules of the pandas round trip
+    (None == x False, None != x True, groupby drops None, sort puts None last, numeric None -> 0)."""
+    from barcoder_amd import design as D
+    cols = ["spacer", "locus_tag", "gene", "chr", "mismatches", "target", "tar_start", "tar_end", "offset", "overlap",
+            "sp_dir", "tar_dir", "note"]
+
+    def row(sp, tag, chr_, a, off, ov, sd, td, note, mm=0, target="acgt"):
+        return dict(spacer=sp, locus_tag=tag, gene=tag and tag.lower(), chr=chr_, mismatches=mm, target=target,
+                    tar_start=a, tar_end=None if a is None else a + 4, offset=off, overlap=ov, sp_dir=sd, tar_dir=td,
+                    note=note)
+    rows = [
+        row("AAAA", "G1", "c1", 10, 0, 4, "F", "F", "1 site, 1 gene"),
+        row("CCCC", "G1", "c1", 14, 4, 4, "R", "F", "1 site, 1 gene"),
+        row("GGGG", "G1", "c1", 18, 8, 3, "F", "F", "2 sites, 1 gene, 1 intergenic"),
+        row("GGGG", None, "c1", 90, None, None, "F", None, "2 sites, 1 gene, 1 intergenic"),
+        row("TTTT", "G2", "c2", 5, 2, 4, "F", "F", "1 site, 2 genes"),
+        row("TTTT", "G3", "c2", 5, 30, 4, "F", "R", "1 site, 2 genes"),
+        row("ACAC", "G2", "c2", 25, 22, 4, "F", "F", "1 site, 1 gene", mm=1),
+        row("NONE", None, None, None, None, None, None, None, "0 sites", target=None),
+    ]
+    sp = lambda out: [r["spacer"] for r in out[1]]
+    base = D.filter_guides(cols, rows, 4)
+    assert base[1][0]["target"] == "ACGT"                                   # upper-cased (:110)
+    assert sp(base) == ["AAAA", "CCCC", "GGGG", "GGGG", "TTTT", "TTTT", "ACAC", "NONE"]  # chr, tar_start, ..., None last
+    assert base[1][3]["offset"] == 0 and base[1][3]["locus_tag"] is None     # numeric None -> 0, strings stay None
+    assert base[1][7]["tar_start"] == 0 and base[1][7]["chr"] is None
+    assert sp(D.filter_guides(cols, rows, 4, orientation="forward")) == ["AAAA", "GGGG", "TTTT", "ACAC"]
+    assert sp(D.filter_guides(cols, rows, 4, orientation="reverse")) == ["CCCC", "GGGG", "TTTT", "NONE"]
+    assert sp(D.filter_guides(cols, rows, 4, omit_offtargets=True)) == ["AAAA", "CCCC", "TTTT", "TTTT", "ACAC"]
+    assert sp(D.filter_guides(cols, rows, 4, mismatches=1)) == ["AAAA", "CCCC", "GGGG", "GGGG", "TTTT", "TTTT", "NONE"]
+    assert sp(D.filter_guides(cols, rows, 4, omit_ambiguous=True)) == ["AAAA", "CCCC", "ACAC"]
+    assert sp(D.filter_guides(cols, rows, 4, omit_intergenic=True)) == ["AAAA", "CCCC", "TTTT", "TTTT", "ACAC", "NONE"]
+    assert sp(D.filter_guides(cols, rows, 4, full_overlap=True)) == ["AAAA", "CCCC", "TTTT", "TTTT", "ACAC"]
+    # tiles of 8 along each gene: G1 offsets 0,4,8 -> 0 and 8; G2 offsets 2,22 -> both; G3 -> 30
+    assert sp(D.filter_guides(cols, rows, 4, tile_size=8)) == ["AAAA", "GGGG", "GGGG", "TTTT", "TTTT", "ACAC"]
+    # with full overlap the walk starts at the first fully overlapping guide and GGGG (overlap 3) is gone already
+    assert sp(D.filter_guides(cols, rows, 4, full_overlap=True, tile_size=8)) == ["AAAA", "TTTT", "TTTT", "ACAC"]
+    assert sp(D.filter_guides(cols, rows, 4, keep_top=1)) == ["AAAA", "TTTT", "TTTT"]
+    assert sp(D.filter_guides(cols, rows, 4, keep_top=2)) == ["AAAA", "CCCC", "TTTT", "TTTT", "ACAC"]

@@ -154,7 +154,8 @@ def test_annotated_table_matches_shipped_tsv(gpu_device, plasmids):
     # the shipped library went through design_guides.py --orientation forward (design_guides.py:113-115):
     # rows whose spacer and gene strands differ were dropped there
     assert sum(r["sp_dir"] != r["tar_dir"] for r in table) == 3
-    table = [r for r in table if r["sp_dir"] == r["tar_dir"]]
+    from barcoder_amd import design as D
+    cols, table = D.filter_guides(cols, table, 32, orientation="forward")
     got = Counter(tuple(str(r[c]) for c in common) for r in table)
     want = Counter(tuple(r[c] for c in common) for r in gold)
     assert got == want and sum(got.values()) == 772
@@ -209,3 +210,40 @@ def test_crispri_library_on_gpu_hits(gpu_device, plasmids):
     assert list(lib.unique_targets.sort_values(["Chromosome", "Start", "End"]).index) == list(lib.unique_targets.index)
     assert not lib.unambiguous_targets.duplicated(subset=["Barcode"]).any()
     assert len(lib.unambiguous_targets) <= len(lib.unique_targets) <= len(mt)
+
+
+def test_design_guides_pipeline(gpu_device, plasmids, oracle):
+    """design_guides.main on the GPU path (sliding PAM scan -> hits -> annotation -> filters) on the two smallest
+    plasmids: the spacer universe is the oracle's sliding-scan set, every row obeys the filters asked for, and the
+    tiling walk leaves guides at least `tile_size` apart along each gene."""
+    from barcoder_amd import design as D, targets as T
+    small = sorted(plasmids, key=lambda c: len(c.seq))[:2]
+    genes = [g for g in T.read_genes_tsv(os.path.join(GOLDEN, "plasmid_genes.tsv"), {c.name: len(c.seq) for c in plasmids})
+             if g.chrom in {c.name for c in small}]
+    cols, full = D.design_guides(small, genes, "NGG", 20, device=gpu_device)
+    want = set()
+    for c in small:
+        topo = c.seq + (c.seq[:100_000] if c.circular else "")
+        want |= set(oracle.sliding_sites_py(topo, 20, "NGG", "downstream"))
+    assert {r["spacer"] for r in full} == want and len(want) > 1000
+    cols, rows = D.design_guides(small, genes, "NGG", 20, device=gpu_device, orientation="forward", omit_offtargets=True,
+                                 omit_intergenic=True, full_overlap=True, tile_size=50)
+    assert rows and all(r["sp_dir"] == r["tar_dir"] and "intergenic" not in r["note"] for r in rows)
+    assert all(r["note"].startswith("1 site") for r in rows)
+    # the tiling walk: a subset of the untiled result that keeps every gene's first guide; a guide chosen along one
+    # gene stays in the table for every gene it overlaps, so spacing is only guaranteed along the gene that chose it
+    _, untiled = D.design_guides(small, genes, "NGG", 20, device=gpu_device, orientation="forward", omit_offtargets=True,
+                                 omit_intergenic=True, full_overlap=True)
+    key = lambda r: (r["spacer"], r["locus_tag"], r["tar_start"])
+    assert {key(r) for r in rows} < {key(r) for r in untiled}
+    first = {}
+    for r in untiled:  # with full_overlap the walk starts at a gene's first fully overlapping guide (:246-255)
+        if r["overlap"] == 20:
+            first[r["locus_tag"]] = min(first.get(r["locus_tag"], 1 << 30), r["offset"])
+    got_first = {}
+    for r in rows:
+        if r["overlap"] == 20:
+            got_first[r["locus_tag"]] = min(got_first.get(r["locus_tag"], 1 << 30), r["offset"])
+    assert got_first == first
+    assert len(rows) < len(untiled) // 2 and len(untiled) < len(full)
+    assert T.to_tsv(cols, rows).startswith("spacer\tlocus_tag\tgene\tchr")
