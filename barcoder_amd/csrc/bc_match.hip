@@ -984,32 +984,27 @@ __device__ __forceinline__ uint4 load16(const char* base, uint32_t off) {
 }
 
 // request the slabs of the quad's four reads, NQ quarters per lane and read (1: 64-byte slabs, 2: 128, 4: 256).
-// off = byte offset of the slab wanted by the read this lane owns (FROM3: by read j, held in lane 3 as off4[j]);
-// NOSLAB = none: the load is skipped (every vector-L1 access counts) and w[j] keeps what it held; v[j] says
-// whether read j's slab was requested.
-constexpr uint32_t NOSLAB = 0xFFFFFFFFu;
-template <int NQ, bool FROM3, bool COND>
+// off = byte offset of the slab wanted by the read this lane owns (FROM3: by read j, held in lane 3 as off4[j]).
+// A read that wants nothing is pointed at its table's all-empty slab: skipping the load instead (exec-masked
+// branches per read, results masked afterwards) measured 6 % slower once the kernel had become VALU-bound.
+template <int NQ, bool FROM3>
 __device__ __forceinline__ void visit_issue(const char* base, uint32_t off, const uint32_t (&off4)[4], int s,
-                                            uint4 (&w)[4][NQ], bool (&v)[4]) {
+                                            uint4 (&w)[4][NQ]) {
     auto one = [&](auto jt) {
         constexpr int j = decltype(jt)::value;
         const uint32_t oj = FROM3 ? quad_bcast<3>(off4[j]) : quad_bcast<j>(off);
-        v[j] = !COND || oj != NOSLAB;
-        if (v[j]) {
 #pragma unroll
-            for (int h = 0; h < NQ; ++h) w[j][h] = load16(base, oj + (uint32_t)(s + 4 * h) * 16u);
-        }
+        for (int h = 0; h < NQ; ++h) w[j][h] = load16(base, oj + (uint32_t)(s + 4 * h) * 16u);
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
 }
 
 // scan them: kmin = min(kmin, best key of the read this lane owns); l[j] = last slot's first word of read j's
-// slab as seen by this lane — in lane 3 that is the overflow link (0 = none: the slot is link-or-empty).
-// A slab that was not requested contributes nothing (its registers hold stale data).
-template <int NQ, bool COND>
-__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], const bool (&v)[4], uint32_t rest, uint32_t half,
-                                           uint32_t hmask, int s, uint32_t& kmin, uint32_t (&l)[4]) {
+// slab as seen by this lane — in lane 3 that is the overflow link (0 = none: the slot is link-or-empty)
+template <int NQ>
+__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], uint32_t rest, uint32_t half, uint32_t hmask, int s,
+                                           uint32_t& kmin, uint32_t (&l)[4]) {
     uint32_t a[4];
     auto one = [&](auto jt) {
         constexpr int j = decltype(jt)::value;
@@ -1022,8 +1017,8 @@ __device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], const bool (
             const uint32_t d1 = __popc((x1 & hmask) | (x1 >> half));
             m = min(m, min((d0 << 24) | w[j][h].y, (d1 << 24) | w[j][h].w));
         }
-        a[j] = (!COND || v[j]) ? m : 0xFFFFFFFFu;
-        l[j] = (!COND || v[j]) ? w[j][NQ - 1].z : 0u;
+        a[j] = m;
+        l[j] = w[j][NQ - 1].z;
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
@@ -1083,7 +1078,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     const char* const b2 = reinterpret_cast<const char*>(T2.slabs);
     const uint32_t lane = threadIdx.x;
     const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
-    const uint32_t empty1 = T1.empty << 6, empty2 = T2.empty << (T2.log2S + 3u);  // what idle lanes fetch
+    const uint32_t empty0 = T0.empty << 6, empty1 = T1.empty << 6, empty2 = T2.empty << (T2.log2S + 3u);  // what idle lanes fetch
     const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
     const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u, sh2 = T2.log2S + 3u;
     const int s = (int)(lane & 3u);
@@ -1144,9 +1139,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         }
         // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
         auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << 6) : 0u; };
-        auto finish = [&](int j, const uint4 (&w)[4][1], const bool (&v)[4]) {
+        auto finish = [&](int j, const uint4 (&w)[4][1]) {
             uint32_t l[4], key = 0xFFFFFFFFu;
-            visit_scan<1, false>(w, v, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key, l);
+            visit_scan<1>(w, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key, l);
             const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
             const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner needs its link for the list
             // final already: the guide itself (d = 0), or a guide within max_mm whose isolation flag rules out any
@@ -1162,20 +1157,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             if (push) {
                 q_read[at[j]] = r[j];
                 q_key[at[j]] = key;
-                q_off[at[j]] = lnk ? (lnk << 6) : NOSLAB;
+                q_off[at[j]] = lnk ? (lnk << 6) : empty0;
             }
             qn += (uint32_t)__popcll(m);
         };
         uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
-        bool va[4], vb[4];
-        visit_issue<1, false, false>(b0, off0(0), none4, s, wa, va);
-        visit_issue<1, false, false>(b0, off0(1), none4, s, wb, vb);
-        finish(0, wa, va);
-        visit_issue<1, false, false>(b0, off0(2), none4, s, wa, va);
-        finish(1, wb, vb);
-        visit_issue<1, false, false>(b0, off0(3), none4, s, wb, vb);
-        finish(2, wa, va);
-        finish(3, wb, vb);
+        visit_issue<1, false>(b0, off0(0), none4, s, wa);
+        visit_issue<1, false>(b0, off0(1), none4, s, wb);
+        finish(0, wa);
+        visit_issue<1, false>(b0, off0(2), none4, s, wa);
+        finish(1, wb);
+        visit_issue<1, false>(b0, off0(3), none4, s, wb);
+        finish(2, wa);
+        finish(3, wb);
     }
     wave_lds_sync();
     phase_mark(0);
@@ -1184,7 +1178,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     for (uint32_t qb = 0; qb < qn; qb += 64) {
         const uint32_t qi = qb + lane;
         const bool mine = qi < qn;
-        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, rest0 = 0, rest1 = 0, off0 = NOSLAB, off1 = empty1;
+        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, rest0 = 0, rest1 = 0, off0 = empty0, off1 = empty1;
         if (mine) {
             const uint64_t r = q_read[qi];
             rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
@@ -1194,28 +1188,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             off1 = seed_value(rlo, rhi, T1.start, T1.slen) << 6;
         }
         uint4 wa[4][1], wb[4][1];
-        bool va[4], vb[4];
         uint32_t l0[4] = {0u, 0u, 0u, 0u}, l1[4];
-        bool any0 = __ballot(off0 != NOSLAB) != 0ull;
-        visit_issue<1, false, false>(b1, off1, none4, s, wa, va);
-        if (any0) visit_issue<1, false, true>(b0, off0, none4, s, wb, vb);
-        visit_scan<1, false>(wa, va, rest1, half1, hm1, s, kmin, l1);
-        if (any0) visit_scan<1, true>(wb, vb, rest0, half0, hm0, s, kmin, l0);
+        bool any0 = __ballot(off0 != empty0) != 0ull;
+        visit_issue<1, false>(b1, off1, none4, s, wa);
+        if (any0) visit_issue<1, false>(b0, off0, none4, s, wb);
+        visit_scan<1>(wa, rest1, half1, hm1, s, kmin, l1);
+        if (any0) visit_scan<1>(wb, rest0, half0, hm0, s, kmin, l0);
         for (;;) {  // further overflow slabs, straight from lane 3 (one table at a time: registers)
             any0 = __ballot(s == 3 && (l0[0] | l0[1] | l0[2] | l0[3]) != 0u) != 0ull;
             const bool any1 = __ballot(s == 3 && (l1[0] | l1[1] | l1[2] | l1[3]) != 0u) != 0ull;
             if (!any0 && !any1) break;
             if (any0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) l0[j] = l0[j] ? (l0[j] << 6) : NOSLAB;
-                visit_issue<1, true, true>(b0, 0u, l0, s, wa, va);
-                visit_scan<1, true>(wa, va, rest0, half0, hm0, s, kmin, l0);
+                for (int j = 0; j < 4; ++j) l0[j] = l0[j] ? (l0[j] << 6) : empty0;
+                visit_issue<1, true>(b0, 0u, l0, s, wa);
+                visit_scan<1>(wa, rest0, half0, hm0, s, kmin, l0);
             }
             if (any1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) l1[j] = l1[j] ? (l1[j] << 6) : NOSLAB;
-                visit_issue<1, true, true>(b1, 0u, l1, s, wa, va);
-                visit_scan<1, true>(wa, va, rest1, half1, hm1, s, kmin, l1);
+                for (int j = 0; j < 4; ++j) l1[j] = l1[j] ? (l1[j] << 6) : empty1;
+                visit_issue<1, true>(b1, 0u, l1, s, wa);
+                visit_scan<1>(wa, rest1, half1, hm1, s, kmin, l1);
             }
         }
         // seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1 (NSEG = 3) /
@@ -1245,15 +1238,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
                 off = seed_value(rlo, rhi, T2.start, T2.slen) << sh2;
             }
             uint4 w[4][NQ2];
-            bool v[4];
             uint32_t l[4];
-            visit_issue<NQ2, false, false>(b2, off, none4, s, w, v);
-            visit_scan<NQ2, false>(w, v, rest, half2, hm2, s, kmin, l);
+            visit_issue<NQ2, false>(b2, off, none4, s, w);
+            visit_scan<NQ2>(w, rest, half2, hm2, s, kmin, l);
             while (__ballot(s == 3 && (l[0] | l[1] | l[2] | l[3]) != 0u) != 0ull) {  // overflow slabs, from lane 3
 #pragma unroll
-                for (int j = 0; j < 4; ++j) l[j] = l[j] ? (l[j] << sh2) : NOSLAB;
-                visit_issue<NQ2, true, true>(b2, 0u, l, s, w, v);
-                visit_scan<NQ2, true>(w, v, rest, half2, hm2, s, kmin, l);
+                for (int j = 0; j < 4; ++j) l[j] = l[j] ? (l[j] << sh2) : empty2;
+                visit_issue<NQ2, true>(b2, 0u, l, s, w);
+                visit_scan<NQ2>(w, rest, half2, hm2, s, kmin, l);
             }
             // every guide within max_mm of these reads has segments 0 and 1 dirty, hence a clean segment 2: all seen
             decide(mine, true, qi, kmin, rlo, rhi);
