@@ -931,8 +931,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
 //   one lane per read, slabs fetched as 4 x 16 B by the lane: VALU 47 %, but
 //     four vector-L1 accesses per slab and ~25 dependent memory round trips per
 //     workgroup tile held together by barriers: 1.95 ms.
-// This kernel (1.30 ms; 2.1 L2 requests per read at 160 G requests/s — the stream +
-// gather microbenchmark reaches 142-184 G/s with a table this size — and VALU 93 %):
+// This kernel (1.22 ms; 2.1 L2 requests per read at 170 G requests/s — the stream +
+// gather microbenchmark reaches 142-184 G/s with a table this size — and VALU 90 %):
 //   * no hash table: a guide equal to the read sits in the read's seed-0 bucket, so
 //     table 0 doubles as the exact-match table; 3.7 MB of slabs, 93 % L2 hits;
 //   * a wave works alone (64-thread workgroups) on 256 consecutive reads and keeps
@@ -942,8 +942,8 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
 //     taking quarter s — one L1 access per slab; lane s scans its quarter for all
 //     four reads (rest of read j by DPP broadcast; xor, shift, and-or, popcount,
 //     shift-or, min per entry) and a transposed DPP min-reduction hands every
-//     owner its minimum; overflow links are followed straight from lane 3, and
-//     only the quads that have one issue the load (every L1 access counts);
+//     owner its minimum; overflow links are followed straight from lane 3 (a read
+//     without one is pointed at its table's all-empty slab: no branches, no masks);
 //   * stages run on compacted lists: reads without an exact hit (table 1 + overflow
 //     slabs, then the decision), then the ones that still need table 2;
 //   * n_best = 1 is proven by the best guide's isolation flags; otherwise the
@@ -952,9 +952,9 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
 //   * results are staged in the list entries and leave as full-width coalesced
 //     stores by the lane that owns the read: nothing is patched afterwards.
 // Tried and dropped (slower): persistent waves draining the lists
-// across tiles (fewer VALU, worse memory behaviour), unconditional loads from an
-// all-empty slab (fewer VALU, 60 % more L1 accesses), direct scattered result
-// stores over placeholders (0.5 ms of partial-line writes).
+// across tiles (fewer VALU, worse memory behaviour), skipping the loads nobody
+// needs (fewer L1 accesses, 13 % more VALU: 6 % slower now that VALU is the wall),
+// direct scattered result stores over placeholders (0.5 ms of partial-line writes).
 // ---------------------------------------------------------------------------
 constexpr int WAVE_T = 256;  // reads per wave (4 per lane)
 
