@@ -1339,19 +1339,25 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist(const int32_t* __restrict__
     const uint64_t n4 = n / 4;
     const uint64_t per = (n4 + slices - 1) / slices;
     const uint64_t a = (uint64_t)slice * per, e = min(n4, a + per);
-    const int4* p4 = reinterpret_cast<const int4*>(best_idx);
-    for (uint64_t q = a + threadIdx.x; q < e; q += HIST_BLOCK) {
-        int4 v = p4[q];
-        const int32_t vv[4] = {v.x, v.y, v.z, v.w};
+    const u32x4* pv = reinterpret_cast<const u32x4*>(best_idx);
+    auto take = [&](const u32x4& v, uint64_t q) {
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            uint32_t g = (uint32_t)vv[c] - lo;  // negative sentinels wrap far above width
+            uint32_t g = vv[c] - lo;  // negative sentinels wrap far above width
             if (g < width) {
                 atomicAdd(&cnt[g], 1u);
                 if (first_seen) atomicMin(&fs[g], (uint32_t)(q * 4 + c));
             }
         }
+    };
+    uint64_t q = a + threadIdx.x;
+    for (; q + HIST_BLOCK < e; q += 2 * HIST_BLOCK) {  // two loads in flight
+        const u32x4 v0 = __builtin_nontemporal_load(pv + q), v1 = __builtin_nontemporal_load(pv + q + HIST_BLOCK);
+        take(v0, q);
+        take(v1, q + HIST_BLOCK);
     }
+    if (q < e) take(__builtin_nontemporal_load(pv + q), q);
     if (slice == slices - 1)  // tail reads (n % 4)
         for (uint64_t i = n4 * 4 + threadIdx.x; i < n; i += HIST_BLOCK) {
             uint32_t g = (uint32_t)best_idx[i] - lo;
