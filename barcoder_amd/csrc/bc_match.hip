@@ -1352,12 +1352,15 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist(const int32_t* __restrict__
         }
     };
     uint64_t q = a + threadIdx.x;
-    for (; q + HIST_BLOCK < e; q += 2 * HIST_BLOCK) {  // two loads in flight
+    for (; q + 3 * HIST_BLOCK < e; q += 4 * HIST_BLOCK) {  // four loads in flight
         const u32x4 v0 = __builtin_nontemporal_load(pv + q), v1 = __builtin_nontemporal_load(pv + q + HIST_BLOCK);
+        const u32x4 v2 = __builtin_nontemporal_load(pv + q + 2 * HIST_BLOCK), v3 = __builtin_nontemporal_load(pv + q + 3 * HIST_BLOCK);
         take(v0, q);
         take(v1, q + HIST_BLOCK);
+        take(v2, q + 2 * HIST_BLOCK);
+        take(v3, q + 3 * HIST_BLOCK);
     }
-    if (q < e) take(__builtin_nontemporal_load(pv + q), q);
+    for (; q < e; q += HIST_BLOCK) take(__builtin_nontemporal_load(pv + q), q);
     if (slice == slices - 1)  // tail reads (n % 4)
         for (uint64_t i = n4 * 4 + threadIdx.x; i < n; i += HIST_BLOCK) {
             uint32_t g = (uint32_t)best_idx[i] - lo;
