@@ -48,6 +48,8 @@ SIGNATURES = {
     "bc_pack_windows": (C.c_int, [vp, vp, C.c_size_t, C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, vp, vp]),
     "bc_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "bc_reader_open_range": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "bc_reader_tell": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "bc_reader_next": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]),
     "bc_reader_close": (C.c_int, [vp]),
     "bc_sample_data": (C.c_int, [C.c_char_p, C.c_char_p, vp, C.c_uint32, C.c_int, C.POINTER(vp)]),
@@ -60,6 +62,11 @@ SIGNATURES = {
     "bc_lib_create": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]),
     "bc_lib_destroy": (C.c_int, [vp]),
     "bc_lib_info": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bc_lib_last_kernel": (C.c_char_p, [vp]),
+    "bc_multi_create": (C.c_int, [vp, C.c_uint32, C.c_int, vp, C.c_int, C.POINTER(vp)]),
+    "bc_multi_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bc_multi_gpu_match": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint64]),
+    "bc_multi_destroy": (C.c_int, [vp]),
     "bc_match_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "bc_match_host": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint64]),
     "bc_match_all_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp]),

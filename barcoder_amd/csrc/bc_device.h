@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -80,6 +82,28 @@ struct SlabParams {
     const uint4* nbr;          // [lists][NBR_CAP]
 };
 
+// Tuning / experiment knobs, read from the environment ONCE when a library is created (never per launch).
+// Defaults are the measured best; the knob-coverage tests check that none of them changes a result.
+struct Knobs {
+    int lane = 1;         // BC_LANE=0: quad kernels (k_match_fused) instead of the wave kernel
+    int phase2_sm = 1;    // BC_PHASE2_SM=0: quad kernels without the state machine
+    int single_slab = 0;  // BC_SINGLE_SLAB=1: the one-kernel slab form (k_match_slab) for every d
+    int slab_lpr = 4;     // BC_SLAB_LPR=8: eight lanes per read in k_match_slab
+    int tally = 0;        // BC_TALLY: 0 auto, 1 global atomics, 2 k_hist sweeps, 3 range-partitioned records
+    int phase_prof = 0;   // BC_PHASE_PROF=1: per-stage cycle sums of the wave kernel on stderr
+    int host_pin = 1;     // BC_HOST_PIN=0: bc_match_host does not pin the caller's buffers
+};
+
+// scratch of the record tally (k_hist_part), one per stream that launches on a library
+struct TallyWs {
+    void* stream = nullptr;
+    uint16_t* rec = nullptr;       // [ranges][tiles_cap][64] records
+    uint32_t* ovf_list = nullptr;  // [tiles_cap]
+    uint32_t* ovf_count = nullptr; // self-resetting (k_first_refine)
+    uint32_t* first_tile = nullptr;  // [G], 0xFFFFFFFF between launches
+    uint64_t tiles_cap = 0;
+};
+
 }  // namespace bc
 
 struct bc_lib {
@@ -102,11 +126,10 @@ struct bc_lib {
     bc::SlabParams slab[bc::MAX_SEG] = {};
     bool slab_ok[bc::MAX_SEG] = {false, false, false, false};
     const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
-    // miss queue between the exact stage and the seed stage (grown on demand)
-    uint64_t* q_reads = nullptr;
-    uint32_t* q_idx = nullptr;
-    uint32_t* q_count = nullptr;       // [MAX_BLOCKS] entries appended per workgroup
-    uint64_t q_cap = 0;
+    bc::Knobs knobs;
+    std::deque<bc::TallyWs> ws;    // tally workspaces by stream (deque: pointers stay valid as it grows)
+    std::mutex ws_mutex;
+    std::atomic<const char*> last_kernel{""};  // name of the match kernel launched last (bc_lib_last_kernel)
     void* host_slots = nullptr;    // HostSlot[3]: staging of bc_match_host, kept between calls
     std::mutex host_mutex;
     std::vector<void*> owned;      // every device allocation, for destroy

@@ -60,28 +60,66 @@ struct bc_reader {
     std::vector<char> buf;  // decoded bytes not yet consumed
     size_t pos = 0, len = 0;
     bool eof = false;
+    bool failed = false;     // the decoder reported an error or the stream was cut off: never mistaken for EOF
+    std::string fail_msg;
+    size_t zst_last = 0;     // last ZSTD_decompressStream result: 0 = at a frame boundary
     uint64_t line_in_record = 0;
+    uint64_t abs0 = 0;       // offset of buf[0] in the decoded stream (= file offset for plain files)
+    uint64_t end = UINT64_MAX;  // bc_reader_open_range: records starting at or after this offset are not ours
 
+    // decoded bytes into dst; 0 = end of stream OR failure (then `failed` is set).  The reference's readers
+    // raise on a damaged stream (gzip: EOFError / BadGzipFile, zstandard: ZstdError) and main() prints no
+    // counts (heuristicount.py:882-888); a shortened read stream must never pass for a complete one.
     size_t fill(char* dst, size_t cap) {
-        if (comp == 0) return fread(dst, 1, cap, fp);
+        if (comp == 0) {
+            size_t n = fread(dst, 1, cap, fp);
+            if (n == 0 && ferror(fp)) { failed = true; fail_msg = "read error"; }
+            return n;
+        }
         if (comp == 1) {
             int n = gzread(gz, dst, (unsigned)cap);
-            return n > 0 ? (size_t)n : 0;
+            int errnum = Z_OK;
+            const char* msg = gzerror(gz, &errnum);
+            if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END)) {
+                failed = true;
+                fail_msg = std::string("gzip stream damaged or truncated (") + (msg && *msg ? msg : "zlib error") + ")";
+                return 0;
+            }
+            return (size_t)n;
         }
         size_t produced = 0;
         while (produced == 0) {
             if (zin_pos == zin_len) {
                 zin_len = fread(zin.data(), 1, zin.size(), fp);
                 zin_pos = 0;
-                if (zin_len == 0) return 0;
+                if (zin_len == 0) {
+                    if (ferror(fp)) { failed = true; fail_msg = "read error"; }
+                    else if (zst_last != 0) { failed = true; fail_msg = "zstd stream truncated (input ends inside a frame)"; }
+                    return 0;
+                }
             }
             ZBuf in{zin.data(), zin_len, zin_pos}, out{dst, cap, 0};
             size_t rc = g_zstd.decompressStream(zctx, &out, &in);
             zin_pos = in.pos;
-            if (g_zstd.isError(rc)) return 0;
+            if (g_zstd.isError(rc)) { failed = true; fail_msg = "zstd stream damaged"; return 0; }
+            zst_last = rc;
             produced = out.pos;
         }
         return produced;
+    }
+
+    // index of the '\n' that ends the line starting at `from` (>= pos), or len when the stream ends first;
+    // grows the buffer instead of moving it, so indices stay valid (used while synchronising on a record)
+    size_t line_end_nomove(size_t from) {
+        for (;;) {
+            const char* nl = from < len ? (const char*)memchr(buf.data() + from, '\n', len - from) : nullptr;
+            if (nl) return (size_t)(nl - buf.data());
+            if (eof) return len;
+            if (len == buf.size()) buf.resize(buf.size() * 2);
+            size_t got = fill(buf.data() + len, buf.size() - len);
+            if (got == 0) { eof = true; return len; }
+            len += got;
+        }
     }
 };
 
@@ -122,6 +160,67 @@ int bc_reader_open(const char* path, bc_reader** out) {
     return BC_OK;
 }
 
+// The records of an UNCOMPRESSED file that start in the byte range [begin, end): the shard of one rank when a
+// file is split over several GPUs (barcoder_amd/dist.py; the data-parallel fan-out of heuristicount.py:703-737
+// over independent chunks).  A .reads record starts after every newline; a FASTQ record start is a line that
+// begins with '@' whose third line begins with '+' (a quality line may begin with '@', a sequence line never
+// begins with '+').  Ranges that tile the file yield every record exactly once.
+int bc_reader_open_range(const char* path, uint64_t begin, uint64_t end, bc_reader** out) {
+    int rc = bc_reader_open(path, out);
+    if (rc != BC_OK) return rc;
+    bc_reader* r = *out;
+    if (r->comp != 0) {
+        bc_reader_close(r); *out = nullptr;
+        set_error("bc_reader_open_range: %s is compressed; byte ranges need a plain .fastq / .reads file", path);
+        return BC_EINVAL;
+    }
+    r->end = end;
+    if (begin == 0) return BC_OK;
+    if (fseeko(r->fp, (off_t)(begin - 1), SEEK_SET) != 0) {
+        bc_reader_close(r); *out = nullptr;
+        set_error("bc_reader_open_range: cannot seek in %s", path);
+        return BC_EINVAL;
+    }
+    r->abs0 = begin - 1;
+    // first line start at or after `begin`: one past the first newline at or after begin - 1
+    size_t e = r->line_end_nomove(0);
+    r->pos = e < r->len ? e + 1 : r->len;
+    if (r->kind == 1) {
+        // synchronise on a record header: '@' line whose third line starts with '+'.  When the file ends before
+        // that third line, a '@' line is taken as the header of a cut-off last record (its sequence line, if any,
+        // still counts: heuristicount.py:127-131).
+        for (;;) {
+            const size_t e0 = r->line_end_nomove(r->pos);   // end of the candidate line
+            if (r->pos >= r->len) break;                    // nothing left in this range
+            bool header = r->buf[r->pos] == '@';
+            if (header && e0 < r->len) {
+                const size_t e1 = r->line_end_nomove(e0 + 1);   // end of the would-be sequence line
+                if (e1 < r->len) {
+                    r->line_end_nomove(e1 + 1);                 // make the first byte of the third line available
+                    if (e1 + 1 < r->len) header = r->buf[e1 + 1] == '+';
+                }
+            }
+            if (header) break;
+            r->pos = e0 < r->len ? e0 + 1 : r->len;
+        }
+    }
+    if (r->failed) {
+        std::string m = r->fail_msg;
+        bc_reader_close(r); *out = nullptr;
+        set_error("%s: %s", path, m.c_str());
+        return BC_EINVAL;
+    }
+    return BC_OK;
+}
+
+// offset, in the decoded stream, of the next byte bc_reader_next will look at (plain files: the file offset).
+// Strictly increasing from chunk to chunk and by at least one per read: usable as a first-seen ordering key.
+int bc_reader_tell(const bc_reader* r, uint64_t* offset_out) {
+    if (!r || !offset_out) { set_error("bc_reader_tell: null argument"); return BC_EINVAL; }
+    *offset_out = r->abs0 + r->pos;
+    return BC_OK;
+}
+
 int bc_reader_close(bc_reader* r) {
     if (!r) return BC_OK;
     if (r->gz) gzclose(r->gz);
@@ -141,11 +240,13 @@ int bc_reader_next(bc_reader* r, uint64_t max_reads, char* text, uint64_t text_c
     off[0] = 0;
     const uint64_t per = r->kind ? 4 : 1, seq_line = r->kind ? 1 : 0;
     while (n < max_reads) {
+        if (r->line_in_record == 0 && r->abs0 + r->pos >= r->end) break;  // the next record belongs to another range
         const char* nl = (const char*)memchr(r->buf.data() + r->pos, '\n', r->len - r->pos);
         while (!nl && !r->eof) {  // pull more decoded bytes behind the unconsumed tail
             if (r->pos > 0) {
                 memmove(r->buf.data(), r->buf.data() + r->pos, r->len - r->pos);
                 r->len -= r->pos;
+                r->abs0 += r->pos;
                 r->pos = 0;
             }
             if (r->len == r->buf.size()) r->buf.resize(r->buf.size() * 2);  // one very long line
@@ -171,6 +272,11 @@ int bc_reader_next(bc_reader* r, uint64_t max_reads, char* text, uint64_t text_c
         }
         r->line_in_record = (r->line_in_record + 1) % per;
         r->pos += ll + (nl ? 1 : 0);
+    }
+    if (r->failed) {  // a damaged / truncated stream is an error, not a short file
+        *n_out = 0;
+        set_error("reads file: %s", r->fail_msg.c_str());
+        return BC_EINVAL;
     }
     *n_out = n;
     return BC_OK;

@@ -20,12 +20,14 @@
 //   k_hist         : per-guide counts + first-seen from best_idx, LDS-privatised.
 // Measured bound of the lookup kernels: ~0.3-0.4 vector-L1 (TCP) accesses per clock
 // per CU, i.e. the number of divergent table visits per read, not HBM or L2.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
 #include <atomic>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <type_traits>
 
@@ -44,14 +46,66 @@ __device__ __forceinline__ void load_reads4(const uint64_t* p, uint64_t (&r)[4])
     r[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); r[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
 }
 
+// Tally records (K5', see k_hist_part): while a tile of 256 results is still on chip, the matcher writes, for each
+// of the NR guide ranges the tally kernel owns in LDS, one 128-byte line of up to 64 two-byte records (guide index
+// inside the range, 0xFFFF = empty) to rec[range][tile][64].  The tally then streams every range's records ONCE
+// (2.5 B per read in all at NR = 5) instead of sweeping best_idx once per range (4 B per read and range).
+// A tile with more than 64 hits in one range writes empty lines and puts its number on the overflow list; the
+// tally takes such tiles from best_idx.
+constexpr int PART_CAP = 64;        // records per range and tile: one 128-byte line
+constexpr int PART_MAX_NR = 8;      // ranges the staging area of a wave holds (512 two-byte records)
+struct PartOut {
+    uint16_t* rec;        // [nr][n_tiles][PART_CAP]; NULL = no records wanted
+    uint32_t* ovf_list;   // [n_tiles] tiles whose records did not fit
+    uint32_t* ovf_count;
+    uint32_t n_tiles;     // tiles of this launch (record stride between ranges)
+    uint32_t nr;          // ranges
+    uint32_t R;           // guides per range (<= HIST_R)
+    uint32_t magic;       // range of guide g = umulhi(g, magic) (exact for g < G, checked on the host)
+};
+
 struct MatchOut {
     int32_t* best_idx;
     uint8_t* best_dist;
     uint8_t* n_best;
-    uint32_t* counts;      // NULL when the tally is done by k_hist afterwards
+    uint32_t* counts;      // NULL when the tally is done by k_hist / k_hist_part afterwards
     uint64_t* first_seen;  // idem
     uint64_t base;
+    PartOut part;
 };
+
+// One wave, one tile of 256 consecutive results (4 per lane): stage the tally records in LDS (stage: PART_MAX_NR *
+// PART_CAP two-byte slots, cnt: PART_MAX_NR counters; both private to the wave) and store them as whole lines.
+__device__ __forceinline__ void part_emit(const PartOut& P, uint32_t tile, const int32_t (&idx)[4], uint32_t lane,
+                                          uint16_t* stage, uint32_t* cnt) {
+    // empty staging area: 512 slots = 256 dwords, four per lane; counters
+    reinterpret_cast<uint4*>(stage)[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (lane < (uint32_t)PART_MAX_NR) cnt[lane] = 0u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (idx[j] >= 0) {
+            const uint32_t g = (uint32_t)idx[j];
+            const uint32_t p = __umulhi(g, P.magic);
+            const uint32_t slot = atomicAdd(&cnt[p], 1u);
+            if (slot < (uint32_t)PART_CAP) stage[p * PART_CAP + slot] = (uint16_t)(g - p * P.R);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t c = lane < P.nr ? cnt[lane] : 0u;
+    const bool ovf = __ballot(c > (uint32_t)PART_CAP) != 0ull;
+    if (ovf && lane == 0) P.ovf_list[atomicAdd(P.ovf_count, 1u)] = tile;
+    // lines out: lane l stores dword (l & 31) of range 2r + (l >> 5): two ranges per store instruction
+    const uint32_t* sw = reinterpret_cast<const uint32_t*>(stage);
+    for (uint32_t r = 0; r < P.nr; r += 2) {
+        const uint32_t rg = r + (lane >> 5);
+        if (rg < P.nr) {
+            const uint32_t v = ovf ? 0xFFFFFFFFu : sw[rg * (PART_CAP / 2) + (lane & 31u)];
+            uint32_t* dst = reinterpret_cast<uint32_t*>(P.rec + ((size_t)rg * P.n_tiles + tile) * PART_CAP) + (lane & 31u);
+            __builtin_nontemporal_store(v, dst);
+        }
+    }
+}
 
 __device__ __forceinline__ bool read_skipped(uint64_t r, const uint8_t* flags, uint64_t i, int k) {
     bool s = (k <= 31) && (r >> 63);
@@ -114,103 +168,68 @@ __device__ __forceinline__ int32_t hash_lookup(uint64_t key, const uint64_t* __r
     return BC_IDX_MISS;
 }
 
-// Reads the exact-match stage cannot place are handed to the seed-index stage
-// through a queue.  A single global append counter saturates at ~88 appends/us
-// (measured: 6.3 ms per 33M-read tile), so every workgroup owns a private
-// region of the queue and counts its appends in LDS; stage 2 runs the same grid
-// and workgroup b drains region b.
-struct MissQueue {
-    uint64_t* reads;       // [grid][region_cap] packed read (masked)
-    uint32_t* idx;         // [grid][region_cap] index of the read inside the current tile
-    uint32_t* count;       // [grid] appended entries per workgroup; NULL = no queue (a miss is final)
-    uint32_t region_cap;
-};
-
-template <int VEC>
-__device__ __forceinline__ void queue_push(const MissQueue& q, uint32_t* lds_count, const bool (&push)[VEC],
-                                           const uint64_t (&r)[VEC], const uint32_t (&i)[VEC]) {
-    unsigned long long mask[VEC];
-    uint32_t total = 0;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) { mask[j] = __ballot(push[j]); total += (uint32_t)__popcll(mask[j]); }
-    if (total == 0u) return;
-    uint32_t base = 0;
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const unsigned long long active = __ballot(true);
-    const int leader = __ffsll((long long)active) - 1;
-    if ((int)lane == leader) base = atomicAdd(lds_count, total);  // one LDS atomic per wave and step
-    base = (uint32_t)__shfl((int)base, leader);
-    const size_t region = (size_t)blockIdx.x * q.region_cap;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        if (push[j]) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask[j], 0u));
-            q.reads[region + base + rank] = r[j];
-            q.idx[region + base + rank] = i[j];
-        }
-        base += (uint32_t)__popcll(mask[j]);
-    }
-}
-
 template <bool WIDE, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict__ reads,
                                                       const uint8_t* __restrict__ flags, uint64_t n,
                                                       const uint64_t* __restrict__ s64,
                                                       const uint32_t* __restrict__ s32,
                                                       const uint64_t* __restrict__ guides, int k,
-                                                      int log_slots, uint64_t kmask, MatchOut o, MissQueue q) {
-    __shared__ uint32_t q_n;
-    if (q.count) {
-        if (threadIdx.x == 0) q_n = 0;
-        __syncthreads();
-    }
+                                                      int log_slots, uint64_t kmask, MatchOut o) {
+    __shared__ __attribute__((aligned(16))) uint16_t p_stage[VEC == 4 ? (BLOCK / 64) * PART_MAX_NR * PART_CAP : 8];
+    __shared__ uint32_t p_cnt[VEC == 4 ? (BLOCK / 64) * PART_MAX_NR : 1];
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     const uint64_t ngroups = n / VEC;
-    for (uint64_t g = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; g < ngroups; g += stride) {
+    // the loop bound is wave-uniform (g0 = the wave's first group): a wave's 64 groups of 4 reads are one tile of
+    // 256 consecutive reads, and the whole wave takes part in the tile's tally records even when the tile is ragged
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t g0 = (uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u); g0 < ngroups; g0 += stride) {
+        const uint64_t g = g0 + lane;
+        const bool active = g < ngroups;
         uint64_t r[VEC];
-        if constexpr (VEC == 4) {
-            load_reads4(reads + g * 4, r);
-        } else {
-            r[0] = reads[g];
-        }
         int32_t idx[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            uint64_t i = g * VEC + j;
-            if (read_skipped(r[j], flags, i, k)) idx[j] = BC_IDX_SKIP;
-            else idx[j] = hash_lookup<WIDE>(r[j] & kmask, s64, s32, guides, k, log_slots, kmask);
-        }
-        if (q.count) {
-            bool push[VEC];
-            uint64_t rr[VEC];
-            uint32_t ii[VEC];
+        for (int j = 0; j < VEC; ++j) { r[j] = 0; idx[j] = BC_IDX_SKIP; }
+        if (active) {
+            if constexpr (VEC == 4) {
+                load_reads4(reads + g * 4, r);
+            } else {
+                r[0] = reads[g];
+            }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { push[j] = idx[j] == BC_IDX_MISS; rr[j] = r[j] & kmask; ii[j] = (uint32_t)(g * VEC + j); }
-            queue_push<VEC>(q, &q_n, push, rr, ii);
+            for (int j = 0; j < VEC; ++j) {
+                uint64_t i = g * VEC + j;
+                if (read_skipped(r[j], flags, i, k)) idx[j] = BC_IDX_SKIP;
+                else idx[j] = hash_lookup<WIDE>(r[j] & kmask, s64, s32, guides, k, log_slots, kmask);
+            }
         }
         if constexpr (VEC == 4) {
-            {   // results are final: non-temporal stores keep the table in the L2
+            if (active) {   // results are final: non-temporal stores keep the table in the L2
                 const u32x4 t = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2], (uint32_t)idx[3]};
                 __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(o.best_idx) + g);
-            }
-            if (o.best_dist) {
-                uchar4 d;
-                d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
-                d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
-                __builtin_nontemporal_store((uint32_t)d.x | ((uint32_t)d.y << 8) | ((uint32_t)d.z << 16) | ((uint32_t)d.w << 24), reinterpret_cast<uint32_t*>(o.best_dist) + g);
-            }
-            if (o.n_best) {
-                uchar4 d;
-                d.x = idx[0] >= 0; d.y = idx[1] >= 0; d.z = idx[2] >= 0; d.w = idx[3] >= 0;
-                __builtin_nontemporal_store((uint32_t)d.x | ((uint32_t)d.y << 8) | ((uint32_t)d.z << 16) | ((uint32_t)d.w << 24), reinterpret_cast<uint32_t*>(o.n_best) + g);
-            }
+                if (o.best_dist) {
+                    uchar4 d;
+                    d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
+                    d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
+                    __builtin_nontemporal_store((uint32_t)d.x | ((uint32_t)d.y << 8) | ((uint32_t)d.z << 16) | ((uint32_t)d.w << 24), reinterpret_cast<uint32_t*>(o.best_dist) + g);
+                }
+                if (o.n_best) {
+                    uchar4 d;
+                    d.x = idx[0] >= 0; d.y = idx[1] >= 0; d.z = idx[2] >= 0; d.w = idx[3] >= 0;
+                    __builtin_nontemporal_store((uint32_t)d.x | ((uint32_t)d.y << 8) | ((uint32_t)d.z << 16) | ((uint32_t)d.w << 24), reinterpret_cast<uint32_t*>(o.n_best) + g);
+                }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) tally(o, g * VEC + j, idx[j]);
+                for (int j = 0; j < VEC; ++j) tally(o, g * VEC + j, idx[j]);
+            }
+            if (o.part.rec) {
+                const uint32_t w = threadIdx.x >> 6;
+                part_emit(o.part, (uint32_t)((g0 * VEC) >> 8), idx, lane, p_stage + w * (PART_MAX_NR * PART_CAP),
+                          p_cnt + w * PART_MAX_NR);
+            }
         } else {
-            emit(o, g, idx[0], idx[0] >= 0 ? 0u : (uint32_t)BC_DIST_NONE, idx[0] >= 0 ? 1u : 0u);
+            if (active) emit(o, g, idx[0], idx[0] >= 0 ? 0u : (uint32_t)BC_DIST_NONE, idx[0] >= 0 ? 1u : 0u);
         }
     }
-    // tail (n % VEC reads) by the first threads of block 0
+    // tail (n % VEC reads) by the first threads of block 0; the tally kernel takes these reads from best_idx
     if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < (n % VEC)) {
         uint64_t i = ngroups * VEC + threadIdx.x;
         uint64_t r = reads[i];
@@ -218,15 +237,6 @@ __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict
                           ? BC_IDX_SKIP
                           : hash_lookup<WIDE>(r & kmask, s64, s32, guides, k, log_slots, kmask);
         emit(o, i, idx, idx >= 0 ? 0u : (uint32_t)BC_DIST_NONE, idx >= 0 ? 1u : 0u);
-        if (q.count && idx == BC_IDX_MISS) {  // tail reads (block 0 only): one lane at a time is fine
-            uint32_t at = atomicAdd(&q_n, 1u);
-            q.reads[at] = r & kmask;
-            q.idx[at] = (uint32_t)i;
-        }
-    }
-    if (q.count) {
-        __syncthreads();
-        if (threadIdx.x == 0) q.count[blockIdx.x] = q_n;
     }
 }
 
@@ -360,7 +370,6 @@ __device__ __forceinline__ uint32_t grp_last(uint32_t v, int last_lane) {  // va
     else return (uint32_t)__shfl((int)v, last_lane);
 }
 
-constexpr int QUEUE_MAX_BLOCKS = 32768;  // workgroups (= queue regions) of one two-stage tile
 constexpr int SLAB_MAX_LOG2S = 5;  // <= 32 entries (256 B) per slab; longer buckets chain
 
 // Running result of one lane: key = dist << 24 | guide index (one v_min keeps the
@@ -499,10 +508,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_slab(const SlabParams* __restri
 }
 
 // ---------------------------------------------------------------------------
-// K3a'': second stage of the two-stage matcher.  Input = the queue of reads that
-// have no exact hit (stage 1 = k_match_hash); every lane group is busy on a read
-// that really needs the seed search.  All tables' primary slabs are requested
-// up front; the scan is branch-free:
+// Branch-free slab scan of the quad kernels:
 //   key  = dist << 24 | guide            -> kmin = min key  (best distance, lowest index)
 //   key2 = key + (255 - max_mm) << 24    -> kmax = max key2 (largest candidate; distances
 //                                           above max_mm wrap below every candidate)
@@ -574,51 +580,6 @@ __device__ __forceinline__ void slab_slow(const SlabParams& sp, uint32_t rlo, ui
     const uint32_t mine = (md <= 3u) ? (uint32_t)((b.cnt >> (16 * (md & 3u))) & 0xFFFFu) : 0u;
     key_out = key;
     nb_out = grp_sum<LPR>(mine);
-}
-
-template <int LPR, int NSEG>
-__global__ __launch_bounds__(BLOCK) void k_match_slabq(const SlabParams* __restrict__ spp,
-                                                       const uint64_t* __restrict__ q_reads,
-                                                       const uint32_t* __restrict__ q_idx,
-                                                       const uint32_t* __restrict__ q_count, uint32_t region_cap,
-                                                       int max_mm, MatchOut o) {
-    const SlabParams& sp = *spp;
-    constexpr int MAXSTEP = (1 << SLAB_MAX_LOG2S) / (2 * LPR);
-    const uint32_t n = q_count[blockIdx.x];  // this workgroup drains the region its twin filled
-    q_reads += (size_t)blockIdx.x * region_cap;
-    q_idx += (size_t)blockIdx.x * region_cap;
-    const int sub = threadIdx.x & (LPR - 1);
-    const int last_lane = (threadIdx.x & 63) | (LPR - 1);
-    const uint32_t bias = (255u - (uint32_t)max_mm) << 24;
-    for (uint32_t qi = threadIdx.x / LPR; qi < n; qi += BLOCK / LPR) {
-        const uint64_t r = q_reads[qi];
-        const uint64_t i = q_idx[qi];
-        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
-        uint4 v[NSEG][MAXSTEP];
-#pragma unroll
-        for (int s = 0; s < NSEG; ++s)
-            slab_load<LPR, MAXSTEP>(sp.t[s], seed_value(rlo, rhi, sp.t[s].start, sp.t[s].slen), sub, v[s]);
-        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-#pragma unroll
-        for (int s = 0; s < NSEG; ++s) {
-            const SlabTable& T = sp.t[s];
-            const uint32_t rest = slab_rest(T, rlo, rhi);
-            uint32_t slab = slab_scan_fast<LPR, MAXSTEP>(T, v[s], rest, bias, kmin, kmax, last_lane);
-            while (slab != 0u) {  // overflow chain
-                slab_load<LPR, MAXSTEP>(T, slab, sub, v[s]);
-                slab = slab_scan_fast<LPR, MAXSTEP>(T, v[s], rest, bias, kmin, kmax, last_lane);
-            }
-        }
-        kmin = grp_min<LPR>(kmin);
-        kmax = grp_max<LPR>(kmax);
-        uint32_t key = kmin, nb = 1u;
-        const bool hit = (kmin >> 24) <= (uint32_t)max_mm;
-        if (hit && (kmax - bias) != kmin) slab_slow<LPR, NSEG>(sp, rlo, rhi, max_mm, sub, last_lane, key, nb);
-        if (sub == 0) {
-            if (hit) emit(o, i, (int32_t)(key & SLAB_GIDX_MASK), key >> 24, nb);
-            else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1063,7 +1024,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     static_assert(NSEG == 2 || NSEG == 3, "wave kernel: d = 1 or 2");
     // list of reads without an exact hit: read, best key so far, table 0's overflow slab (byte offset), position
     __shared__ uint64_t q_read[WAVE_T];
-    __shared__ uint32_t q_key[WAVE_T], q_off[WAVE_T];
+    __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];
+    __shared__ uint32_t q_off[WAVE_T];
     __shared__ uint16_t l_t2[WAVE_T];     // list entries that need table 2
     __shared__ uint16_t l_slow[WAVE_T];   // list entries that need the exact path
     const SlabParams& sp = *spp;
@@ -1306,6 +1268,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
+        if (o.part.rec) {
+            // the lists are dead (every lane has its results in registers; the stores above come after the waits on
+            // those LDS reads): q_key becomes the record staging area (256 dwords), q_off the range counters
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j >= tn) idx[j] = BC_IDX_SKIP;
+            part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_key), q_off);
+        }
     }
     phase_mark(3);
     if (PROF && threadIdx.x == 0) {
@@ -1376,6 +1347,108 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist(const int32_t* __restrict__
             if (counts) atomicAdd(&counts[lo + j], c);
             if (first_seen) atomicMin((unsigned long long*)&first_seen[lo + j], (unsigned long long)(base + fs[j]));
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5': the tally from the matcher's range-partitioned records (PartOut).  Workgroup (range p, slice s) owns the
+// range's R guides in LDS (count + first TILE seen) and streams the records rec[p][tiles of slice s] — whole
+// 128-byte lines, 8 records per lane and load — then the tiles on the overflow list and the reads past the last
+// full group of four (both from best_idx, filtered to its range), and flushes with contiguous atomics: counts
+// into counts[], first tiles into first_tile[] (a min over slices).  k_first_refine then turns a guide's first
+// tile into its first read by scanning that tile's 256 results, and leaves first_tile[] / the overflow counter
+// reset for the next launch.  Bytes per read: 2.5 (records) instead of 4 x ranges (five sweeps of best_idx).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(HIST_BLOCK) void k_hist_part(PartOut P, const int32_t* __restrict__ best_idx, uint64_t n,
+                                                          uint64_t tail_begin, uint32_t G, int slices,
+                                                          uint32_t* __restrict__ counts,
+                                                          uint32_t* __restrict__ first_tile) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* cnt = lds;
+    uint32_t* ft = lds + HIST_R;
+    const uint32_t range = blockIdx.x / slices, slice = blockIdx.x % slices;
+    const uint32_t lo = range * P.R;
+    const uint32_t width = min(P.R, G - lo);
+    for (uint32_t j = threadIdx.x; j < width; j += HIST_BLOCK) { cnt[j] = 0; ft[j] = 0xFFFFFFFFu; }
+    __syncthreads();
+    // records: 8 lanes per tile line (16 B each), tiles of this slice
+    const uint64_t per = ((uint64_t)P.n_tiles + slices - 1) / slices;
+    const uint64_t t0 = (uint64_t)slice * per, t1 = min((uint64_t)P.n_tiles, t0 + per);
+    const u32x4* pv = reinterpret_cast<const u32x4*>(P.rec + (size_t)range * P.n_tiles * PART_CAP);
+    auto take = [&](const u32x4& v, uint32_t tile) {
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t g = (vv[c] >> (16 * h)) & 0xFFFFu;
+                if (g < width) {  // 0xFFFF = empty
+                    atomicAdd(&cnt[g], 1u);
+                    if (first_tile) atomicMin(&ft[g], tile);
+                }
+            }
+        }
+    };
+    const uint64_t q0 = t0 * 8, q1 = t1 * 8;  // 16-byte pieces
+    uint64_t q = q0 + threadIdx.x;
+    for (; q + 3 * HIST_BLOCK < q1; q += 4 * HIST_BLOCK) {  // four loads in flight
+        const u32x4 v0 = __builtin_nontemporal_load(pv + q), v1 = __builtin_nontemporal_load(pv + q + HIST_BLOCK);
+        const u32x4 v2 = __builtin_nontemporal_load(pv + q + 2 * HIST_BLOCK), v3 = __builtin_nontemporal_load(pv + q + 3 * HIST_BLOCK);
+        take(v0, (uint32_t)(q >> 3));
+        take(v1, (uint32_t)((q + HIST_BLOCK) >> 3));
+        take(v2, (uint32_t)((q + 2 * HIST_BLOCK) >> 3));
+        take(v3, (uint32_t)((q + 3 * HIST_BLOCK) >> 3));
+    }
+    for (; q < q1; q += HIST_BLOCK) take(__builtin_nontemporal_load(pv + q), (uint32_t)(q >> 3));
+    // tiles whose records did not fit: their share of the overflow list, straight from best_idx
+    auto take_idx = [&](int32_t v, uint32_t tile) {
+        const uint32_t g = (uint32_t)v - lo;  // negative sentinels wrap far above width
+        if (g < width) {
+            atomicAdd(&cnt[g], 1u);
+            if (first_tile) atomicMin(&ft[g], tile);
+        }
+    };
+    const uint32_t novf = *P.ovf_count;
+    for (uint32_t e = slice; e < novf; e += (uint32_t)slices) {
+        const uint32_t tile = P.ovf_list[e];
+        const uint64_t a = (uint64_t)tile << 8, b = min(tail_begin, a + 256);
+        for (uint64_t i = a + threadIdx.x; i < b; i += HIST_BLOCK) take_idx(best_idx[i], tile);
+    }
+    if (slice == (uint32_t)slices - 1)  // reads the matcher's record path did not cover
+        for (uint64_t i = tail_begin + threadIdx.x; i < n; i += HIST_BLOCK) take_idx(best_idx[i], (uint32_t)(i >> 8));
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < width; j += HIST_BLOCK) {
+        const uint32_t c = cnt[j];
+        if (c) {
+            if (counts) atomicAdd(&counts[lo + j], c);
+            if (first_tile) atomicMin(&first_tile[lo + j], ft[j]);
+        }
+    }
+}
+
+// one quarter-wave (16 lanes x 16 results) per guide: first read of the guide inside its first tile
+__global__ __launch_bounds__(BLOCK) void k_first_refine(const int32_t* __restrict__ best_idx, uint64_t n, uint32_t G,
+                                                        uint32_t* __restrict__ first_tile,
+                                                        uint64_t* __restrict__ first_seen, uint64_t base,
+                                                        uint32_t* __restrict__ ovf_count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ovf_count = 0u;  // every consumer of the list ran in an earlier launch
+    const uint32_t g = (blockIdx.x * BLOCK + threadIdx.x) >> 4;
+    const uint32_t sub = threadIdx.x & 15u;
+    if (g >= G) return;
+    const uint32_t tile = first_tile[g];
+    if (tile == 0xFFFFFFFFu) return;  // uniform over the 16 lanes
+    const uint64_t a = (uint64_t)tile << 8;
+    uint32_t pos = 0xFFFFFFFFu;
+#pragma unroll 4
+    for (uint32_t j = 0; j < 16; ++j) {
+        const uint64_t i = a + j * 16u + sub;
+        if (i < n && best_idx[i] == (int32_t)g) pos = min(pos, j * 16u + sub);
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) pos = min(pos, (uint32_t)__shfl_xor((int)pos, m));
+    if (sub == 0) {
+        first_tile[g] = 0xFFFFFFFFu;
+        if (pos != 0xFFFFFFFFu) atomicMin((unsigned long long*)&first_seen[g], (unsigned long long)(base + a + pos));
     }
 }
 
@@ -1748,97 +1821,183 @@ int build_hash(bc_lib* lib) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
-                        int max_mm, int algo, const MatchOut& o, hipStream_t st);
+                        int max_mm, int algo, const MatchOut& o, hipStream_t st, bool* part_done, uint64_t* tail_begin);
+
+// dynamic LDS above 64 KiB needs the attribute once per device and kernel (a second bc_lib on another device, or a
+// second thread, must not launch without it)
+template <typename K>
+int ensure_big_lds(K kernel, int device, size_t bytes) {
+    static std::mutex m;
+    static bool done[64] = {};
+    std::lock_guard<std::mutex> g(m);
+    if (device >= 0 && device < 64 && done[device]) return BC_OK;
+    BC_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (device >= 0 && device < 64) done[device] = true;
+    return BC_OK;
+}
+
+constexpr size_t HIST_LDS_BYTES = (size_t)HIST_R * 2 * sizeof(uint32_t);
 
 int launch_hist(bc_lib* lib, const MatchOut& o, uint64_t n, hipStream_t st) {
-    static bool attr_set = false;
-    const size_t lds_bytes = (size_t)HIST_R * 2 * sizeof(uint32_t);
-    if (!attr_set) {
-        BC_HIP(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    int rc = ensure_big_lds(k_hist, lib->device, HIST_LDS_BYTES);
+    if (rc != BC_OK) return rc;
     const int passes = (int)((lib->G + HIST_R - 1) / HIST_R);
     const int slices = std::max(1, 256 / passes);
     const uint64_t CH = 0xFFFFFFF0ull;  // first-seen is tracked as a 32-bit offset inside a sweep
     for (uint64_t a = 0; a < n; a += CH) {
         uint64_t m = std::min(CH, n - a);
-        hipLaunchKernelGGL(k_hist, dim3(passes * slices), dim3(HIST_BLOCK), lds_bytes, st, o.best_idx + a, m, lib->G,
+        hipLaunchKernelGGL(k_hist, dim3(passes * slices), dim3(HIST_BLOCK), HIST_LDS_BYTES, st, o.best_idx + a, m, lib->G,
                            slices, o.counts, o.first_seen, o.base + a);
     }
     BC_HIP(hipGetLastError());
     return BC_OK;
 }
 
-int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
-                 int max_mm, int algo, const MatchOut& o_in, hipStream_t st) {
-    if (n == 0) return BC_OK;
-    if (algo == BC_ALGO_AUTO) algo = (max_mm == 0) ? BC_ALGO_HASH : BC_ALGO_SEED;
-    // tally: in-kernel global atomics for small launches, LDS histogram sweep otherwise
-    MatchOut o = o_in;
-    const int tally_mode = env_int("BC_TALLY", 0);  // 0 auto, 1 atomics, 2 LDS histogram
-    const bool want_tally = o.counts || o.first_seen;
-    bool use_hist = want_tally && aligned16(o.best_idx) && (tally_mode == 2 || (tally_mode == 0 && n >= 4ull * lib->G));
-    if (use_hist) { o.counts = nullptr; o.first_seen = nullptr; }
-    int rc = launch_match_kernel(lib, d_reads, d_flags, n, max_mm, algo, o, st);
-    if (rc != BC_OK) return rc;
-    if (use_hist) return launch_hist(lib, o_in, n, st);
+// ---- tally records: geometry and per-stream workspace -------------------------------------------------------
+// ranges: as few as the LDS allows (HIST_R guides each), equal sizes; range(g) = umulhi(g, magic) must be exact
+bool part_geometry(uint32_t G, PartOut& P) {
+    const uint32_t nr = (G + HIST_R - 1) / HIST_R;
+    if (nr < 3 || nr > (uint32_t)PART_MAX_NR) return false;  // one or two ranges: sweeping best_idx costs no more
+    const uint32_t R = (G + nr - 1) / nr;
+    const uint32_t magic = (uint32_t)((0x100000000ull + R - 1) / R);
+    for (uint32_t g = 0; g < G; ++g)
+        if ((uint32_t)(((uint64_t)g * magic) >> 32) != g / R) return false;
+    P.nr = nr; P.R = R; P.magic = magic;
+    return true;
+}
+
+// launches on one stream are ordered, so one workspace per stream is enough; it only ever grows
+int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, TallyWs** out) {
+    std::lock_guard<std::mutex> g(lib->ws_mutex);
+    TallyWs* w = nullptr;
+    for (auto& e : lib->ws) if (e.stream == (void*)st) w = &e;
+    if (!w) {
+        if (lib->ws.size() >= 64) { set_error("bc_match: more than 64 streams share one library"); return BC_EINVAL; }
+        lib->ws.emplace_back();
+        w = &lib->ws.back();
+        w->stream = (void*)st;
+        BC_HIP(hipMalloc((void**)&w->first_tile, (size_t)lib->G * 4));
+        BC_HIP(hipMalloc((void**)&w->ovf_count, 16));
+        BC_HIP(hipMemset(w->first_tile, 0xFF, (size_t)lib->G * 4));
+        BC_HIP(hipMemset(w->ovf_count, 0, 16));
+    }
+    if (n_tiles > w->tiles_cap) {
+        BC_HIP(hipStreamSynchronize(st));  // nothing of this stream may still use the old buffers
+        if (w->rec) (void)hipFree(w->rec);
+        if (w->ovf_list) (void)hipFree(w->ovf_list);
+        w->rec = nullptr; w->ovf_list = nullptr; w->tiles_cap = 0;
+        BC_HIP(hipMalloc((void**)&w->rec, (size_t)n_tiles * nr * PART_CAP * sizeof(uint16_t)));
+        BC_HIP(hipMalloc((void**)&w->ovf_list, (size_t)n_tiles * 4));
+        w->tiles_cap = n_tiles;
+    }
+    *out = w;
     return BC_OK;
 }
 
-int launch_hash(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o,
-                const MissQueue& q, hipStream_t st, int max_grid = 0) {
-    bool vec = aligned16(d_reads) && aligned16(o.best_idx) && (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
-               (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0) && n >= 4;
-    if (!vec && q.count) {
-        set_error("bc_match: the two-stage matcher needs 16-byte aligned read / result buffers and n >= 4");
-        return BC_EINVAL;
-    }
-    if (vec) {
-        // 4 rows of 256 four-read groups per workgroup unless the caller fixes the grid (queue regions)
-        const uint64_t rows = (n / 4 + BLOCK - 1) / BLOCK;
-        int grid = (int)std::max<uint64_t>(1, max_grid > 0 ? std::min<uint64_t>(rows, (uint64_t)max_grid) : std::min<uint64_t>((rows + 3) / 4, 1u << 20));
-        if (lib->wide)
-            hipLaunchKernelGGL((k_match_hash<true, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
-                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o, q);
-        else
-            hipLaunchKernelGGL((k_match_hash<false, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
-                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o, q);
-    } else {
-        int grid = grid_for(n);
-        if (lib->wide)
-            hipLaunchKernelGGL((k_match_hash<true, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
-                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o, q);
-        else
-            hipLaunchKernelGGL((k_match_hash<false, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
-                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o, q);
-    }
+int launch_hist_part(bc_lib* lib, const MatchOut& o, const TallyWs* w, uint64_t n, uint64_t tail_begin, hipStream_t st) {
+    int rc = ensure_big_lds(k_hist_part, lib->device, HIST_LDS_BYTES);
+    if (rc != BC_OK) return rc;
+    const int slices = std::max(1, 256 / (int)o.part.nr);
+    hipLaunchKernelGGL(k_hist_part, dim3(o.part.nr * slices), dim3(HIST_BLOCK), HIST_LDS_BYTES, st, o.part, o.best_idx, n,
+                       tail_begin, lib->G, slices, o.counts, o.first_seen ? w->first_tile : nullptr);
+    // always: it also resets the overflow counter for the next launch on this stream
+    hipLaunchKernelGGL(k_first_refine, dim3((lib->G * 16 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, o.best_idx, n,
+                       o.first_seen ? lib->G : 0u, w->first_tile, o.first_seen, o.base, w->ovf_count);
     BC_HIP(hipGetLastError());
     return BC_OK;
 }
 
-// the miss queue lives in the library object and only ever grows; the first
-// large call allocates it (keep it out of a graph capture: warm up first)
-int ensure_queue(bc_lib* lib, uint64_t cap, int grid) {
-    if (!lib->q_count) BC_HIP(hipMalloc((void**)&lib->q_count, sizeof(uint32_t) * QUEUE_MAX_BLOCKS));
-    (void)grid;
-    if (cap <= lib->q_cap) return BC_OK;
-    if (lib->q_reads) (void)hipFree(lib->q_reads);
-    if (lib->q_idx) (void)hipFree(lib->q_idx);
-    lib->q_reads = nullptr; lib->q_idx = nullptr; lib->q_cap = 0;
-    BC_HIP(hipMalloc((void**)&lib->q_reads, cap * sizeof(uint64_t)));
-    BC_HIP(hipMalloc((void**)&lib->q_idx, cap * sizeof(uint32_t)));
-    lib->q_cap = cap;
+// which kernel ran last (tests assert the path, bc_lib_last_kernel)
+void note_kernel(bc_lib* lib, const char* name) { lib->last_kernel.store(name, std::memory_order_relaxed); }
+
+int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
+                 int max_mm, int algo, const MatchOut& o_in, hipStream_t st) {
+    if (n == 0) return BC_OK;
+    if (max_mm < 0 || max_mm >= lib->k) {
+        // a guide within d substitutions keeps a clean pigeonhole segment only when k > d; and "every k-mer matches" is
+        // never what a caller means
+        set_error("bc_match: max_mismatch %d must be >= 0 and < k = %d", max_mm, lib->k);
+        return BC_EINVAL;
+    }
+    if (algo == BC_ALGO_AUTO) algo = (max_mm == 0) ? BC_ALGO_HASH : BC_ALGO_SEED;
+    // tally: in-kernel global atomics for small launches; otherwise LDS-privatised, from the matcher's range-partitioned
+    // records (k_hist_part) when the kernel that runs can write them, else by sweeping best_idx once per range (k_hist)
+    const int tally_mode = lib->knobs.tally;  // 0 auto, 1 atomics, 2 k_hist, 3 records when possible
+    const bool want_tally = o_in.counts || o_in.first_seen;
+    const bool use_lds = want_tally && aligned16(o_in.best_idx) && (tally_mode >= 2 || (tally_mode == 0 && n >= 4ull * lib->G));
+    const uint64_t CH = 1ull << 31;  // reads per launch: 32-bit tile numbers and offsets stay far from wrapping
+    for (uint64_t a = 0; a < n; a += CH) {
+        const uint64_t m = std::min(CH, n - a);
+        MatchOut o = o_in;
+        o.best_idx += a;
+        if (o.best_dist) o.best_dist += a;
+        if (o.n_best) o.n_best += a;
+        o.base += a;
+        o.part = PartOut{};
+        TallyWs* w = nullptr;
+        if (use_lds) {
+            o.counts = nullptr; o.first_seen = nullptr;
+            if (tally_mode != 2 && part_geometry(lib->G, o.part)) {
+                o.part.n_tiles = (uint32_t)((m + 255) >> 8);
+                int rc = tally_workspace(lib, st, o.part.n_tiles, o.part.nr, &w);
+                if (rc != BC_OK) return rc;
+                o.part.rec = w->rec; o.part.ovf_list = w->ovf_list; o.part.ovf_count = w->ovf_count;
+            }
+        }
+        uint64_t tail_begin = m;
+        bool part_done = false;
+        int rc = launch_match_kernel(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, max_mm, algo, o, st, &part_done,
+                                     &tail_begin);
+        if (rc != BC_OK) return rc;
+        if (use_lds) {
+            MatchOut t = o;
+            t.counts = o_in.counts; t.first_seen = o_in.first_seen;
+            rc = part_done ? launch_hist_part(lib, t, w, m, tail_begin, st) : launch_hist(lib, t, m, st);
+            if (rc != BC_OK) return rc;
+        }
+    }
+    return BC_OK;
+}
+
+int launch_hash(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o_in,
+                hipStream_t st, bool* part_done, uint64_t* tail_begin) {
+    bool vec = aligned16(d_reads) && aligned16(o_in.best_idx) && (!o_in.best_dist || (((uintptr_t)o_in.best_dist) & 3u) == 0) &&
+               (!o_in.n_best || (((uintptr_t)o_in.n_best) & 3u) == 0) && n >= 4;
+    MatchOut o = o_in;
+    if (!vec) o.part = PartOut{};
+    if (vec) {
+        // 4 rows of 256 four-read groups per workgroup
+        const uint64_t rows = (n / 4 + BLOCK - 1) / BLOCK;
+        int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((rows + 3) / 4, 1u << 20));
+        if (lib->wide)
+            hipLaunchKernelGGL((k_match_hash<true, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
+                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
+        else
+            hipLaunchKernelGGL((k_match_hash<false, 4>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
+                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
+        if (o.part.rec) { *part_done = true; *tail_begin = n & ~3ull; }
+    } else {
+        int grid = grid_for(n);
+        if (lib->wide)
+            hipLaunchKernelGGL((k_match_hash<true, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
+                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
+        else
+            hipLaunchKernelGGL((k_match_hash<false, 1>), dim3(grid), dim3(BLOCK), 0, st, d_reads, d_flags, n, lib->d_slots64,
+                               lib->d_slots32, lib->d_guides, lib->k, lib->log_slots, lib->kmask, o);
+    }
+    note_kernel(lib, "k_match_hash");
+    BC_HIP(hipGetLastError());
     return BC_OK;
 }
 
 int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
-                        int max_mm, int algo, const MatchOut& o, hipStream_t st) {
+                        int max_mm, int algo, const MatchOut& o, hipStream_t st, bool* part_done, uint64_t* tail_begin) {
     if (algo == BC_ALGO_HASH) {
         if (max_mm != 0) {
             set_error("bc_match: BC_ALGO_HASH requires max_mismatch == 0");
             return BC_EINVAL;
         }
-        int rc = launch_hash(lib, d_reads, d_flags, n, o, MissQueue{nullptr, nullptr, nullptr, 0}, st);
+        int rc = launch_hash(lib, d_reads, d_flags, n, o, st, part_done, tail_begin);
         if (rc != BC_OK) return rc;
     } else if (algo == BC_ALGO_SEED || algo == BC_ALGO_SEED_CSR) {
         if (max_mm < 0 || max_mm >= MAX_SEG) {
@@ -1846,17 +2005,48 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
             return BC_EINVAL;
         }
         if (algo == BC_ALGO_SEED && lib->slab_ok[max_mm]) {
-            const int lpr = env_int("BC_SLAB_LPR", 4);
             uint32_t minS = 1u << SLAB_MAX_LOG2S;
             for (int s = 0; s < lib->slab[max_mm].nseg; ++s) minS = std::min(minS, 1u << lib->slab[max_mm].t[s].log2S);
             const SlabParams* dp = lib->d_slab[max_mm];
-            const bool l8 = (lpr == 8 && minS >= 16);
+            const bool l8 = (lib->knobs.slab_lpr == 8 && minS >= 16);
             const int nseg = lib->slab[max_mm].nseg;
             const bool vec_ok = aligned16(d_reads) && aligned16(o.best_idx) && n >= 4 &&
                                 (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
                                 (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
-            const int stage_mode = env_int("BC_TWO_STAGE", 1);  // 1 fused (default), 2 two kernels + global queue, 0 single slab kernel
-            if (max_mm >= 1 && vec_ok && stage_mode == 1) {
+            if (max_mm >= 1 && vec_ok && !lib->knobs.single_slab) {
+                const SlabParams& hp = lib->slab[max_mm];
+                // default: the wave kernel (lane-owned reads, quad-cooperative loads, no hash table);
+                // BC_LANE=0 selects the quad kernels
+                const bool wave_ok = lib->knobs.lane && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
+                                     hp.t[1].log2S == 3 && !lib->h_nn.empty();
+                if (wave_ok) {
+                    const bool prof = lib->knobs.phase_prof != 0;  // tuning aid: per-stage cycle sums on stderr
+                    const int nq2 = nseg == 3 ? (1 << (hp.t[2].log2S - 3)) : 1;
+                    const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
+#define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_)                                                                         \
+    hipLaunchKernelGGL((k_match_wave<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n,   \
+                       lib->k, lib->kmask, max_mm, o)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false); } while (0)
+                    if (nseg == 2) BC_WAVE_P(2, 1);
+                    else if (nq2 == 1) BC_WAVE_P(3, 1);
+                    else if (nq2 == 2) BC_WAVE_P(3, 2);
+                    else BC_WAVE_P(3, 4);
+#undef BC_WAVE_P
+#undef BC_WAVE_LAUNCH
+                    note_kernel(lib, "k_match_wave");
+                    BC_HIP(hipGetLastError());
+                    if (o.part.rec) { *part_done = true; *tail_begin = n; }
+                    if (prof) {
+                        unsigned long long c[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        BC_HIP(hipStreamSynchronize(st));
+                        BC_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof(c)));
+                        BC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
+                        fprintf(stderr, "match stages (cycles/wave): 1 %.0f  2a %.0f  2b %.0f  2c+3 %.0f  waves %llu\n",
+                                (double)c[0] / c[7], (double)c[1] / c[7], (double)c[2] / c[7], (double)c[3] / c[7], c[7]);
+                    }
+                    return BC_OK;
+                }
+                // quad kernels (previous generation): d = 3, buckets above 16 guides, BC_LANE=0
                 const int grid = (int)((n + FUSED_T - 1) / FUSED_T);
                 // steps (16-byte pieces per lane) of the largest slab in round A (tables 0,1) and round B
                 int sa = 1, sb = 1;
@@ -1881,37 +2071,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
         else BC_FUSED_W(NSEG_, 4, 4);                                            \
     } while (0)
                 // the quad state machine handles 8-entry slabs for tables 0,1 and 8/16-entry slabs for table 2
-                const SlabParams& hp = lib->slab[max_mm];
-                // default: the wave kernel (lane-owned reads, quad-cooperative loads, no hash table);
-                // BC_LANE=0 selects the quad kernels
-                const bool wave_ok = env_int("BC_LANE", 1) && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
-                                     hp.t[1].log2S == 3 && !lib->h_nn.empty();
-                if (wave_ok) {
-                    const bool prof = env_int("BC_PHASE_PROF", 0) != 0;  // tuning aid: per-stage cycle sums on stderr
-                    const int nq2 = nseg == 3 ? (1 << (hp.t[2].log2S - 3)) : 1;
-                    const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
-#define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_)                                                                         \
-    hipLaunchKernelGGL((k_match_wave<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n,   \
-                       lib->k, lib->kmask, max_mm, o)
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false); } while (0)
-                    if (nseg == 2) BC_WAVE_P(2, 1);
-                    else if (nq2 == 1) BC_WAVE_P(3, 1);
-                    else if (nq2 == 2) BC_WAVE_P(3, 2);
-                    else BC_WAVE_P(3, 4);
-#undef BC_WAVE_P
-#undef BC_WAVE_LAUNCH
-                    BC_HIP(hipGetLastError());
-                    if (prof) {
-                        unsigned long long c[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                        BC_HIP(hipStreamSynchronize(st));
-                        BC_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof(c)));
-                        BC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
-                        fprintf(stderr, "match stages (cycles/wave): 1 %.0f  2a %.0f  2b %.0f  2c %.0f  waves %llu\n",
-                                (double)c[0] / c[7], (double)c[1] / c[7], (double)c[2] / c[7], (double)c[3] / c[7], c[7]);
-                    }
-                    return BC_OK;
-                }
-                const bool sm_ok = env_int("BC_PHASE2_SM", 1) && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
+                const bool sm_ok = lib->knobs.phase2_sm && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
                                    hp.t[1].log2S == 3 && (nseg == 2 || hp.t[2].log2S == 3 || hp.t[2].log2S == 4);
                 if (sm_ok && nseg == 2) { if (lib->wide) BC_FUSED_SM(true, 2); else BC_FUSED_SM(false, 2); }
                 else if (sm_ok && nseg == 3) { if (lib->wide) BC_FUSED_SM(true, 3); else BC_FUSED_SM(false, 3); }
@@ -1924,40 +2084,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
 #undef BC_FUSED_S
 #undef BC_FUSED_W
 #undef BC_FUSED_LAUNCH
-            } else if (max_mm >= 1 && vec_ok && stage_mode == 2) {
-                // stage 1: exact hits through the hash table; stage 2: the residue through the seed index
-                const uint64_t TILE = 1ull << 27;  // 134M reads per stage pair; the queue holds 12 B per read of a tile
-                // stage 1 grid and the per-workgroup queue regions (a workgroup sees at most `per` reads)
-                // many small workgroups (4096 reads each) instead of a capped persistent grid: the
-                // hardware dispatcher balances them and no resident slot idles through a long tail
-                const uint64_t tile_max = std::min(n, TILE);
-                const uint64_t rows = (tile_max / 4 + BLOCK - 1) / BLOCK;  // 256-group rows in a tile
-                const int qgrid = (int)std::max<uint64_t>(1, std::min<uint64_t>((rows + 3) / 4, QUEUE_MAX_BLOCKS));
-                const uint64_t groups_per_block = (rows + qgrid - 1) / qgrid;
-                const uint32_t region_cap = (uint32_t)(groups_per_block * BLOCK * 4 + 8);
-                int rc = ensure_queue(lib, (uint64_t)qgrid * region_cap, qgrid);
-                if (rc != BC_OK) return rc;
-                for (uint64_t a = 0; a < n; a += TILE) {
-                    const uint64_t m = std::min(TILE, n - a);
-                    MatchOut ot = o;
-                    ot.best_idx += a;
-                    if (ot.best_dist) ot.best_dist += a;
-                    if (ot.n_best) ot.n_best += a;
-                    ot.base += a;
-                    BC_HIP(hipMemsetAsync(lib->q_count, 0, sizeof(uint32_t) * qgrid, st));
-                    MissQueue q{lib->q_reads, lib->q_idx, lib->q_count, region_cap};
-                    rc = launch_hash(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, ot, q, st, qgrid);
-                    if (rc != BC_OK) return rc;
-#define BC_SLABQ_LAUNCH(LPR_, NSEG_)                                                                      \
-    hipLaunchKernelGGL((k_match_slabq<LPR_, NSEG_>), dim3(qgrid), dim3(BLOCK), 0, st, dp, lib->q_reads,     \
-                       lib->q_idx, lib->q_count, region_cap, max_mm, ot)
-                    switch (nseg) {
-                        case 2: if (l8) BC_SLABQ_LAUNCH(8, 2); else BC_SLABQ_LAUNCH(4, 2); break;
-                        case 3: if (l8) BC_SLABQ_LAUNCH(8, 3); else BC_SLABQ_LAUNCH(4, 3); break;
-                        default: if (l8) BC_SLABQ_LAUNCH(8, 4); else BC_SLABQ_LAUNCH(4, 4); break;
-                    }
-#undef BC_SLABQ_LAUNCH
-                }
+                note_kernel(lib, "k_match_fused");
             } else {
 #define BC_SLAB_LAUNCH(LPR_, NSEG_)                                                                          \
     hipLaunchKernelGGL((k_match_slab<LPR_, NSEG_>), dim3(grid_for(n * LPR_)), dim3(BLOCK), 0, st, dp, d_reads, \
@@ -1969,10 +2096,12 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     default: if (l8) BC_SLAB_LAUNCH(8, 4); else BC_SLAB_LAUNCH(4, 4); break;
                 }
 #undef BC_SLAB_LAUNCH
+                note_kernel(lib, "k_match_slab");
             }
         } else {
             hipLaunchKernelGGL(k_match_seed, dim3(grid_for(n)), dim3(BLOCK), 0, st, lib->seed[max_mm], d_reads,
                                d_flags, n, lib->k, lib->kmask, max_mm, o);
+            note_kernel(lib, "k_match_seed");
         }
     } else if (algo == BC_ALGO_BRUTE) {
         if (max_mm < 0 || max_mm > lib->k) {
@@ -1984,6 +2113,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
         if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
         hipLaunchKernelGGL(k_match_brute, dim3((int)blocks), dim3(BLOCK), 0, st, lib->d_guides, lib->G, d_reads,
                            d_flags, n, lib->k, lib->kmask, max_mm, o);
+        note_kernel(lib, "k_match_brute");
     } else {
         set_error("bc_match: unknown algo %d", algo);
         return BC_EINVAL;
@@ -2007,6 +2137,7 @@ static int slot_reserve(HostSlot& s, uint64_t cap) {
     if (cap <= s.cap) return BC_OK;
     for (void* p : {(void*)s.d_r, (void*)s.d_f, (void*)s.d_bd, (void*)s.d_nb, (void*)s.d_bi}) if (p) (void)hipFree(p);
     s.cap = 0;
+    s.d_r = nullptr; s.d_bi = nullptr; s.d_f = s.d_bd = s.d_nb = nullptr;
     BC_HIP(hipMalloc((void**)&s.d_r, cap * 8));
     BC_HIP(hipMalloc((void**)&s.d_bi, cap * 4));
     BC_HIP(hipMalloc((void**)&s.d_f, cap));
@@ -2016,6 +2147,112 @@ static int slot_reserve(HostSlot& s, uint64_t cap) {
     return BC_OK;
 }
 
+namespace {
+
+// scope guards: every exit path of the host entry points releases what it took
+struct DevMem {
+    void* p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        BC_HIP(hipMalloc(&p, bytes ? bytes : 16));
+        return BC_OK;
+    }
+};
+struct Pinned {
+    std::vector<void*> v;
+    void pin(const void* p, size_t bytes) {
+        if (p && hipHostRegister((void*)p, bytes, hipHostRegisterDefault) == hipSuccess) v.push_back((void*)p);
+        else (void)hipGetLastError();
+    }
+    ~Pinned() { for (void* p : v) (void)hipHostUnregister(p); }
+};
+struct Events {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
+// Host buffers in, per-read results out to the host; counts / first-seen are left ON THE DEVICE (d_c: uint32[G],
+// d_fs: uint64[G], accumulated over the chunks).  The call is cut into chunks that HOST_WORKERS threads take in
+// turn, each with its own HIP stream and device staging slot (kept in the library object between calls): while one
+// worker copies results back, another uploads the next chunk and a third one's kernels run, so H2D, compute and
+// D2H overlap (PCIe is full duplex).  The caller holds lib->host_mutex.
+int match_host_chunks(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, uint64_t n, int max_mismatch,
+                      int algo, int32_t* h_best_idx, uint8_t* h_best_dist, uint8_t* h_n_best, uint32_t* d_c,
+                      uint64_t* d_fs, uint64_t first_index_base) {
+    constexpr int HOST_WORKERS = 3;
+    const uint64_t CH = 1ull << 23;  // 8M reads = 64 MB up, 48 MB down per chunk
+    const uint64_t n_chunks = (n + CH - 1) / CH;
+    const int workers = (int)std::min<uint64_t>(HOST_WORKERS, n_chunks);
+    if (!lib->host_slots) lib->host_slots = new HostSlot[HOST_WORKERS];
+    HostSlot* slots = (HostSlot*)lib->host_slots;
+    for (int w = 0; w < workers; ++w) {
+        int rc = slot_reserve(slots[w], std::min(n, CH));
+        if (rc != BC_OK) return rc;
+    }
+    BC_HIP(hipDeviceSynchronize());
+    // pageable copies serialise inside the runtime; pinning the caller's buffers for the duration of a
+    // large call lets the three workers' transfers really overlap (BC_HOST_PIN=0 disables)
+    Pinned pinned;
+    if (workers > 1 && lib->knobs.host_pin) {
+        pinned.pin(h_reads, n * 8); pinned.pin(h_best_idx, n * 4); pinned.pin(h_flags, n);
+        pinned.pin(h_best_dist, n); pinned.pin(h_n_best, n);
+    }
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> first_rc{BC_OK};
+    std::string err;
+    std::mutex err_mutex;
+    auto work = [&](int w) {
+        HostSlot& s = slots[w];
+        auto fail = [&](int rc) {
+            int expect = BC_OK;
+            if (first_rc.compare_exchange_strong(expect, rc)) {
+                std::lock_guard<std::mutex> g(err_mutex);
+                err = bc_last_error();
+            }
+        };
+        if (hipSetDevice(lib->device) != hipSuccess) { set_error("hipSetDevice failed in a worker"); fail(BC_EHIP); return; }
+        auto step = [&](uint64_t a, uint64_t m) -> int {
+            BC_HIP(hipMemcpyAsync(s.d_r, h_reads + a, m * 8, hipMemcpyHostToDevice, s.st));
+            if (h_flags) BC_HIP(hipMemcpyAsync(s.d_f, h_flags + a, m, hipMemcpyHostToDevice, s.st));
+            MatchOut o{s.d_bi, h_best_dist ? s.d_bd : nullptr, h_n_best ? s.d_nb : nullptr, d_c, d_fs, first_index_base + a, PartOut{}};
+            int rc = launch_match(lib, s.d_r, h_flags ? s.d_f : nullptr, m, max_mismatch, algo, o, s.st);
+            if (rc != BC_OK) return rc;
+            BC_HIP(hipMemcpyAsync(h_best_idx + a, s.d_bi, m * 4, hipMemcpyDeviceToHost, s.st));
+            if (h_best_dist) BC_HIP(hipMemcpyAsync(h_best_dist + a, s.d_bd, m, hipMemcpyDeviceToHost, s.st));
+            if (h_n_best) BC_HIP(hipMemcpyAsync(h_n_best + a, s.d_nb, m, hipMemcpyDeviceToHost, s.st));
+            BC_HIP(hipStreamSynchronize(s.st));
+            return BC_OK;
+        };
+        for (;;) {
+            const uint64_t c = next.fetch_add(1);
+            if (c >= n_chunks || first_rc.load() != BC_OK) break;
+            const uint64_t a = c * CH, m = std::min(CH, n - a);
+            int rc = step(a, m);
+            if (rc != BC_OK) { fail(rc); break; }
+        }
+    };
+    if (workers == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < workers; ++w) th.emplace_back(work, w);
+        for (auto& t : th) t.join();
+    }
+    const int rc = first_rc.load();
+    if (rc != BC_OK) { set_error("%s", err.c_str()); return rc; }
+    BC_HIP(hipDeviceSynchronize());
+    return BC_OK;
+}
+
+__global__ void k_widen_counts(const uint32_t* __restrict__ c32, uint64_t* __restrict__ c64, uint32_t G) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) c64[g] = c32[g];
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -2048,6 +2285,14 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     BC_HIP(hipSetDevice(device));
     bc_lib* lib = new bc_lib();
     lib->device = device; lib->G = n_guides; lib->k = k; lib->kmask = km;
+    // experiment knobs: the environment is read here, once per library, never per launch
+    lib->knobs.lane = env_int("BC_LANE", 1);
+    lib->knobs.phase2_sm = env_int("BC_PHASE2_SM", 1);
+    lib->knobs.single_slab = env_int("BC_SINGLE_SLAB", 0);
+    lib->knobs.slab_lpr = env_int("BC_SLAB_LPR", 4);
+    lib->knobs.tally = env_int("BC_TALLY", 0);
+    lib->knobs.phase_prof = env_int("BC_PHASE_PROF", 0);
+    lib->knobs.host_pin = env_int("BC_HOST_PIN", 1);
     lib->h_guides.assign(h_guides, h_guides + n_guides);
     int rc = dev_upload(lib, lib->h_guides, &lib->d_guides);
     if (rc == BC_OK) rc = compute_nn(lib);
@@ -2061,8 +2306,10 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
 int bc_lib_destroy(bc_lib* lib) {
     if (!lib) return BC_OK;
     (void)hipSetDevice(lib->device);
+    (void)hipDeviceSynchronize();
     for (void* p : lib->owned) (void)hipFree(p);
-    for (void* p : {(void*)lib->q_reads, (void*)lib->q_idx, (void*)lib->q_count}) if (p) (void)hipFree(p);
+    for (auto& w : lib->ws)
+        for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile}) if (p) (void)hipFree(p);
     if (lib->host_slots) {
         HostSlot* hs = (HostSlot*)lib->host_slots;
         for (int w = 0; w < 3; ++w) {
@@ -2083,13 +2330,17 @@ int bc_lib_info(const bc_lib* lib, uint32_t* n_guides, int* k, int* device) {
     return BC_OK;
 }
 
+const char* bc_lib_last_kernel(const bc_lib* lib) {
+    return lib ? lib->last_kernel.load(std::memory_order_relaxed) : "";
+}
+
 int bc_match_dev(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
                  int max_mismatch, int algo, int32_t* d_best_idx, uint8_t* d_best_dist,
                  uint8_t* d_n_best, uint32_t* d_counts, uint64_t* d_first_seen,
                  uint64_t first_index_base, void* stream) {
     if (!lib || (n && (!d_reads || !d_best_idx))) { set_error("bc_match_dev: null argument"); return BC_EINVAL; }
     BC_HIP(hipSetDevice(lib->device));
-    MatchOut o{d_best_idx, d_best_dist, d_n_best, d_counts, d_first_seen, first_index_base};
+    MatchOut o{d_best_idx, d_best_dist, d_n_best, d_counts, d_first_seen, first_index_base, PartOut{}};
     return launch_match(lib, d_reads, d_flags, n, max_mismatch, algo, o, (hipStream_t)stream);
 }
 
@@ -2100,28 +2351,30 @@ int bc_match_time_dev(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_fla
     if (!lib || !ms_out || iters < 1) { set_error("bc_match_time_dev: bad argument"); return BC_EINVAL; }
     BC_HIP(hipSetDevice(lib->device));
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    BC_HIP(hipEventCreate(&e0));
-    BC_HIP(hipEventCreate(&e1));
-    MatchOut o{d_best_idx, d_best_dist, d_n_best, d_counts, d_first_seen, 0};
-    BC_HIP(hipEventRecord(e0, st));
+    Events ev;  // destroyed on every path
+    BC_HIP(hipEventCreate(&ev.e0));
+    BC_HIP(hipEventCreate(&ev.e1));
+    MatchOut o{d_best_idx, d_best_dist, d_n_best, d_counts, d_first_seen, 0, PartOut{}};
+    BC_HIP(hipEventRecord(ev.e0, st));
     int rc = BC_OK;
     for (int it = 0; it < iters && rc == BC_OK; ++it)
         rc = launch_match(lib, d_reads, d_flags, n, max_mismatch, algo, o, st);
-    BC_HIP(hipEventRecord(e1, st));
-    BC_HIP(hipEventSynchronize(e1));
+    BC_HIP(hipEventRecord(ev.e1, st));
+    BC_HIP(hipEventSynchronize(ev.e1));
+    if (rc != BC_OK) return rc;  // *ms_out untouched: there is nothing to report
     float ms = 0;
-    BC_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    BC_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *ms_out = ms / iters;
-    return rc;
+    return BC_OK;
 }
 
 int bc_match_all_dev(bc_lib* lib, const uint64_t* d_queries, const uint8_t* d_flags, uint64_t n,
                      int max_mismatch, bc_hit* d_hits, uint64_t cap, uint64_t* d_n_hits, void* stream) {
     if (!lib || !d_n_hits || (n && !d_queries) || (cap && !d_hits)) { set_error("bc_match_all_dev: null argument"); return BC_EINVAL; }
-    if (max_mismatch < 0 || max_mismatch >= MAX_SEG) { set_error("bc_match_all_dev: 0 <= max_mismatch <= %d", MAX_SEG - 1); return BC_EINVAL; }
+    if (max_mismatch < 0 || max_mismatch >= MAX_SEG || max_mismatch >= lib->k) {
+        set_error("bc_match_all_dev: 0 <= max_mismatch <= %d and < k", MAX_SEG - 1);
+        return BC_EINVAL;
+    }
     if (n > 0xFFFFFFFFull) { set_error("bc_match_all_dev: at most 2^32-1 queries per call"); return BC_EINVAL; }
     if (n == 0) return BC_OK;
     BC_HIP(hipSetDevice(lib->device));
@@ -2132,11 +2385,8 @@ int bc_match_all_dev(bc_lib* lib, const uint64_t* d_queries, const uint8_t* d_fl
     return BC_OK;
 }
 
-// Host buffers in, host results out.  The call is cut into chunks that HOST_WORKERS threads
-// take in turn, each with its own HIP stream and device staging slot (kept in the library
-// object between calls): while one worker copies results back, another uploads the next
-// chunk and a third one's kernels run, so H2D, compute and D2H overlap (PCIe is full duplex).
-// Counts / first-seen accumulate on the device across chunks and come back once.
+// Host buffers in, host results out (see match_host_chunks).  Counts / first-seen accumulate on the device across
+// chunks and come back once.
 int bc_match_host(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, uint64_t n,
                   int max_mismatch, int algo, int32_t* h_best_idx, uint8_t* h_best_dist,
                   uint8_t* h_n_best, uint64_t* h_counts, uint64_t* h_first_seen,
@@ -2155,101 +2405,214 @@ int bc_match_host(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, 
         }
         return BC_OK;
     }
-    constexpr int HOST_WORKERS = 3;
-    const uint64_t CH = 1ull << 23;  // 8M reads = 64 MB up, 48 MB down per chunk
-    const uint64_t n_chunks = (n + CH - 1) / CH;
-    // the two-kernel tuning variant shares one global miss queue per library: one worker only
-    const int workers = env_int("BC_TWO_STAGE", 1) == 2 ? 1 : (int)std::min<uint64_t>(HOST_WORKERS, n_chunks);
-    if (!lib->host_slots) lib->host_slots = new HostSlot[HOST_WORKERS];
-    HostSlot* slots = (HostSlot*)lib->host_slots;
     std::lock_guard<std::mutex> guard(lib->host_mutex);  // the staging slots belong to one call at a time
-    for (int w = 0; w < workers; ++w) {
-        int rc = slot_reserve(slots[w], std::min(n, CH));
-        if (rc != BC_OK) return rc;
-    }
-    uint32_t* d_c = nullptr;
-    uint64_t* d_fs = nullptr;
+    DevMem d_c, d_fs;  // freed on every path
     if (h_counts) {
-        BC_HIP(hipMalloc((void**)&d_c, (size_t)lib->G * 4));
-        BC_HIP(hipMemset(d_c, 0, (size_t)lib->G * 4));
+        int rc = d_c.alloc((size_t)lib->G * 4);
+        if (rc != BC_OK) return rc;
+        BC_HIP(hipMemset(d_c.p, 0, (size_t)lib->G * 4));
     }
     if (h_first_seen) {
-        BC_HIP(hipMalloc((void**)&d_fs, (size_t)lib->G * 8));
-        BC_HIP(hipMemset(d_fs, 0xFF, (size_t)lib->G * 8));
+        int rc = d_fs.alloc((size_t)lib->G * 8);
+        if (rc != BC_OK) return rc;
+        BC_HIP(hipMemset(d_fs.p, 0xFF, (size_t)lib->G * 8));
     }
-    BC_HIP(hipDeviceSynchronize());
-    // pageable copies serialise inside the runtime; pinning the caller's buffers for the duration of a
-    // large call lets the three workers' transfers really overlap (BC_HOST_PIN=0 disables)
-    std::vector<void*> pinned;
-    if (workers > 1 && env_int("BC_HOST_PIN", 1)) {
-        auto pin = [&](const void* p, size_t bytes) {
-            if (p && hipHostRegister((void*)p, bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back((void*)p);
-            else (void)hipGetLastError();
-        };
-        pin(h_reads, n * 8); pin(h_best_idx, n * 4); pin(h_flags, n); pin(h_best_dist, n); pin(h_n_best, n);
+    int rc = match_host_chunks(lib, h_reads, h_flags, n, max_mismatch, algo, h_best_idx, h_best_dist, h_n_best,
+                               (uint32_t*)d_c.p, (uint64_t*)d_fs.p, first_index_base);
+    if (rc != BC_OK) return rc;
+    if (d_c.p) {
+        std::vector<uint32_t> c32(lib->G);
+        BC_HIP(hipMemcpy(c32.data(), d_c.p, (size_t)lib->G * 4, hipMemcpyDeviceToHost));
+        for (uint32_t g = 0; g < lib->G; ++g) h_counts[g] += c32[g];
     }
-    std::atomic<uint64_t> next{0};
-    std::atomic<int> first_rc{BC_OK};
-    std::string err;
-    std::mutex err_mutex;
-    auto work = [&](int w) {
-        HostSlot& s = slots[w];
-        auto fail = [&](int rc) {
-            int expect = BC_OK;
-            if (first_rc.compare_exchange_strong(expect, rc)) {
-                std::lock_guard<std::mutex> g(err_mutex);
-                err = bc_last_error();
+    if (d_fs.p) {
+        std::vector<uint64_t> fs(lib->G);
+        BC_HIP(hipMemcpy(fs.data(), d_fs.p, (size_t)lib->G * 8, hipMemcpyDeviceToHost));
+        for (uint32_t g = 0; g < lib->G; ++g) h_first_seen[g] = std::min(h_first_seen[g], fs[g]);
+    }
+    return BC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-GPU, one process: a replica of the library per device, reads sharded in contiguous ranges, one all-reduce
+// (RCCL over xGMI: SUM of the count vectors, MIN of the first-seen indices) at the end — the C-ABI form of what
+// barcoder_amd/dist.py does with one process per GPU (heuristicount.py:703-737: Pool fan-out + Counter merge).
+// RCCL is resolved at run time (dlopen), so the library loads on hosts without it; it is required only when the
+// group spans several distinct devices.  A device listed more than once gets several replicas (rehearsal of the
+// sharding on a box with fewer GPUs); RCCL cannot put two ranks on one device, so such a group — and a group of
+// one — reduces through the host instead.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    typedef void* comm_t;
+    void* h = nullptr;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::mutex m;
+    bool load() {
+        std::lock_guard<std::mutex> g(m);
+        if (h) return true;
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return false;
+        CommInitAll = (int (*)(comm_t*, int, const int*))dlsym(h, "ncclCommInitAll");
+        CommDestroy = (int (*)(comm_t))dlsym(h, "ncclCommDestroy");
+        GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+        GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+        AllReduce = (int (*)(const void*, void*, size_t, int, int, comm_t, hipStream_t))dlsym(h, "ncclAllReduce");
+        GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        const bool ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce && GetErrorString;
+        if (!ok) { dlclose(h); h = nullptr; }
+        return ok;
+    }
+};
+Rccl g_rccl;
+constexpr int NCCL_UINT64 = 5, NCCL_SUM = 0, NCCL_MIN = 3;  // rccl.h: ncclDataType_t / ncclRedOp_t
+
+}  // namespace
+
+struct bc_multi {
+    std::vector<bc_lib*> libs;
+    std::vector<int> devices;
+    std::vector<Rccl::comm_t> comms;  // empty: reduce through the host
+    std::mutex call_mutex;
+};
+
+int bc_multi_destroy(bc_multi* m) {
+    if (!m) return BC_OK;
+    for (auto c : m->comms) if (c) (void)g_rccl.CommDestroy(c);
+    for (bc_lib* l : m->libs) bc_lib_destroy(l);
+    delete m;
+    return BC_OK;
+}
+
+int bc_multi_create(const uint64_t* h_guides, uint32_t n_guides, int k, const int* devices, int n_gpus, bc_multi** out) {
+    if (!out || n_gpus < 1 || n_gpus > 64) { set_error("bc_multi_create: bad argument (n_gpus=%d)", n_gpus); return BC_EINVAL; }
+    bc_multi* m = new bc_multi();
+    for (int i = 0; i < n_gpus; ++i) {
+        bc_lib* l = nullptr;
+        const int dev = devices ? devices[i] : i;
+        int rc = bc_lib_create(h_guides, n_guides, k, dev, &l);
+        if (rc != BC_OK) { bc_multi_destroy(m); return rc; }
+        m->libs.push_back(l);
+        m->devices.push_back(dev);
+    }
+    bool distinct = true;
+    for (int i = 0; i < n_gpus; ++i)
+        for (int j = 0; j < i; ++j) distinct = distinct && m->devices[i] != m->devices[j];
+    if (n_gpus > 1 && distinct) {
+        if (!g_rccl.load()) { bc_multi_destroy(m); set_error("bc_multi_create: librccl is not available"); return BC_ENODEV; }
+        m->comms.assign(n_gpus, nullptr);
+        int r = g_rccl.CommInitAll(m->comms.data(), n_gpus, m->devices.data());
+        if (r != 0) {
+            m->comms.clear();
+            bc_multi_destroy(m);
+            set_error("ncclCommInitAll: %s", g_rccl.GetErrorString(r));
+            return BC_EHIP;
+        }
+    }
+    *out = m;
+    return BC_OK;
+}
+
+int bc_multi_info(const bc_multi* m, int* n_gpus, int* uses_rccl) {
+    if (!m) { set_error("bc_multi_info: null"); return BC_EINVAL; }
+    if (n_gpus) *n_gpus = (int)m->libs.size();
+    if (uses_rccl) *uses_rccl = m->comms.empty() ? 0 : 1;
+    return BC_OK;
+}
+
+int bc_multi_gpu_match(bc_multi* m, const uint64_t* h_reads, const uint8_t* h_flags, uint64_t n, int max_mismatch,
+                       int algo, int32_t* h_best_idx, uint8_t* h_best_dist, uint8_t* h_n_best, uint64_t* h_counts,
+                       uint64_t* h_first_seen, uint64_t first_index_base) {
+    if (!m || (n && (!h_reads || !h_best_idx))) { set_error("bc_multi_gpu_match: null argument"); return BC_EINVAL; }
+    if (n == 0) return BC_OK;
+    std::lock_guard<std::mutex> call(m->call_mutex);
+    const int P = (int)m->libs.size();
+    const uint32_t G = m->libs[0]->G;
+    const uint64_t per = (n + P - 1) / P;
+    std::vector<DevMem> d_c(P), d_c64(P), d_fs(P);
+    std::vector<int> rcs(P, BC_OK);
+    std::vector<std::string> errs(P);
+    auto shard = [&](int i) {
+        bc_lib* lib = m->libs[i];
+        auto run = [&]() -> int {
+            BC_HIP(hipSetDevice(lib->device));
+            std::lock_guard<std::mutex> guard(lib->host_mutex);
+            int rc;
+            if ((rc = d_c[i].alloc((size_t)G * 4)) != BC_OK) return rc;
+            if ((rc = d_c64[i].alloc((size_t)G * 8)) != BC_OK) return rc;
+            if ((rc = d_fs[i].alloc((size_t)G * 8)) != BC_OK) return rc;
+            BC_HIP(hipMemset(d_c[i].p, 0, (size_t)G * 4));
+            BC_HIP(hipMemset(d_fs[i].p, 0xFF, (size_t)G * 8));
+            const uint64_t a = std::min(n, (uint64_t)i * per), b = std::min(n, a + per);
+            if (b > a) {
+                rc = match_host_chunks(lib, h_reads + a, h_flags ? h_flags + a : nullptr, b - a, max_mismatch, algo,
+                                       h_best_idx + a, h_best_dist ? h_best_dist + a : nullptr,
+                                       h_n_best ? h_n_best + a : nullptr, (uint32_t*)d_c[i].p, (uint64_t*)d_fs[i].p,
+                                       first_index_base + a);
+                if (rc != BC_OK) return rc;
             }
-        };
-        if (hipSetDevice(lib->device) != hipSuccess) { set_error("hipSetDevice failed in a worker"); fail(BC_EHIP); return; }
-        auto step = [&](uint64_t a, uint64_t m) -> int {
-            BC_HIP(hipMemcpyAsync(s.d_r, h_reads + a, m * 8, hipMemcpyHostToDevice, s.st));
-            if (h_flags) BC_HIP(hipMemcpyAsync(s.d_f, h_flags + a, m, hipMemcpyHostToDevice, s.st));
-            MatchOut o{s.d_bi, h_best_dist ? s.d_bd : nullptr, h_n_best ? s.d_nb : nullptr, d_c, d_fs, first_index_base + a};
-            int rc = launch_match(lib, s.d_r, h_flags ? s.d_f : nullptr, m, max_mismatch, algo, o, s.st);
-            if (rc != BC_OK) return rc;
-            BC_HIP(hipMemcpyAsync(h_best_idx + a, s.d_bi, m * 4, hipMemcpyDeviceToHost, s.st));
-            if (h_best_dist) BC_HIP(hipMemcpyAsync(h_best_dist + a, s.d_bd, m, hipMemcpyDeviceToHost, s.st));
-            if (h_n_best) BC_HIP(hipMemcpyAsync(h_n_best + a, s.d_nb, m, hipMemcpyDeviceToHost, s.st));
-            BC_HIP(hipStreamSynchronize(s.st));
+            hipLaunchKernelGGL(k_widen_counts, dim3((G + 255) / 256), dim3(256), 0, 0, (const uint32_t*)d_c[i].p,
+                               (uint64_t*)d_c64[i].p, G);
+            BC_HIP(hipGetLastError());
+            BC_HIP(hipDeviceSynchronize());
             return BC_OK;
         };
-        for (;;) {
-            const uint64_t c = next.fetch_add(1);
-            if (c >= n_chunks || first_rc.load() != BC_OK) break;
-            const uint64_t a = c * CH, m = std::min(CH, n - a);
-            int rc = step(a, m);
-            if (rc != BC_OK) { fail(rc); break; }
-        }
+        rcs[i] = run();
+        if (rcs[i] != BC_OK) errs[i] = bc_last_error();
     };
-    if (workers == 1) {
-        work(0);
+    if (P == 1) {
+        shard(0);
     } else {
         std::vector<std::thread> th;
-        for (int w = 0; w < workers; ++w) th.emplace_back(work, w);
+        for (int i = 0; i < P; ++i) th.emplace_back(shard, i);
         for (auto& t : th) t.join();
     }
-    int rc = first_rc.load();
-    if (rc != BC_OK) set_error("%s", err.c_str());
-    auto finish = [&]() -> int {
-        BC_HIP(hipDeviceSynchronize());
-        if (d_c) {
-            std::vector<uint32_t> c32(lib->G);
-            BC_HIP(hipMemcpy(c32.data(), d_c, (size_t)lib->G * 4, hipMemcpyDeviceToHost));
-            for (uint32_t g = 0; g < lib->G; ++g) h_counts[g] += c32[g];
+    for (int i = 0; i < P; ++i)
+        if (rcs[i] != BC_OK) { set_error("GPU %d: %s", m->devices[i], errs[i].c_str()); return rcs[i]; }
+    std::vector<uint64_t> c64(G), fs(G);
+    if (!m->comms.empty()) {
+        // one all-reduce of each vector over RCCL / xGMI; every device ends with the job-wide result
+        int r = g_rccl.GroupStart();
+        for (int i = 0; i < P && r == 0; ++i) {
+            BC_HIP(hipSetDevice(m->devices[i]));
+            r = g_rccl.AllReduce(d_c64[i].p, d_c64[i].p, G, NCCL_UINT64, NCCL_SUM, m->comms[i], 0);
+            if (r == 0) r = g_rccl.AllReduce(d_fs[i].p, d_fs[i].p, G, NCCL_UINT64, NCCL_MIN, m->comms[i], 0);
         }
-        if (d_fs) {
-            std::vector<uint64_t> fs(lib->G);
-            BC_HIP(hipMemcpy(fs.data(), d_fs, (size_t)lib->G * 8, hipMemcpyDeviceToHost));
-            for (uint32_t g = 0; g < lib->G; ++g) h_first_seen[g] = std::min(h_first_seen[g], fs[g]);
+        const int r2 = g_rccl.GroupEnd();
+        if (r == 0) r = r2;
+        if (r != 0) { set_error("ncclAllReduce: %s", g_rccl.GetErrorString(r)); return BC_EHIP; }
+        for (int i = 0; i < P; ++i) {
+            BC_HIP(hipSetDevice(m->devices[i]));
+            BC_HIP(hipDeviceSynchronize());
         }
-        return BC_OK;
-    };
-    if (rc == BC_OK) rc = finish();
-    for (void* p : pinned) (void)hipHostUnregister(p);
-    if (d_c) (void)hipFree(d_c);
-    if (d_fs) (void)hipFree(d_fs);
-    return rc;
+        BC_HIP(hipSetDevice(m->devices[0]));
+        BC_HIP(hipMemcpy(c64.data(), d_c64[0].p, (size_t)G * 8, hipMemcpyDeviceToHost));
+        BC_HIP(hipMemcpy(fs.data(), d_fs[0].p, (size_t)G * 8, hipMemcpyDeviceToHost));
+        for (uint32_t g = 0; g < G; ++g) {
+            if (h_counts) h_counts[g] += c64[g];
+            if (h_first_seen) h_first_seen[g] = std::min(h_first_seen[g], fs[g]);
+        }
+    } else {
+        for (int i = 0; i < P; ++i) {
+            BC_HIP(hipSetDevice(m->devices[i]));
+            BC_HIP(hipMemcpy(c64.data(), d_c64[i].p, (size_t)G * 8, hipMemcpyDeviceToHost));
+            BC_HIP(hipMemcpy(fs.data(), d_fs[i].p, (size_t)G * 8, hipMemcpyDeviceToHost));
+            for (uint32_t g = 0; g < G; ++g) {
+                if (h_counts) h_counts[g] += c64[g];
+                if (h_first_seen) h_first_seen[g] = std::min(h_first_seen[g], fs[g]);
+            }
+        }
+    }
+    return BC_OK;
 }
 
 int bc_synth_reads_dev(bc_lib* lib, uint64_t seed, uint64_t first_index, uint64_t n, int mixture,

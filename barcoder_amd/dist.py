@@ -3,15 +3,27 @@ count vector (and one MIN all-reduce of first-seen indices) at the end.
 
 Replaces the Pool fan-out and Counter merge of heuristicount.py:703-737.  One
 process per GPU; torch.distributed's "nccl" backend is RCCL over xGMI on ROCm,
-"gloo" is used by the CPU tests.  There is no data-path collective besides the
-final reduction: shards are independent."""
+"gloo" is used by the CPU tests (and by BC_DIST_BACKEND=gloo, which lets one GPU
+rehearse the N > 1 path).  There is no data-path collective besides the final
+reduction: shards are independent.
+
+Product entry points that use this module: bench.py (`--gpus N`) and
+`python -m barcoder_amd.heuristicount --gpus N`.  Both start their own ranks with
+`launch_workers` when no launcher (torchrun) has exported WORLD_SIZE; the parent
+process never touches the GPU, the children are fresh interpreters.
+
+Importing this module does not import torch or the native library."""
 from __future__ import annotations
 
 import os
+import socket
+import subprocess
+import sys
 
 import numpy as np
 
 I64_MAX = np.iinfo(np.int64).max
+U64_MAX = np.iinfo(np.uint64).max
 
 
 def shard_range(n_total: int, rank: int, world: int):
@@ -21,60 +33,177 @@ def shard_range(n_total: int, rank: int, world: int):
     return a, min(n_total, a + per)
 
 
+def under_launcher() -> bool:
+    """True when a launcher (torchrun or launch_workers) has described the process group."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_workers(argv, nproc: int, env=None, timeout=None) -> int:
+    """Start `nproc` ranks of `python argv...` on this node (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment) and wait for
+    them.  Rank 0 inherits stdout; the other ranks' stdout goes to stderr, so a
+    caller that prints one result line on rank 0 keeps a clean stdout.  Returns
+    the first non-zero exit status (the remaining ranks are terminated), else 0.
+
+    The calling process must not have initialised the GPU: the children are
+    fresh interpreters (no fork of a HIP context, no exec from a GPU process)."""
+    if nproc < 1:
+        raise ValueError("launch_workers: nproc must be >= 1")
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base["MASTER_PORT"] = str(free_port())
+    base["WORLD_SIZE"] = str(nproc)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    procs = []
+    try:
+        for r in range(nproc):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            out = None if r == 0 else sys.stderr
+            procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, stdout=out))
+        rc = 0
+        import time
+        t0 = time.monotonic()
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                st = p.poll()
+                if st is None:
+                    continue
+                alive.remove(p)
+                if st != 0 and rc == 0:
+                    rc = st
+                    for q in alive:  # a failed rank would leave the others waiting in a collective
+                        q.terminate()
+            if alive:
+                if timeout is not None and time.monotonic() - t0 > timeout:
+                    rc = rc or 124
+                    for q in alive:
+                        q.terminate()
+                    timeout = None
+                time.sleep(0.05)
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+
+
 def init_from_env(backend: str | None = None):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun
+    or launch_workers).  Returns (rank, world, local device index)."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    have_gpu = torch.cuda.is_available()
+    if have_gpu:
+        # fewer devices than ranks (BC_DIST_BACKEND=gloo rehearsal on one GPU): ranks share devices
+        local = local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend is None:  # BC_DIST_BACKEND=gloo lets one GPU rehearse the N > 1 path
-            backend = os.environ.get("BC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():
-            local = local % max(torch.cuda.device_count(), 1)
-            torch.cuda.set_device(local)
+        if backend is None:
+            backend = os.environ.get("BC_DIST_BACKEND") or ("nccl" if have_gpu else "gloo")
+        if backend == "nccl" and have_gpu and torch.cuda.device_count() < world:
+            raise RuntimeError(f"{world} ranks over RCCL need {world} GPUs, {torch.cuda.device_count()} visible "
+                               "(set BC_DIST_BACKEND=gloo to rehearse on fewer)")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if torch.cuda.is_available():
-        local = local % max(torch.cuda.device_count(), 1)
     return rank, world, local
+
+
+def _group_backend():
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
 def reduce_counts(counts, first_seen=None, device=None):
     """All-reduce SUM of int64 counts[G] and MIN of int64 first_seen[G] (I64_MAX
-    = unseen) across the group; returns numpy arrays on every rank.  Accepts
-    numpy arrays or torch tensors (tensors are reduced in place on their device)."""
+    = unseen) across the group.  numpy arrays in -> numpy arrays out on every
+    rank; torch tensors are reduced in place on their device (staged through the
+    host when the group's backend is gloo and the tensor lives on a GPU)."""
     import torch
     import torch.distributed as dist
     is_np = isinstance(counts, np.ndarray)
     if is_np:
         c = torch.from_numpy(np.ascontiguousarray(counts).astype(np.int64))
         f = None if first_seen is None else torch.from_numpy(
-            np.minimum(np.ascontiguousarray(first_seen), np.uint64(I64_MAX)).astype(np.int64))
-        if device is not None:
+            np.minimum(np.ascontiguousarray(first_seen).astype(np.uint64), np.uint64(I64_MAX)).astype(np.int64))
+        if device is not None and _group_backend() == "nccl":  # RCCL reduces device tensors
+            device = torch.device("cuda", device) if isinstance(device, int) else device
             c = c.to(device)
             f = None if f is None else f.to(device)
     else:
         c, f = counts, first_seen
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        if f is not None:
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        gloo_on_gpu = _group_backend() == "gloo" and c.is_cuda
+        for t, op in ((c, dist.ReduceOp.SUM), (f, dist.ReduceOp.MIN)):
+            if t is None:
+                continue
+            if gloo_on_gpu:
+                h = t.cpu()
+                dist.all_reduce(h, op=op)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=op)
     if is_np:
         return c.cpu().numpy(), (None if f is None else f.cpu().numpy())
     return c, f
 
 
+def reduce_scalar_max(x: float, device=None) -> float:
+    """MAX over ranks of one float (bench timing)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return float(x)
+    dev = device if (device is not None and _group_backend() == "nccl") else "cpu"
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def gather_objects(obj):
+    """Every rank's picklable `obj` as a list on every rank (small, variable-length results:
+    undocumented k-mer tables, odd string events)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def count_sharded(n_total: int, match_shard, n_guides: int, rank: int, world: int, device=None):
-    """Run `match_shard(a, b) -> (counts uint64[G], first_seen uint64[G])` on this
-    rank's read range and combine over ranks.  `first_seen` carries GLOBAL read
-    indices, so MIN over ranks is the job-wide first occurrence."""
+    """Run `match_shard(a, b) -> (counts[G], first_seen[G])` on this rank's read
+    range and combine over ranks.  `first_seen` carries GLOBAL read indices, so
+    MIN over ranks is the job-wide first occurrence.  numpy arrays (uint64,
+    U64_MAX = unseen) or torch int64 tensors (reduced in place)."""
     a, b = shard_range(n_total, rank, world)
     if b > a:
         counts, first_seen = match_shard(a, b)
     else:
         counts = np.zeros(n_guides, np.uint64)
-        first_seen = np.full(n_guides, np.iinfo(np.uint64).max, np.uint64)
+        first_seen = np.full(n_guides, U64_MAX, np.uint64)
     return reduce_counts(counts, first_seen, device=device)
+
+
+def shutdown():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

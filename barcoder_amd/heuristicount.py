@@ -498,10 +498,42 @@ def process_chunk(chunk, bcs_with_flanks_fwd, bcs_with_flanks_rev, L_fwd_start, 
 
 
 # ------------------------------------------------------------------------------ driver
-def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch: int = 0):
+def merge_undocumented(tables):
+    """[(words, counts, first), ...] -> one table: unique packed windows with summed counts and
+    the smallest first index (any order of the input tables: ranks, chunks)."""
+    tables = [t for t in tables if t[0] is not None and t[0].size]
+    if not tables:
+        z = np.zeros(0, np.uint64)
+        return z, z, z
+    w = np.concatenate([t[0] for t in tables])
+    c = np.concatenate([t[1] for t in tables]).astype(np.uint64)
+    f = np.concatenate([t[2] for t in tables]).astype(np.uint64)
+    order = np.lexsort((f, w))
+    w, c, f = w[order], c[order], f[order]
+    starts = np.flatnonzero(np.concatenate(([True], w[1:] != w[:-1])))
+    return w[starts], np.add.reduceat(c, starts), f[starts]
+
+
+def shard_plan(file1, file2, world: int) -> str:
+    """How the bulk pass is split over `world` ranks: "bytes" = byte ranges of one uncompressed
+    single-end file (every rank reads only its part); "stride" = chunk c belongs to rank
+    c % world (compressed or paired input: every rank decodes the stream, the per-read work
+    — windows, match, tally — is split)."""
+    plain = not file1.endswith((".gz", ".zst"))
+    return "bytes" if (world > 1 and not file2 and plain) else "stride"
+
+
+def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch: int = 0, rank: int = 0,
+                   world: int = 1, chunk_reads: int = 1 << 20):
     """Everything main() computes, returned instead of printed: dict with
     doc (first-seen ordered {barcode: count}), undoc Counter, total_reads, and
-    the discovered geometry."""
+    the discovered geometry.
+
+    rank / world: this process is one of `world` ranks of a torch.distributed group (one per
+    GPU, barcoder_amd.dist): the bulk pass covers this rank's shard and the per-guide counts /
+    first-seen keys are all-reduced (dist.count_sharded), which replaces the Pool fan-out and
+    Counter merge of heuristicount.py:703-737.  Every rank returns the job-wide result."""
+    from . import dist as D
     barcodes = read_fasta(fasta_file)
     validate_barcodes(barcodes)
     lengths = {len(b) for b in barcodes}
@@ -549,31 +581,67 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     log.info("Executing high-throughput read analysis...")
     cc = ChunkCounter(ordered, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
                       device=device, max_mismatch=max_mismatch)
-    total_reads = 0
     G = len(cc.labels)
-    counts = np.zeros(G, np.uint64)
-    first_seen = np.full(G, np.iinfo(np.uint64).max, np.uint64)
-    u_words, u_counts, u_first, odd_events = [], [], [], []
-    # bulk pass: native reader (bc_reader_*) -> bc_pack_windows -> GPU match, 1M reads at a time;
-    # per-chunk results stay in array form and are merged once at the end
+    plan = shard_plan(file1, file2, world)
+    undoc_tables, odd_events = [], []
+    n_mine = [0]
+    t_bulk = [0.0]
     from .ingest import NativeReader
-    with NativeReader(file1) as r1, (NativeReader(file2) if is_paired else nullcontext()) as r2:
-        while True:
-            b1 = r1.next()
-            n1 = b1[1].size - 1
-            b2 = None
-            if r2 is not None:
-                b2 = r2.next(max(n1, 1))  # same number of mates; a shorter file ends the pairing with a ValueError
-            if n1 == 0 and (b2 is None or b2[1].size <= 1):
-                break
-            res = cc.match_buffers(b1 if n1 else None, b2 if (b2 is not None and b2[1].size > 1) else None,
-                                   first_index=total_reads)
-            total_reads += res.n
-            if res.n:
-                counts += res.counts
-                np.minimum(first_seen, res.first_seen, out=first_seen)
-                u_words.append(res.u_words); u_counts.append(res.u_counts); u_first.append(res.u_first)
-                odd_events += res.odd_events
+    import time as _time
+
+    def bulk(a, b):
+        """dist.count_sharded's match_shard.  Plan "bytes": [a, b) is a byte range of file1; plan
+        "stride": [a, b) are the chunk residues (c % world) this rank owns (everything when world = 1).
+        Native reader (bc_reader_*) -> bc_pack_windows -> GPU match, 1M reads at a time; per-chunk results
+        stay in array form and are merged once at the end.  The first-seen key of a read is its global
+        index (stride) or the file offset of its chunk + its position in the chunk (bytes): both grow
+        with the read's position in the file, which is all the output order needs."""
+        counts = np.zeros(G + 1, np.uint64)  # last element: reads seen by this rank
+        first_seen = np.full(G + 1, np.iinfo(np.uint64).max, np.uint64)
+        t0 = _time.perf_counter()
+        rng = (a, b) if plan == "bytes" else None
+        seen = 0
+        with NativeReader(file1, max_reads=chunk_reads, byte_range=rng) as r1, \
+                (NativeReader(file2, max_reads=chunk_reads) if is_paired else nullcontext()) as r2:
+            c = 0
+            while True:
+                key = r1.tell() if plan == "bytes" else seen
+                b1 = r1.next()
+                n1 = b1[1].size - 1
+                b2 = None
+                if r2 is not None:
+                    b2 = r2.next(max(n1, 1))  # same number of mates; a shorter file ends the pairing with a ValueError
+                n2 = 0 if b2 is None else b2[1].size - 1
+                if n1 == 0 and n2 == 0:
+                    break
+                if n1 and n2 and n1 != n2:  # every rank sees this, whoever owns the chunk
+                    raise ValueError("Length of reads1 and reads2 must be the same for paired-end data.")
+                mine = plan == "bytes" or (a <= c % world < b)
+                c += 1
+                seen += max(n1, n2)
+                if not mine:
+                    continue
+                res = cc.match_buffers(b1 if n1 else None, b2 if n2 else None, first_index=key)
+                n_mine[0] += res.n
+                if res.n:
+                    counts[:G] += res.counts
+                    np.minimum(first_seen[:G], res.first_seen, out=first_seen[:G])
+                    undoc_tables.append((res.u_words, res.u_counts, res.u_first))
+                    odd_events.extend(res.odd_events)
+        counts[G] = n_mine[0]
+        t_bulk[0] = _time.perf_counter() - t0
+        return counts, first_seen
+
+    n_units = os.path.getsize(file1) if plan == "bytes" else world
+    counts, first_seen = D.count_sharded(n_units, bulk, G + 1, rank, world, device=device)
+    total_reads = int(counts[G])
+    counts, first_seen = counts[:G], first_seen[:G]
+    mine_u = merge_undocumented(undoc_tables)
+    if world > 1:  # variable-length leftovers: undocumented windows and odd (string) events of every rank
+        parts = D.gather_objects((mine_u, odd_events))
+        mine_u = merge_undocumented([p[0] for p in parts])
+        odd_events = [e for p in parts for e in p[1]]
+    uw, uc, uf = mine_u
     # documented: first-seen order (heuristicount.py:876-877 prints Counter insertion order)
     doc_events = [(int(f), cc.labels[g], int(c)) for g, c, f in
                   zip(np.flatnonzero(counts).tolist(), counts[counts > 0].tolist(), first_seen[counts > 0].tolist())]
@@ -586,19 +654,11 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     doc = Counter()
     for _f, key, c in sorted(doc_events, key=lambda e: e[0]):
         doc[key] += c
-    if u_words:
-        # chunks arrive in read order and each holds its own minimum, so the first occurrence of a
-        # word in the concatenation carries its global first index
-        w = np.concatenate(u_words)
-        uw, first_at, inv = np.unique(w, return_index=True, return_inverse=True)
-        uc = np.bincount(inv, weights=np.concatenate(u_counts).astype(np.float64), minlength=uw.size).astype(np.uint64)
-        uf = np.concatenate(u_first)[first_at]
-    else:
-        uw = uc = uf = np.zeros(0, np.uint64)
     undoc = PackedCounter(bc_len, uw, uc, uf, extra_undoc)
     return dict(doc=doc, undoc=undoc, total_reads=total_reads, barcodes=barcodes, bc_len=bc_len,
                 bc_start1=bc_start1, bc_start2=bc_start2, flanks_fwd=(L_fwd, R_fwd), flanks_rev=(L_rev, R_rev),
-                need_swap=need_swap, forward_name=fwd_name, reverse_name=rev_name)
+                need_swap=need_swap, forward_name=fwd_name, reverse_name=rev_name, shard_plan=plan,
+                bulk_mreads_per_s=(n_mine[0] / t_bulk[0] / 1e6 if t_bulk[0] > 0 else None))
 
 
 def summary_lines(r, fasta_file):
@@ -625,14 +685,18 @@ def summary_lines(r, fasta_file):
     return out
 
 
-def main(args, device: int = 0):
+def main(args, device: int = 0, rank: int = 0, world: int = 1):
     """Same contract as heuristicount.main: log to stderr, `barcode<TAB>count`
     for documented barcodes in first-seen order on stdout, errors logged and
-    swallowed (heuristicount.py:882-888)."""
+    swallowed (heuristicount.py:882-888).  With world > 1 every rank computes,
+    rank 0 prints."""
     log.info("Initializing heuristic barcode counting...")
     try:
         r = count_barcodes(args.fasta_file, args.file1, args.file2, device=device,
-                           max_mismatch=getattr(args, "mismatches", 0))
+                           max_mismatch=getattr(args, "mismatches", 0), rank=rank, world=world,
+                           chunk_reads=getattr(args, "chunk_reads", 1 << 20))
+        if rank != 0:
+            return
         for line in summary_lines(r, args.fasta_file):
             print(line, file=sys.stderr)
         for barcode, count in r["doc"].items():
@@ -650,9 +714,29 @@ def _cli():
     p.add_argument("file2", type=str, nargs="?", default=None, help="Second reads file: FASTQ or raw reads (optional).")
     p.add_argument("--mismatches", type=int, default=0, help="count reads within this many substitutions (extension)")
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--chunk-reads", type=int, default=1 << 20, help="reads per device pass (default 1048576)")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="ranks (one per GPU) the bulk pass is sharded over; replaces the reference's Pool fan-out")
     a = p.parse_args()
     logging.basicConfig(level=logging.INFO, stream=sys.stderr, format="%(levelname)s %(message)s")
-    main(a, device=a.device)
+    from . import dist as D
+    if a.gpus > 1 and not D.under_launcher():
+        # start the ranks as fresh processes; this parent never touches the GPU
+        env = dict(os.environ)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        raise SystemExit(D.launch_workers(["-m", "barcoder_amd.heuristicount"] + sys.argv[1:], a.gpus, env=env))
+    if D.under_launcher():
+        rank, world, local = D.init_from_env()
+        if rank != 0:
+            logging.getLogger().setLevel(logging.WARNING)
+        try:
+            main(a, device=local, rank=rank, world=world)
+        finally:
+            D.barrier()
+            D.shutdown()
+    else:
+        main(a, device=a.device)
 
 
 if __name__ == "__main__":

@@ -11,9 +11,15 @@ from . import _native as N
 
 
 class NativeReader:
-    def __init__(self, path: str, max_reads: int = 1 << 20, bytes_per_read: int = 192):
+    def __init__(self, path: str, max_reads: int = 1 << 20, bytes_per_read: int = 192, byte_range=None):
+        """byte_range=(begin, end): only the records that start in that byte range of an
+        uncompressed file (one rank's shard, bc_reader_open_range)."""
         self._h = N.vp()
-        N.check(N.load().bc_reader_open(path.encode(), C.byref(self._h)))
+        if byte_range is None:
+            N.check(N.load().bc_reader_open(path.encode(), C.byref(self._h)))
+        else:
+            N.check(N.load().bc_reader_open_range(path.encode(), int(byte_range[0]), int(byte_range[1]),
+                                                  C.byref(self._h)))
         self.max_reads = int(max_reads)
         self._text = np.empty(self.max_reads * bytes_per_read, np.uint8)
         self._off = np.empty(self.max_reads + 1, np.uint64)
@@ -29,6 +35,12 @@ class NativeReader:
             break
         k = int(n.value)
         return self._text[:int(self._off[k])], self._off[:k + 1]
+
+    def tell(self) -> int:
+        """Offset of the next unread byte in the decoded stream (bc_reader_tell)."""
+        v = C.c_uint64(0)
+        N.check(N.load().bc_reader_tell(self._h, C.byref(v)))
+        return int(v.value)
 
     def next(self, max_reads: int | None = None):
         """(text uint8[...], off uint64[n+1]); n = min(max_reads, reads left in the

@@ -163,6 +163,11 @@ class DeviceLibrary:
     def size(self) -> int:
         return int(self.packed.size)
 
+    @property
+    def last_kernel(self) -> str:
+        """Name of the match kernel the last call on this library launched (bc_lib_last_kernel)."""
+        return (N.load().bc_lib_last_kernel(self.handle) or b"").decode()
+
     def close(self):
         if self.handle:
             N.load().bc_lib_destroy(self.handle)

@@ -118,3 +118,45 @@ class GpuMatcher:
                 if p:
                     L.bc_dev_free(p)
         return np.sort(hits, order=("query", "guide"))
+
+
+class MultiGpuMatcher:
+    """One process, several GPUs: `bc_multi_*` — a replica of the library per device, contiguous
+    read shards, one RCCL all-reduce of counts (SUM) and first-seen (MIN) at the end.  The
+    single-process form of barcoder_amd.dist (heuristicount.py:703-737, Pool fan-out + merge).
+    `devices` may repeat a device (rehearsal on fewer GPUs; the reduction then goes through the host)."""
+
+    def __init__(self, packed, k: int, devices):
+        packed = np.ascontiguousarray(packed, np.uint64)
+        self.size, self.k = int(packed.size), int(k)
+        devs = np.ascontiguousarray(devices, np.int32)
+        self.handle = N.vp()
+        N.check(N.load().bc_multi_create(N.ptr(packed), packed.size, self.k, N.ptr(devs), devs.size, C.byref(self.handle)))
+        ng, ur = C.c_int(0), C.c_int(0)
+        N.check(N.load().bc_multi_info(self.handle, C.byref(ng), C.byref(ur)))
+        self.n_gpus, self.uses_rccl = ng.value, bool(ur.value)
+
+    def match(self, reads, flags=None, max_mismatch: int = 0, algo: str = "auto", first_index: int = 0) -> MatchResult:
+        reads = np.ascontiguousarray(reads, np.uint64)
+        n, G = reads.size, self.size
+        if flags is not None:
+            flags = np.ascontiguousarray(flags, np.uint8)
+            if flags.size != n:
+                raise ValueError("flags and reads differ in length")
+        bi, bd, nb = np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        counts, first_seen = np.zeros(G, np.uint64), np.full(G, U64_MAX, np.uint64)
+        N.check(N.load().bc_multi_gpu_match(self.handle, N.ptr(reads), N.ptr(flags), n, int(max_mismatch), N.ALGOS[algo],
+                                            N.ptr(bi), N.ptr(bd), N.ptr(nb), N.ptr(counts), N.ptr(first_seen),
+                                            int(first_index)))
+        return MatchResult(bi, bd, nb, counts, first_seen)
+
+    def close(self):
+        if self.handle:
+            N.load().bc_multi_destroy(self.handle)
+            self.handle = N.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -6,17 +6,23 @@ Workload (BASELINE.json configs[2]): library of 1e5 distinct
 random), generated on the device by the seeded splitmix64 stream so they are
 resident in HBM before the timed region.  A step = one pass of the matcher over
 the rank's reads (best index + distance + n_best + per-guide counts + first-seen)
-followed, for N > 1, by the RCCL all-reduce of the count vector.
+followed, for N > 1, by the all-reduce (RCCL) of the count vector and of the
+first-seen indices: barcoder_amd.dist.count_sharded, the same function
+`python -m barcoder_amd.heuristicount --gpus N` uses.
+
+`python bench.py --gpus N` from a bare shell starts its own N ranks (fresh child
+processes, before anything in this process touches the GPU); under torchrun it
+joins the group the launcher describes.
 
 Prints ONE JSON line on rank 0 (see the contract in DESIGN.md "Measurement").
 """
 import argparse
+import importlib.util
 import json
 import os
+import statistics
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,8 +34,17 @@ MAX_MM = 2
 G = 100_000
 
 
+def _dist_module_without_package():
+    """barcoder_amd/dist.py loaded by path: the launching parent needs neither torch nor the native library."""
+    spec = importlib.util.spec_from_file_location("_bc_dist_launcher", os.path.join(ROOT, "barcoder_amd", "dist.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def ascii_from_packed(packed, k):
     """plane-form uint64 k-mers -> (n, k) uint8 ASCII array (what the string-based oracle reads)"""
+    import numpy as np
     p = np.ascontiguousarray(packed, np.uint64)
     sh = np.arange(k, dtype=np.uint64)
     out = np.empty((p.size, k), np.uint8)
@@ -46,6 +61,7 @@ def cpu_baseline(lib_packed, n_sample, seed, max_mm):
     """The CPU port of the same job on the first reads of the same stream: oracle.c's pigeonhole-indexed best-hit
     search (strings, OpenMP, all host cores), sized from a probe to ~10 s of CPU work; the brute-force sweep the
     oracle is defined by runs on a prefix (~5 s) and must agree with it."""
+    import numpy as np
     from barcoder_amd import synth as S
     from oracle import oracle as orc
     la = ascii_from_packed(lib_packed, K)
@@ -75,6 +91,123 @@ def cpu_baseline(lib_packed, n_sample, seed, max_mm):
                             indexed_equals_brute_force_on_prefix=bool(same))
 
 
+def secondary_workloads(torch, dev, local, stream, lib_packed, matcher, n, steps):
+    """The other BASELINE configurations and the host-inclusive rates, measured after the timed region (rank 0,
+    N = 1).  Each entry is bounded to a few seconds and reports its own failure instead of taking the headline down."""
+    import numpy as np
+    from barcoder_amd import synth as S
+    out = {}
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001 - a secondary number must never hide the headline
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+
+    def exact():  # BASELINE configs[1]: exact match, 1e5 guides, 1e8 reads, HBM-resident
+        reads = torch.empty(n, dtype=torch.int64, device=dev)
+        bi = torch.empty(n, dtype=torch.int32, device=dev)
+        bd = torch.empty(n, dtype=torch.uint8, device=dev)
+        nb = torch.empty(n, dtype=torch.uint8, device=dev)
+        c32 = torch.zeros(lib_packed.size, dtype=torch.int32, device=dev)
+        fs = torch.full((lib_packed.size,), -1, dtype=torch.int64, device=dev)
+        matcher.synth_reads_dev(1, 0, n, 0, reads.data_ptr(), stream)
+        kw = dict(d_best_dist=bd.data_ptr(), d_n_best=nb.data_ptr(), stream=stream)
+        matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=2, **kw)
+        k_ms = matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=max(3, steps), **kw)
+        p_ms = matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=max(3, steps),
+                                d_counts=c32.data_ptr(), d_first_seen=fs.data_ptr(), **kw)
+        hit = float((bi >= 0).float().mean().item())
+        return {"workload": f"20-mer exact match, {lib_packed.size} guides, {n} reads (BASELINE configs[1])",
+                "kernel": "k_match_hash", "kernel_ms": k_ms, "pass_ms": p_ms, "Mreads_per_s": n / p_ms / 1e3,
+                "frac": n * ALGO_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "pass_frac": n * ALGO_BYTES / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "matched_fraction": hit}
+
+    def pam():  # BASELINE configs[3]: NGG / 20-mer site scan over an E. coli-sized genome
+        from barcoder_amd import _native as N, pam as P
+        from barcoder_amd.devmem import DevBuf
+        from barcoder_amd.encoding import pam_masks
+        L = N.load()
+        bp = 4_641_652
+        g = P.pack_genome(S.genome(bp, seed=4), wrap=22)
+        masks = pam_masks("NGG")
+        nw = g.bases.size
+        iters = 500
+        with DevBuf.from_numpy(g.bases, local) as d_b, DevBuf.from_numpy(g.invalid, local) as d_i, \
+                DevBuf(nw * 4, local) as d_f, DevBuf(nw * 4, local) as d_r:
+            for _ in range(3):
+                N.check(L.bc_pam_scan_dev(d_b.ptr, d_i.ptr, g.total, N.ptr(masks), 3, d_f.ptr, d_r.ptr, None))
+            N.check(L.bc_dev_sync(None))
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                N.check(L.bc_pam_scan_dev(d_b.ptr, d_i.ptr, g.total, N.ptr(masks), 3, d_f.ptr, d_r.ptr, None))
+            N.check(L.bc_dev_sync(None))
+            dt = (time.perf_counter() - t0) / iters
+        P.find_sites(g, "NGG", 20)
+        t0 = time.perf_counter()
+        st = P.find_sites(g, "NGG", 20)
+        pipe = time.perf_counter() - t0
+        byts = nw * (8 + 4 + 4 + 4)
+        return {"workload": f"NGG site scan, both strands, {bp} bp synthetic circular genome (BASELINE configs[3])",
+                "kernel": "k_pam_scan", "us_per_scan": dt * 1e6, "Gbp_per_s": bp / dt / 1e9,
+                "frac": byts / dt / 1e9 / HBM_PEAK_GBPS, "note": "launch-bound at this size",
+                "find_sites_ms_incl_h2d_d2h": pipe * 1e3, "sites": int(st.start.size)}
+
+    def host_pcie():  # bc_match_host: host buffers in, host results out (PCIe included), <= 2 mismatches
+        m = min(n, 20_000_000)
+        reads = np.concatenate([S.reads(lib_packed, K, 2, a, min(5_000_000, m - a), 1) for a in range(0, m, 5_000_000)])
+        matcher.match(reads[:1_000_000], None, MAX_MM, "seed")
+        t0 = time.perf_counter()
+        res = matcher.match(reads, None, MAX_MM, "seed")
+        dt = time.perf_counter() - t0
+        return {"workload": f"bc_match_host, {m} reads from pageable host buffers, all outputs back to the host",
+                "Mreads_per_s": m / dt / 1e6, "GB_per_s_over_pcie": m * 14 / dt / 1e9,
+                "matched_fraction": float((res.best_idx >= 0).mean())}
+
+    def from_file():  # heuristicount end to end from a .reads file (sampling + bulk pass + merge)
+        import shutil
+        import tempfile
+        from barcoder_amd import encoding as E, heuristicount as H
+        m = min(n, 10_000_000)
+        d = tempfile.mkdtemp(prefix="bc_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            labels = E.unpack_kmers(lib_packed, K)
+            fa, rd = os.path.join(d, "lib.fasta"), os.path.join(d, "reads.reads")
+            with open(fa, "w") as f:
+                f.write("".join(f">g{i}\n{s}\n" for i, s in enumerate(labels)))
+            lut = np.frombuffer(b"ACGT", np.uint8)
+            sh = np.arange(K, dtype=np.uint64)
+            with open(rd, "wb") as f:
+                for a in range(0, m, 2_000_000):
+                    c = min(2_000_000, m - a)
+                    w = S.reads(lib_packed, K, 2, a, c, 1)
+                    codes = (((w[:, None] >> sh) & np.uint64(1)) | (((w[:, None] >> (sh + np.uint64(32))) & np.uint64(1)) << np.uint64(1))).astype(np.uint8)
+                    pre = lut[((S.draw(9, np.arange(a, a + c, dtype=np.uint64), 0)[:, None] >> (np.arange(5, dtype=np.uint64) * np.uint64(2))) & np.uint64(3)).astype(np.uint8)]
+                    row = np.empty((c, 46), np.uint8)
+                    row[:, :5] = pre
+                    row[:, 5:15] = np.frombuffer(b"CCGGATTCAG", np.uint8)
+                    row[:, 15:35] = lut[codes]
+                    row[:, 35:45] = np.frombuffer(b"GTTTTAGAGC", np.uint8)
+                    row[:, 45] = 10
+                    f.write(row.tobytes())
+            t0 = time.perf_counter()
+            r = H.count_barcodes(fa, rd, device=local)
+            dt = time.perf_counter() - t0
+            return {"workload": f"heuristicount.count_barcodes on a {m}-read .reads file (46-byte lines), exact match",
+                    "Mreads_per_s": m / dt / 1e6, "seconds": dt, "documented_reads": int(sum(r["doc"].values())),
+                    "bulk_Mreads_per_s": r.get("bulk_mreads_per_s")}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    guarded("exact_1e8", exact)
+    guarded("pam_4p6Mbp", pam)
+    guarded("host_pcie", host_pcie)
+    guarded("from_file", from_file)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,25 +219,31 @@ def main():
     ap.add_argument("--max-mismatch", type=int, default=MAX_MM)
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = ~15 s worth)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads after the timed region")
     ap.add_argument("--mixture", type=int, default=1, help="synthetic stream: 1 = SURVEY cfg3 mismatch mix (default), 0 = cfg2 exact mix")
     args = ap.parse_args()
 
+    # ---- self-launch: N ranks as fresh child processes, before this process imports torch or touches the GPU
+    if args.gpus > 1 and not ("WORLD_SIZE" in os.environ and "RANK" in os.environ):
+        launcher = _dist_module_without_package()
+        raise SystemExit(launcher.launch_workers([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
+    import numpy as np
     import torch
-    import torch.distributed as dist
-    from barcoder_amd import DeviceLibrary, GpuMatcher, synth as S
-    from barcoder_amd.dist import init_from_env
+    from barcoder_amd import DeviceLibrary, GpuMatcher, dist as D, synth as S
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
-    rank, world, local = init_from_env()
+    rank, world, local = D.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     n = int(args.reads)
     seed = 2
+    Gn = args.guides
 
-    lib_packed = S.library(args.guides, K)
+    lib_packed = S.library(Gn, K)
     dl = DeviceLibrary(lib_packed, K, local)
     m = GpuMatcher(dl)
     stream = torch.cuda.current_stream().cuda_stream
@@ -113,44 +252,54 @@ def main():
     best_idx = torch.empty(n, dtype=torch.int32, device=dev)
     best_dist = torch.empty(n, dtype=torch.uint8, device=dev)
     n_best = torch.empty(n, dtype=torch.uint8, device=dev)
-    counts32 = torch.zeros(args.guides, dtype=torch.int32, device=dev)
-    counts64 = torch.zeros(args.guides, dtype=torch.int64, device=dev)
-    first_seen = torch.full((args.guides,), -1, dtype=torch.int64, device=dev)  # 0xFFFF.. = unseen
+    counts32 = torch.zeros(Gn, dtype=torch.int32, device=dev)
+    counts64 = torch.zeros(Gn, dtype=torch.int64, device=dev)
+    first_seen = torch.full((Gn,), -1, dtype=torch.int64, device=dev)  # 0xFFFF.. = unseen
     first = rank * n  # global index of this rank's first read (weak scaling: n per GPU)
     m.synth_reads_dev(seed, first, n, args.mixture, reads.data_ptr(), stream)
     torch.cuda.synchronize()
+    i64max = torch.iinfo(torch.int64).max
 
-    def step():
+    def match_shard(a, b):
+        """This rank's shard [a, b) of the job's world*n reads (resident since before the timed region)."""
+        assert (a, b) == (first, first + n)
         counts32.zero_()
+        first_seen.fill_(-1)
         m.match_dev(reads.data_ptr(), n, best_idx.data_ptr(), max_mismatch=args.max_mismatch, algo=args.algo,
                     d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), d_counts=counts32.data_ptr(),
                     d_first_seen=first_seen.data_ptr(), first_index=first, stream=stream)
         counts64.copy_(counts32)
-        if world > 1:
-            dist.all_reduce(counts64, op=dist.ReduceOp.SUM)
+        first_seen.masked_fill_(first_seen < 0, i64max)  # unseen: the identity of MIN over int64
+        return counts64, first_seen
+
+    def step():
+        return D.count_sharded(world * n, match_shard, Gn, rank, world, device=dev)
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.reduce_scalar_max(time.perf_counter() - t0, device=dev)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    med_ms = D.reduce_scalar_max(statistics.median(step_ms), device=dev)
+    job_counts, job_first = step()  # the job-wide result (identical on every rank)
+    total_hits = int(job_counts.sum().item())
 
     # dominant kernel alone (the matcher without the tally), HIP events on the launch stream: roofline.achieved;
-    # then the whole pass (matcher + k_hist) the same way
+    # then the whole pass (matcher + tally) the same way
     k_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(3, args.steps),
                       d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), stream=stream)
+    counts32.zero_()
+    first_seen.fill_(-1)
     pass_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(3, args.steps),
                          d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), d_counts=counts32.data_ptr(),
                          d_first_seen=first_seen.data_ptr(), stream=stream)
@@ -162,6 +311,7 @@ def main():
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
             metric = "Mreads/s matched, 20-mer <=2 mismatch, at 1/2/4/8 MI355X; % HBM roofline"
+        backend = torch.distributed.get_backend() if world > 1 else None
         out = {
             "metric": metric,
             "value": world * n * args.steps / dt / 1e6,
@@ -170,12 +320,16 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"20-mer <={args.max_mismatch}-mismatch best hit, {args.guides}-guide library, "
+            "value_median": world * n / (med_ms * 1e-3) / 1e6,
+            "ms_per_step_median": med_ms,
+            "config": {"workload": f"20-mer <={args.max_mismatch}-mismatch best hit, {Gn}-guide library, "
                                    f"{n} reads per GPU (BASELINE configs[2])",
-                       "algo": args.algo, "reads_per_gpu": n, "guides": args.guides, "k": K,
+                       "algo": args.algo, "reads_per_gpu": n, "guides": Gn, "k": K,
                        "max_mismatch": args.max_mismatch, "matched_fraction": matched / n,
-                       "outputs": "best_idx i32 + best_dist u8 + n_best u8 + counts u32[G] + first_seen u64[G]",
-                       "parallelism": f"reads sharded x{world}, counts all-reduced"},
+                       "job_matched_reads": total_hits,
+                       "outputs": "best_idx i32 + best_dist u8 + n_best u8 + counts[G] + first_seen[G] (job-wide on every rank)",
+                       "parallelism": f"reads sharded x{world}, counts SUM + first-seen MIN all-reduced"
+                                      + (f" ({backend})" if backend else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": {"seed": "k_match_wave (table 0 = exact stage, tables 1-2 on compacted lists)",
@@ -183,7 +337,7 @@ def main():
                                     "auto": "k_match_wave"}[args.algo],
                          "kernel_ms": k_ms, "algorithmic_bytes_per_read": ALGO_BYTES,
                          "frac_of_measured_copy_peak": achieved / 6290.0,
-                         "pass_ms": pass_ms, "pass": "matcher + k_hist (per-guide counts and first-seen)",
+                         "pass_ms": pass_ms, "pass": "matcher + tally (per-guide counts and first-seen)",
                          "pass_achieved": n * ALGO_BYTES / (pass_ms * 1e-3) / 1e9,
                          "pass_frac": n * ALGO_BYTES / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         }
@@ -192,7 +346,7 @@ def main():
             try:
                 t = json.load(open(tr))
                 if t.get("reads") == n and t.get("algo") == args.algo and t.get("max_mismatch") == args.max_mismatch:
-                    # per launch of the dominant kernel, like `achieved`; the whole pass (with k_hist) beside it
+                    # per launch of the dominant kernel, like `achieved`; the whole pass (with the tally) beside it
                     dom = [v["hbm_bytes"] for k_, v in t.get("per_kernel", {}).items() if k_.startswith("k_match")]
                     out["roofline"]["traffic"] = dom[0] if dom else t["hbm_bytes_per_pass"]
                     out["roofline"]["pass_traffic"] = t["hbm_bytes_per_pass"]
@@ -205,10 +359,11 @@ def main():
                                           np.array_equal(best_dist[:m_].cpu().numpy(), ref["best_dist"]) and
                                           np.array_equal(n_best[:m_].cpu().numpy(), ref["n_best"]))
             out["cpu_baseline"] = cb
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_workloads(torch, dev, local, stream, lib_packed, m, n, args.steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.barrier()
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -54,8 +54,8 @@ extern "C" {
 /* match algorithms */
 #define BC_ALGO_AUTO 0  /* exact hash when max_mismatch==0, else seed index */
 #define BC_ALGO_HASH 1  /* d = 0 only: open-addressing table in L2          */
-#define BC_ALGO_SEED 2  /* pigeonhole seed index + verify, d <= 3 (slab    */
-                        /* layout when the k-mer allows it, else CSR)       */
+#define BC_ALGO_SEED 2  /* pigeonhole seed index + verify, d <= 3 and d < k */
+                        /* (slab layout when the k-mer allows it, else CSR) */
 #define BC_ALGO_BRUTE 3 /* LDS-tiled all-pairs XOR+popcount, any d          */
 #define BC_ALGO_SEED_CSR 4 /* the seed index in its CSR layout, always      */
 
@@ -110,6 +110,17 @@ int bc_pack_windows(const char *h_text, const uint64_t *h_off, size_t n_reads,
  * *n_out == 0 at end of file). */
 typedef struct bc_reader bc_reader;
 int bc_reader_open(const char *path, bc_reader **out);
+/* bc_reader_open_range: only the records of an UNCOMPRESSED file that start in
+ * the byte range [begin, end) — one rank's shard when the chunks of
+ * heuristicount.py:703-737 (Pool fan-out) are spread over several GPUs.
+ * Ranges that tile the file deliver every record exactly once.
+ * bc_reader_tell: offset of the next unread byte in the decoded stream; it
+ * grows by at least one per read, so (offset at chunk start + i) orders reads
+ * like their global index does (first-seen order, heuristicount.py:876-877).
+ * A damaged or truncated .gz / .zst stream makes bc_reader_next fail with
+ * BC_EINVAL (the reference's gzip / zstandard readers raise there). */
+int bc_reader_open_range(const char *path, uint64_t begin, uint64_t end, bc_reader **out);
+int bc_reader_tell(const bc_reader *r, uint64_t *offset_out);
 int bc_reader_next(bc_reader *r, uint64_t max_reads, char *h_text, uint64_t text_cap,
                    uint64_t *h_off /* max_reads + 1 */, uint64_t *n_out);
 int bc_reader_close(bc_reader *r);
@@ -141,6 +152,10 @@ int bc_lib_create(const uint64_t *h_guides, uint32_t n_guides, int k, int device
                   bc_lib **out);
 int bc_lib_destroy(bc_lib *lib);
 int bc_lib_info(const bc_lib *lib, uint32_t *n_guides, int *k, int *device);
+/* name of the match kernel the last bc_match_* call on this library launched
+ * ("k_match_wave", "k_match_hash", "k_match_seed", ...): lets a test assert
+ * which path a (k, max_mismatch, library size) combination takes. */
+const char *bc_lib_last_kernel(const bc_lib *lib);
 
 /* ---- read -> library match (K2, K3, K5) ----------------------------------
  * The device twin of the back half of process_chunk (heuristicount.py:449-453
@@ -177,6 +192,28 @@ int bc_match_host(bc_lib *lib, const uint64_t *h_reads, const uint8_t *h_flags, 
                   int max_mismatch, int algo,
                   int32_t *h_best_idx, uint8_t *h_best_dist, uint8_t *h_n_best,
                   uint64_t *h_counts, uint64_t *h_first_seen, uint64_t first_index_base);
+
+/* ---- several GPUs in one process --------------------------------------------
+ * The data-parallel fan-out of heuristicount.py:703-737 (Pool.starmap over
+ * chunks, Counter merge :731-737) for a caller that owns all GPUs of a node
+ * from one process: one replica of the library per listed device
+ * (devices == NULL: 0..n_gpus-1), reads sharded in contiguous ranges of
+ * ceil(n / n_gpus), per-read outputs written to the caller's arrays range by
+ * range, and ONE all-reduce of the per-guide vectors at the end — SUM of the
+ * counts, MIN of the first-seen indices — over RCCL/xGMI when the devices are
+ * distinct (librccl is resolved with dlopen).  A device listed more than once,
+ * or n_gpus == 1, reduces through the host (rehearsal on fewer GPUs).
+ * Arguments as bc_match_host; h_counts is ADDED to, h_first_seen min'ed.
+ * The one-process-per-GPU form of the same job is barcoder_amd/dist.py. */
+typedef struct bc_multi bc_multi;
+int bc_multi_create(const uint64_t *h_guides, uint32_t n_guides, int k, const int *devices,
+                    int n_gpus, bc_multi **out);
+int bc_multi_info(const bc_multi *m, int *n_gpus, int *uses_rccl);
+int bc_multi_gpu_match(bc_multi *m, const uint64_t *h_reads, const uint8_t *h_flags, uint64_t n,
+                       int max_mismatch, int algo,
+                       int32_t *h_best_idx, uint8_t *h_best_dist, uint8_t *h_n_best,
+                       uint64_t *h_counts, uint64_t *h_first_seen, uint64_t first_index_base);
+int bc_multi_destroy(bc_multi *m);
 
 /* ---- all hits (guide -> genome search, the Bowtie bypass) -----------------
  * For every query word q[i] (a genome window or a read) emit every guide

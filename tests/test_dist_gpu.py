@@ -1,0 +1,87 @@
+"""GPU: the N > 1 path with the HIP matcher on every rank.  On a one-GPU box the two ranks share
+cuda:0 and reduce over gloo (BC_DIST_BACKEND=gloo); with two or more GPUs the same tests also run
+over RCCL ("nccl").  Both product entry points are exercised from a bare shell environment: they
+start their own ranks (dist.launch_workers) and rank 0 prints."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bare_env(backend):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["BC_DIST_BACKEND"] = backend
+    return env
+
+
+def _backends():
+    import torch
+    return ["gloo"] + (["nccl"] if torch.cuda.device_count() >= 2 else [])
+
+
+def test_bench_self_launch_two_ranks(gpu_device):
+    """`python bench.py --gpus 2` with no launcher in the environment prints one valid line for N = 2 whose
+    job-wide matched count equals a single process over the same 2 x n reads of the seeded stream."""
+    from barcoder_amd import DeviceLibrary, GpuMatcher, synth as S
+    n, G = 1_000_000, 20_000
+    lib = S.library(G, 20)
+    m = GpuMatcher(DeviceLibrary(lib, 20, gpu_device))
+    reads = np.concatenate([S.reads(lib, 20, 2, a, 500_000, 1) for a in range(0, 2 * n, 500_000)])
+    want = int(m.match(reads, None, 2, "seed").counts.sum())
+    for backend in _backends():
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", str(n),
+                              "--guides", str(G), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-secondary"],
+                             capture_output=True, text=True, timeout=900, env=_bare_env(backend), cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, out.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+        assert rec["config"]["job_matched_reads"] == want, backend
+        assert backend in rec["config"]["parallelism"]
+        assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec
+
+
+def test_bench_refuses_mismatched_world(gpu_device):
+    env = dict(_bare_env("gloo"), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "1000"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+@pytest.mark.parametrize("scenario,compress", [("fwd_single", False), ("fwd_single", True), ("paired", False)])
+def test_heuristicount_cli_two_ranks_equals_reference(gpu_device, tmp_path, scenario, compress):
+    """`python -m barcoder_amd.heuristicount --gpus 2`: stdout byte-identical to the reference's single-process
+    run — byte-range shards of a plain single-end file, chunk striding for gz / paired input."""
+    with gzip.open(os.path.join(GOLDEN, "heuristicount_main.json.gz"), "rt") as f:
+        cases = json.load(f)
+    s = next((x for x in cases if x["name"] == scenario), None) or next(x for x in cases if x["paired"])
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">bc{i}\n{b}\n" for i, b in enumerate(s["barcodes"])))
+
+    def write(path, reads):
+        op = gzip.open if str(path).endswith(".gz") else open
+        with op(path, "wt") as f:
+            for i, r in enumerate(reads):
+                f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" if s["ext"] == "fastq" else r + "\n")
+    ext = s["ext"] + (".gz" if compress else "")
+    files = [tmp_path / f"r1.{ext}"]
+    write(files[0], s["reads1"])
+    if s["paired"]:
+        files.append(tmp_path / f"r2.{ext}")
+        write(files[1], s["reads2"])
+    for backend in _backends():
+        out = subprocess.run([sys.executable, "-m", "barcoder_amd.heuristicount", str(fa)] + [str(p) for p in files] +
+                             ["--gpus", "2", "--chunk-reads", "257"], cwd=ROOT, capture_output=True, text=True,
+                             timeout=900, env=_bare_env(backend))
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout == s["stdout"], (scenario, compress, backend)
+        assert "Total Reads" in out.stderr

@@ -349,3 +349,142 @@ def test_design_filters():
     assert sp(D.filter_guides(cols, rows, 4, full_overlap=True, tile_size=8)) == ["AAAA", "TTTT", "TTTT", "ACAC"]
     assert sp(D.filter_guides(cols, rows, 4, keep_top=1)) == ["AAAA", "TTTT", "TTTT"]
     assert sp(D.filter_guides(cols, rows, 4, keep_top=2)) == ["AAAA", "CCCC", "TTTT", "TTTT", "ACAC"]
+
+
+def _zstd_compress(raw: bytes):
+    import ctypes
+    try:
+        z = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    cap = z.ZSTD_compressBound(len(raw))
+    dst = ctypes.create_string_buffer(cap)
+    m = z.ZSTD_compress(dst, cap, raw, len(raw), 3)
+    return dst.raw[:m]
+
+
+def test_damaged_compressed_stream_is_an_error(tmp_path):
+    """A truncated or corrupt .gz / .zst reads file must fail (the reference's gzip / zstandard readers
+    raise; main() then prints no counts, heuristicount.py:882-888) — never a silently shorter stream."""
+    import random
+    from barcoder_amd import ingest
+    rng = random.Random(7)
+    reads = ["".join(rng.choice("ACGT") for _ in range(60)) for _ in range(40000)]
+    raw = ("\n".join(reads) + "\n").encode()
+    good = gzip.compress(raw)
+    (tmp_path / "ok.reads.gz").write_bytes(good)
+    assert ingest.read_all(str(tmp_path / "ok.reads.gz")) == reads
+    (tmp_path / "cut.reads.gz").write_bytes(good[:len(good) // 2])
+    with pytest.raises(ValueError, match="gzip stream"):
+        ingest.read_all(str(tmp_path / "cut.reads.gz"))
+    bad = bytearray(good)
+    for i in range(len(bad) // 2, len(bad) // 2 + 64):
+        bad[i] ^= 0x5A
+    (tmp_path / "bad.reads.gz").write_bytes(bytes(bad))
+    with pytest.raises(ValueError, match="gzip stream"):
+        ingest.read_all(str(tmp_path / "bad.reads.gz"))
+    z = _zstd_compress(raw)
+    if z is not None:
+        (tmp_path / "ok.reads.zst").write_bytes(z)
+        assert ingest.read_all(str(tmp_path / "ok.reads.zst")) == reads
+        (tmp_path / "cut.reads.zst").write_bytes(z[:len(z) // 2])
+        with pytest.raises(ValueError, match="zstd stream"):
+            ingest.read_all(str(tmp_path / "cut.reads.zst"))
+        zb = bytearray(z)
+        for i in range(len(zb) // 2, len(zb) // 2 + 64):
+            zb[i] ^= 0x5A
+        (tmp_path / "bad.reads.zst").write_bytes(bytes(zb))
+        with pytest.raises(ValueError, match="zstd stream"):
+            ingest.read_all(str(tmp_path / "bad.reads.zst"))
+
+
+def test_reader_byte_ranges_tile_the_file(tmp_path):
+    """bc_reader_open_range: ranges that tile an uncompressed file deliver every record exactly once, in
+    order, for .reads and for FASTQ (quality lines that begin with '@' or '+' included); the tell() keys of
+    consecutive chunks order reads like their global index."""
+    import random
+    from barcoder_amd import ingest
+    rng = random.Random(3)
+    reads = ["".join(rng.choice("ACGTN") for _ in range(rng.randrange(1, 90))) for _ in range(2500)]
+    pr = tmp_path / "x.reads"
+    pr.write_text("\n".join(reads) + "\n")
+    pq = tmp_path / "x.fastq"
+    with open(pq, "w") as f:
+        for i, r in enumerate(reads):
+            q = "".join(rng.choice("@+IF#") for _ in r)
+            f.write(f"@r{i} x\n{r}\n+\n{q}\n")
+    pt = tmp_path / "t.fastq"  # last record cut off after its sequence line
+    pt.write_text("".join(f"@r{i}\n{r}\n+\n{'@' * len(r)}\n" for i, r in enumerate(reads[:50])) + "@last\nACGT")
+
+    def ranged(path, cuts):
+        got, keys = [], []
+        for a, b in zip(cuts, cuts[1:]):
+            with ingest.NativeReader(str(path), max_reads=97, byte_range=(a, b)) as r:
+                while True:
+                    key = r.tell()
+                    text, off = r.next()
+                    if off.size <= 1:
+                        break
+                    bts = text.tobytes()
+                    o = off.astype(np.int64)
+                    got += [bts[o[i]:o[i + 1]].decode() for i in range(o.size - 1)]
+                    keys += [key + i for i in range(o.size - 1)]
+        return got, keys
+
+    for path, want in ((pr, reads), (pq, reads), (pt, reads[:50] + ["ACGT"])):
+        size = os.path.getsize(path)
+        for world in (1, 2, 3, 7, 64):
+            per = -(-size // world)
+            cuts = [min(size, r * per) for r in range(world)] + [size]
+            got, keys = ranged(path, cuts)
+            assert got == want, (path.name, world)
+            assert all(x < y for x, y in zip(keys, keys[1:])), (path.name, world)
+        for _ in range(20):  # arbitrary cut points, including inside records and at line starts
+            cuts = [0] + sorted(rng.randrange(0, size + 1) for _ in range(4)) + [size]
+            assert ranged(path, cuts)[0] == want
+    with pytest.raises(ValueError, match="compressed"):
+        (tmp_path / "x.reads.gz").write_bytes(gzip.compress(b"ACGT\n"))
+        ingest.NativeReader(str(tmp_path / "x.reads.gz"), byte_range=(0, 5))
+
+
+def test_merge_undocumented_any_order():
+    from barcoder_amd import heuristicount as H
+    u = np.uint64
+    a = (np.array([5, 9, 7], u), np.array([2, 1, 1], u), np.array([10, 3, 8], u))
+    b = (np.array([9, 5, 1], u), np.array([4, 1, 6], u), np.array([1, 30, 2], u))
+    for tables in ([a, b], [b, a], [a, (None, None, None), b]):
+        w, c, f = H.merge_undocumented(tables)
+        assert w.tolist() == [1, 5, 7, 9] and c.tolist() == [6, 3, 1, 5] and f.tolist() == [2, 10, 8, 1]
+    w, c, f = H.merge_undocumented([])
+    assert w.size == c.size == f.size == 0
+    assert H.shard_plan("a.reads", None, 1) == "stride" and H.shard_plan("a.reads", None, 4) == "bytes"
+    assert H.shard_plan("a.reads.gz", None, 4) == "stride" and H.shard_plan("a.fastq", "b.fastq", 4) == "stride"
+
+
+def test_launch_workers_starts_ranks_and_reports_failure(tmp_path):
+    """dist.launch_workers: fresh child interpreters with the torchrun environment; rank 0 owns stdout; a
+    failing rank ends the job with its status."""
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "print(f'rank {r} of {w}')\n"
+        "if len(sys.argv) > 1 and r == int(sys.argv[1]): sys.exit(7)\n")
+    drv = ("import sys; sys.path.insert(0, %r); import importlib.util as u; "
+           "s = u.spec_from_file_location('d', %r); m = u.module_from_spec(s); s.loader.exec_module(m); "
+           "assert 'torch' not in sys.modules; "
+           "sys.exit(m.launch_workers([%r] + sys.argv[1:], 3, timeout=60))") % (
+        ROOT, os.path.join(ROOT, "barcoder_amd", "dist.py"), str(script))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    ok = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, env=env)
+    assert ok.returncode == 0 and ok.stdout.strip() == "rank 0 of 3"
+    assert "rank 1 of 3" in ok.stderr and "rank 2 of 3" in ok.stderr
+    bad = subprocess.run([sys.executable, "-c", drv, "2"], capture_output=True, text=True, env=env)
+    assert bad.returncode == 7

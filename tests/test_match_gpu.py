@@ -38,14 +38,16 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
     assert (res.best_idx >= 0).sum() > n // 2
 
 
-@pytest.mark.parametrize("env", [{"BC_TALLY": "1"}, {"BC_TALLY": "2"}, {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4", "BC_TWO_STAGE": "0"},
+@pytest.mark.parametrize("env", [{"BC_TALLY": "1"}, {"BC_TALLY": "2"}, {"BC_TALLY": "3"},
+                                 {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4", "BC_SINGLE_SLAB": "1"},
                                  {"BC_SLAB_LOG2S": "3,3,3,3"}, {"BC_SLAB_LOG2S": "5,5,5,5"}, {"BC_SLAB_LOG2S": "4,3,5,4"},
-                                 {"BC_TWO_STAGE": "0"}, {"BC_TWO_STAGE": "2"}, {"BC_TWO_STAGE": "2", "BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4"},
+                                 {"BC_SINGLE_SLAB": "1"}, {"BC_LANE": "0"}, {"BC_LANE": "0", "BC_PHASE2_SM": "0"},
                                  {"BC_HASH_SLOTS_PCT": "120"}, {"BC_HASH_SLOTS_PCT": "3000"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
-    """Tally by global atomics vs LDS histogram, fused vs two-kernel vs single
+    """Tally by global atomics vs LDS histogram vs records, wave vs quad vs single
     slab kernel, 4 vs 8 lanes per read, slab sizes with and without overflow
-    chains, hash tables from crowded to sparse: identical outputs."""
+    chains, hash tables from crowded to sparse: identical outputs.  (The knobs are
+    read when the library is created.)"""
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)
     k, G, n = 20, 6000, 30001
@@ -118,13 +120,16 @@ def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, monkeypatch):
     reads, _ = E.pack_kmers(reads_s, k)
     flags = (rng.random(n) < 0.02).astype(np.uint8)
     monkeypatch.setenv("BC_SLAB_LOG2S", slab)
+    monkeypatch.setenv("BC_LANE", "1")
     dl = DeviceLibrary(lib, k, gpu_device)
+    monkeypatch.setenv("BC_LANE", "0")  # knobs are read at creation: a second library for the quad kernels
+    dq = DeviceLibrary(lib, k, gpu_device)
     for d in (1, 2):
         ref = oracle.best_hit(lib_s, reads_s, d, skip=flags, base=3)
-        monkeypatch.setenv("BC_LANE", "1")
         _check(GpuMatcher(dl).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
-        monkeypatch.setenv("BC_LANE", "0")
-        _check(GpuMatcher(dl).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
+        assert dl.last_kernel == "k_match_wave"
+        _check(GpuMatcher(dq).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
+        assert dq.last_kernel == "k_match_fused"
     if cluster:
         assert (ref["n_best"] > 1).sum() > 50
 
@@ -175,6 +180,109 @@ def test_tally_hot_guides(gpu_device):
     starts = np.r_[0, np.flatnonzero(np.diff(g_sorted)) + 1]
     first[g_sorted[starts]] = idx_hit[order][starts].astype(np.uint64) + np.uint64(100)
     np.testing.assert_array_equal(res.first_seen.astype(np.uint64), first)
+
+
+def _tally_from_best_idx(best_idx, G, base):
+    hit = best_idx >= 0
+    counts = np.bincount(best_idx[hit], minlength=G).astype(np.uint64)
+    first = np.full(G, np.iinfo(np.uint64).max, np.uint64)
+    idx_hit = np.flatnonzero(hit)
+    order = np.argsort(best_idx[idx_hit], kind="stable")
+    g_sorted = best_idx[idx_hit][order]
+    if g_sorted.size:
+        starts = np.r_[0, np.flatnonzero(np.diff(g_sorted)) + 1]
+        first[g_sorted[starts]] = idx_hit[order][starts].astype(np.uint64) + np.uint64(base)
+    return counts, first
+
+
+@pytest.mark.parametrize("G", [45_000, 100_000, 163_840])
+@pytest.mark.parametrize("skew", ["uniform", "hot_guide", "one_range"])
+def test_record_tally(gpu_device, G, skew):
+    """The tally from the matcher's range-partitioned records (k_hist_part + k_first_refine): 3, 5 and 8 guide
+    ranges; uniform reads, one guide that takes 40 % of them (its range overflows the 64-record line in most tiles:
+    overflow list, results taken from best_idx) and reads that all fall into one range; ragged sizes (n % 4, n % 256);
+    exact kernel and wave kernel; accumulation over two calls.  Counts / first-seen must equal what best_idx implies
+    and what the five-sweep tally (BC_TALLY=2) and global atomics (BC_TALLY=1) give."""
+    import os
+    import torch
+    k, n = 20, 700_003
+    lib = S.library(G, k)
+    rng = np.random.default_rng(G % 1000 + len(skew))
+    if skew == "uniform":
+        pick = rng.integers(0, G, size=n)
+    elif skew == "hot_guide":
+        pick = np.where(rng.random(n) < 0.4, G // 2 + 7, rng.integers(0, G, size=n))
+    else:
+        pick = rng.integers(G // 3, G // 3 + 9000, size=n)
+    reads = lib[pick].copy()
+    sub1 = rng.random(n) < 0.3
+    reads[sub1] ^= np.uint64(1) << rng.integers(0, k, size=int(sub1.sum())).astype(np.uint64)  # one substitution
+    junk = rng.random(n) < 0.05
+    reads[junk] = S.draw(77, np.arange(int(junk.sum()), dtype=np.uint64), 0) & E.kmer_mask(k)
+    dev = torch.device("cuda", gpu_device)
+    tr = torch.from_numpy(reads.view(np.int64)).to(dev)
+    results = {}
+    for mode in ("3", "2", "1"):
+        os.environ["BC_TALLY"] = mode
+        try:
+            dl = DeviceLibrary(lib, k, gpu_device)
+        finally:
+            del os.environ["BC_TALLY"]
+        m = GpuMatcher(dl)
+        for algo, d in (("hash", 0), ("seed", 2)):
+            bi = torch.empty(n, dtype=torch.int32, device=dev)
+            cnt = torch.zeros(G, dtype=torch.int32, device=dev)
+            fs = torch.full((G,), -1, dtype=torch.int64, device=dev)
+            # two launches accumulate into the same vectors: [0, n1) then [n1, n)
+            n1 = 300_000 if mode != "1" else n
+            for a, b in ((0, n1), (n1, n)):
+                if b > a:
+                    m.match_dev(tr[a:].data_ptr(), b - a, bi[a:].data_ptr(), max_mismatch=d, algo=algo,
+                                d_counts=cnt.data_ptr(), d_first_seen=fs.data_ptr(), first_index=1000 + a)
+            torch.cuda.synchronize()
+            best = bi.cpu().numpy()
+            want_c, want_f = _tally_from_best_idx(best, G, 1000)
+            np.testing.assert_array_equal(cnt.cpu().numpy().astype(np.uint64), want_c, err_msg=f"{mode} {algo}")
+            np.testing.assert_array_equal(fs.cpu().numpy().view(np.uint64), want_f, err_msg=f"{mode} {algo}")
+            results[(mode, algo)] = best
+            assert dl.last_kernel == ("k_match_hash" if d == 0 else "k_match_wave")
+            if d == 0:
+                hit = ~junk & ~sub1
+                np.testing.assert_array_equal(best[hit], pick[hit])
+    for algo in ("hash", "seed"):
+        np.testing.assert_array_equal(results[("3", algo)], results[("2", algo)])
+
+
+def test_max_mismatch_must_be_below_k(gpu_device):
+    """k <= max_mismatch breaks the pigeonhole guarantee (no clean segment is left): rejected, not answered wrongly."""
+    lib = S.library(50, 3)
+    m = GpuMatcher(DeviceLibrary(lib, 3, gpu_device))
+    reads = S.reads(lib, 3, 1, 0, 100, 1)
+    assert m.match(reads, None, max_mismatch=2, algo="seed").best_idx.size == 100
+    for algo in ("seed", "brute", "seed_csr"):
+        with pytest.raises(ValueError, match="max_mismatch"):
+            m.match(reads, None, max_mismatch=3, algo=algo)
+
+
+def test_multi_gpu_single_process(gpu_device, oracle):
+    """bc_multi_gpu_match: contiguous shards over several library replicas, per-read outputs stitched by range, counts
+    summed and first-seen min'ed — equal to one library over all reads.  One device: a group of one (host reduction)
+    and a group of three replicas on the same device; with >= 2 GPUs also the RCCL all-reduce over distinct devices."""
+    import barcoder_amd
+    from barcoder_amd import MultiGpuMatcher
+    k, G, n = 20, 3000, 50_001
+    lib, reads, flags = _case(G, n, k, 1, seed=5)
+    ref = oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads & E.kmer_mask(k), k), 2, skip=flags, base=9)
+    groups = [[gpu_device], [gpu_device] * 3]
+    if barcoder_amd.device_count() >= 2:
+        groups.append(list(range(min(barcoder_amd.device_count(), 4))))
+    for devs in groups:
+        mm = MultiGpuMatcher(lib, k, devs)
+        assert mm.n_gpus == len(devs) and mm.uses_rccl == (len(set(devs)) == len(devs) and len(devs) > 1)
+        _check(mm.match(reads, flags, max_mismatch=2, algo="seed", first_index=9), ref)
+        _check(mm.match(reads[:2], flags[:2], max_mismatch=2, algo="seed", first_index=9),
+               oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads[:2] & E.kmer_mask(k), k), 2, skip=flags[:2], base=9))
+        mm.close()
 
 
 def test_all_hits(gpu_device, oracle):
