@@ -22,6 +22,7 @@
 // per CU, i.e. the number of divergent table visits per read, not HBM or L2.
 #include <dlfcn.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -95,14 +96,16 @@ __device__ __forceinline__ void part_emit(const PartOut& P, uint32_t tile, const
     const uint32_t c = lane < P.nr ? cnt[lane] : 0u;
     const bool ovf = __ballot(c > (uint32_t)PART_CAP) != 0ull;
     if (ovf && lane == 0) P.ovf_list[atomicAdd(P.ovf_count, 1u)] = tile;
-    // lines out: lane l stores dword (l & 31) of range 2r + (l >> 5): two ranges per store instruction
+    // lines out: lane l stores dword (l & 31) of range r + (l >> 5): two ranges (256 staged bytes, read in lane
+    // order) per store instruction; the upper half-wave's line lies one range stride (< 2^31 bytes) further on
     const uint32_t* sw = reinterpret_cast<const uint32_t*>(stage);
+    const uint32_t stride = P.n_tiles * (uint32_t)(PART_CAP * sizeof(uint16_t));  // bytes between two ranges' lines of a tile
+    const uint32_t lane_off = (lane & 31u) * 4u + (lane >> 5) * stride;
+    const char* line0 = reinterpret_cast<const char*>(P.rec) + (size_t)tile * (PART_CAP * sizeof(uint16_t));
     for (uint32_t r = 0; r < P.nr; r += 2) {
-        const uint32_t rg = r + (lane >> 5);
-        if (rg < P.nr) {
-            const uint32_t v = ovf ? 0xFFFFFFFFu : sw[rg * (PART_CAP / 2) + (lane & 31u)];
-            uint32_t* dst = reinterpret_cast<uint32_t*>(P.rec + ((size_t)rg * P.n_tiles + tile) * PART_CAP) + (lane & 31u);
-            __builtin_nontemporal_store(v, dst);
+        if (r + (lane >> 5) < P.nr) {
+            const uint32_t v = ovf ? 0xFFFFFFFFu : sw[r * (PART_CAP / 2) + lane];
+            __builtin_nontemporal_store(v, (uint32_t*)(line0 + (size_t)r * stride + lane_off));
         }
     }
 }
@@ -918,6 +921,11 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
 // direct scattered result stores over placeholders (0.5 ms of partial-line writes).
 // ---------------------------------------------------------------------------
 constexpr int WAVE_T = 256;  // reads per wave (4 per lane)
+// layout of k_match_wave's kernel-argument segment (natural alignment, declaration order)
+struct WaveKargs {
+    const void* spp; const void* reads; const void* flags; uint64_t n; int k; uint64_t kmask; int max_mm; MatchOut o;
+};
+static_assert(offsetof(WaveKargs, o) == 56, "k_match_wave kernel-argument layout");
 
 // is the best candidate provably the only guide at its distance?
 __device__ __forceinline__ bool key_unique(uint32_t key, uint32_t max_mm) {
@@ -1020,8 +1028,9 @@ template <int NSEG, int NQ2, bool PROF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wave(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,
                                                    const uint8_t* __restrict__ flags, uint64_t n, int k,
-                                                   uint64_t kmask, int max_mm_, MatchOut o) {
+                                                   uint64_t kmask, int max_mm_, MatchOut o_arg) {
     static_assert(NSEG == 2 || NSEG == 3, "wave kernel: d = 1 or 2");
+    (void)o_arg;  // read from the kernel-argument segment in phase 3, see there
     // list of reads without an exact hit: read, best key so far, table 0's overflow slab (byte offset), position
     __shared__ uint64_t q_read[WAVE_T];
     __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];
@@ -1234,6 +1243,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
 
     // ---- phase 3: every lane collects its four reads' results; full-width coalesced stores, nothing is patched
     {
+        // The output descriptor (22 dwords) is needed from here on only.  Left to itself the compiler loads it at
+        // kernel entry and keeps it in SGPRs through every phase, spilling table descriptors around it (v_writelane /
+        // v_readlane count against the VALU issue this kernel is bound by): fetch it from the kernel-argument
+        // segment now, through a pointer the optimiser cannot see through.
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const MatchOut __attribute__((address_space(4)))* karg_out_t;
+        const char __attribute__((address_space(4)))* ka =
+            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const MatchOut o = *(karg_out_t)(ka + offsetof(WaveKargs, o));
+#else
+        const MatchOut o = o_arg;  // host pass of the single-source compile: never executed
+#endif
         uint32_t dist[4], nb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1605,7 +1627,7 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     SlabParams& sl = lib->slab[d];
     if (s == 0) { sl.nseg = cs.nseg; lib->slab_ok[d] = true; }
     const int start = cs.start[s], slen = cs.slen[s], half = lib->k - slen;
-    if (2 * half > 31 || lib->G >= (1u << SLAB_GIDX_BITS) || lib->k > 28) { lib->slab_ok[d] = false; return BC_OK; }  // rest: one dword; index: 22 bits + 2 flags
+    if (2 * half > 32 || lib->G >= (1u << SLAB_GIDX_BITS)) { lib->slab_ok[d] = false; return BC_OK; }  // rest: one dword (two planes of `half` bits); index: 22 bits + 2 flags
     if (!lib->slab_ok[d]) return BC_OK;
     const uint32_t nb = 1u << (2 * slen);
     // slab size: 64-byte slabs (7 entries + link) while the mean bucket fits, else 128-byte slabs and

@@ -96,6 +96,22 @@ def launch_workers(argv, nproc: int, env=None, timeout=None) -> int:
                 p.kill()
 
 
+class stdout_to_stderr:
+    """Send file descriptor 1 to stderr for the duration (native libraries — gloo's "[Gloo] Rank 0 is
+    connected ..." — print there), so that a rank's stdout carries only what it prints afterwards."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def init_from_env(backend: str | None = None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun
     or launch_workers).  Returns (rank, world, local device index)."""

@@ -727,14 +727,21 @@ def _cli():
         env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
         raise SystemExit(D.launch_workers(["-m", "barcoder_amd.heuristicount"] + sys.argv[1:], a.gpus, env=env))
     if D.under_launcher():
-        rank, world, local = D.init_from_env()
-        if rank != 0:
-            logging.getLogger().setLevel(logging.WARNING)
-        try:
-            main(a, device=local, rank=rank, world=world)
-        finally:
-            D.barrier()
-            D.shutdown()
+        import contextlib
+        import io
+        buf = io.StringIO()
+        with D.stdout_to_stderr():  # native libraries (gloo) print to fd 1: keep stdout for the TSV alone
+            rank, world, local = D.init_from_env()
+            if rank != 0:
+                logging.getLogger().setLevel(logging.WARNING)
+            try:
+                with contextlib.redirect_stdout(buf):
+                    main(a, device=local, rank=rank, world=world)
+            finally:
+                D.barrier()
+                D.shutdown()
+        sys.stdout.write(buf.getvalue())
+        sys.stdout.flush()
     else:
         main(a, device=a.device)
 

@@ -228,6 +228,14 @@ def main():
         launcher = _dist_module_without_package()
         raise SystemExit(launcher.launch_workers([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
+    from barcoder_amd import dist as D
+    with D.stdout_to_stderr():  # stdout carries the one JSON line and nothing else (gloo prints to fd 1)
+        line = run(args)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run(args):
     import numpy as np
     import torch
     from barcoder_amd import DeviceLibrary, GpuMatcher, dist as D, synth as S
@@ -361,9 +369,9 @@ def main():
             out["cpu_baseline"] = cb
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_workloads(torch, dev, local, stream, lib_packed, m, n, args.steps)
-        print(json.dumps(out), flush=True)
     D.barrier()
     D.shutdown()
+    return json.dumps(out) if rank == 0 else None
 
 
 if __name__ == "__main__":
