@@ -70,6 +70,8 @@ SIGNATURES = {
     "bc_match_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "bc_match_host": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_uint64]),
     "bc_match_all_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp]),
+    "bc_match_all_pam_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, vp, C.c_int64, C.c_uint64, C.c_uint64, vp,
+                                       C.c_uint64, vp, vp]),
     "bc_genome_pack": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
     "bc_pam_scan_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int, vp, vp, vp]),
     "bc_pam_scan_host": (C.c_int, [C.c_int, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),

@@ -300,16 +300,36 @@ __global__ __launch_bounds__(BLOCK) void k_match_seed(SeedParams sp, const uint6
     }
 }
 
-// all hits: one record per (query, guide) pair within max_mm
+// all hits: one record per (query, guide) pair within max_mm.  With a PAM bitmap (queries = genome windows, query
+// index = window position): only windows whose adjacent PAM matches are searched at all — the PAM test of
+// targets.py:325-352 (extract_*_pam + pam_matches) moved in front of the search instead of after it.
+struct PamGate {
+    const uint32_t* bits;  // bit p: the PAM (on this strand) starts at forward position p; NULL = no gate
+    int64_t shift;         // PAM position = window position + shift
+    uint64_t limit;        // positions >= limit cannot hold a whole PAM
+    uint64_t wrap;         // circular sequence length (a negative position wraps once), 0 = linear
+};
+
+__device__ __forceinline__ bool pam_gate_open(const PamGate& pg, uint64_t i) {
+    if (!pg.bits) return true;
+    int64_t p = (int64_t)i + pg.shift;
+    if (p < 0) {
+        if (!pg.wrap) return false;
+        p += (int64_t)pg.wrap;
+    }
+    if (p < 0 || (uint64_t)p >= pg.limit) return false;
+    return (pg.bits[p >> 5] >> (p & 31)) & 1u;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_match_all(SeedParams sp, const uint64_t* __restrict__ reads,
                                                      const uint8_t* __restrict__ flags, uint64_t n,
-                                                     int k, uint64_t kmask, int max_mm,
+                                                     int k, uint64_t kmask, int max_mm, PamGate pg,
                                                      bc_hit* __restrict__ hits, uint64_t cap,
                                                      unsigned long long* n_hits) {
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         uint64_t r = reads[i];
-        if (read_skipped(r, flags, i, k)) continue;
+        if (read_skipped(r, flags, i, k) || !pam_gate_open(pg, i)) continue;
         r &= kmask;
         const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
         for (int s = 0; s < sp.nseg; ++s) {
@@ -2390,8 +2410,8 @@ int bc_match_time_dev(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_fla
     return BC_OK;
 }
 
-int bc_match_all_dev(bc_lib* lib, const uint64_t* d_queries, const uint8_t* d_flags, uint64_t n,
-                     int max_mismatch, bc_hit* d_hits, uint64_t cap, uint64_t* d_n_hits, void* stream) {
+static int match_all_impl(bc_lib* lib, const uint64_t* d_queries, const uint8_t* d_flags, uint64_t n, int max_mismatch,
+                          const PamGate& pg, bc_hit* d_hits, uint64_t cap, uint64_t* d_n_hits, void* stream) {
     if (!lib || !d_n_hits || (n && !d_queries) || (cap && !d_hits)) { set_error("bc_match_all_dev: null argument"); return BC_EINVAL; }
     if (max_mismatch < 0 || max_mismatch >= MAX_SEG || max_mismatch >= lib->k) {
         set_error("bc_match_all_dev: 0 <= max_mismatch <= %d and < k", MAX_SEG - 1);
@@ -2401,10 +2421,23 @@ int bc_match_all_dev(bc_lib* lib, const uint64_t* d_queries, const uint8_t* d_fl
     if (n == 0) return BC_OK;
     BC_HIP(hipSetDevice(lib->device));
     hipLaunchKernelGGL(k_match_all, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, lib->seed[max_mismatch],
-                       d_queries, d_flags, n, lib->k, lib->kmask, max_mismatch, d_hits, cap,
+                       d_queries, d_flags, n, lib->k, lib->kmask, max_mismatch, pg, d_hits, cap,
                        (unsigned long long*)d_n_hits);
     BC_HIP(hipGetLastError());
     return BC_OK;
+}
+
+int bc_match_all_dev(bc_lib* lib, const uint64_t* d_queries, const uint8_t* d_flags, uint64_t n,
+                     int max_mismatch, bc_hit* d_hits, uint64_t cap, uint64_t* d_n_hits, void* stream) {
+    return match_all_impl(lib, d_queries, d_flags, n, max_mismatch, PamGate{nullptr, 0, 0, 0}, d_hits, cap, d_n_hits, stream);
+}
+
+int bc_match_all_pam_dev(bc_lib* lib, const uint64_t* d_windows, const uint8_t* d_flags, uint64_t n,
+                         int max_mismatch, const uint32_t* d_pam_bits, int64_t pam_shift, uint64_t pam_limit,
+                         uint64_t wrap_len, bc_hit* d_hits, uint64_t cap, uint64_t* d_n_hits, void* stream) {
+    if (!d_pam_bits) { set_error("bc_match_all_pam_dev: null PAM bitmap"); return BC_EINVAL; }
+    return match_all_impl(lib, d_windows, d_flags, n, max_mismatch, PamGate{d_pam_bits, pam_shift, pam_limit, wrap_len},
+                          d_hits, cap, d_n_hits, stream);
 }
 
 // Host buffers in, host results out (see match_host_chunks).  Counts / first-seen accumulate on the device across

@@ -34,6 +34,8 @@ __device__ __forceinline__ uint32_t allowed(uint32_t lo, uint32_t hi, uint32_t m
     return a;
 }
 
+// mask bit 4 (BC_PAM_ANY_CHAR): the pattern position also accepts a character that is not ACGT — the '.' that
+// targets.py:224 (pam_matches) writes for N, as opposed to the [ATCG] of PAMProcessor.py:31 / design_guides.py:26
 __global__ __launch_bounds__(BLOCK) void k_pam_scan(const uint64_t* __restrict__ bases,
                                                     const uint32_t* __restrict__ invalid,
                                                     uint64_t total_len, uint64_t n_words, PamParams pp,
@@ -42,23 +44,25 @@ __global__ __launch_bounds__(BLOCK) void k_pam_scan(const uint64_t* __restrict__
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t w = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += stride) {
         uint64_t b0 = bases[w];
-        uint32_t i0 = invalid[w];
+        uint32_t c0 = invalid[w];          // characters that are not ACGT
+        uint32_t t0 = 0, t1 = 0xFFFFFFFFu; // positions at or past total_len
         uint64_t b1 = 0;
-        uint32_t i1 = 0xFFFFFFFFu;
-        if (w + 1 < n_words) { b1 = bases[w + 1]; i1 = invalid[w + 1]; }
-        if (w == n_words - 1 && (total_len & 31)) i0 |= ~((1u << (total_len & 31)) - 1u);
-        if (w + 2 == n_words && (total_len & 31)) i1 |= ~((1u << (total_len & 31)) - 1u);
+        uint32_t c1 = 0xFFFFFFFFu;
+        if (w + 1 < n_words) { b1 = bases[w + 1]; c1 = invalid[w + 1]; t1 = 0; }
+        if (w == n_words - 1 && (total_len & 31)) t0 = ~((1u << (total_len & 31)) - 1u);
+        if (w + 2 == n_words && (total_len & 31)) t1 = ~((1u << (total_len & 31)) - 1u);
         const uint32_t lo0 = (uint32_t)b0, hi0 = (uint32_t)(b0 >> 32);
         const uint32_t lo1 = (uint32_t)b1, hi1 = (uint32_t)(b1 >> 32);
         uint32_t f = 0xFFFFFFFFu, r = 0xFFFFFFFFu;
         for (int j = 0; j < pp.len; ++j) {
-            uint32_t lo = take32(lo0, lo1, j), hi = take32(hi0, hi1, j);
-            uint32_t ok = ~take32(i0, i1, j);
-            f &= allowed(lo, hi, pp.fwd[j]) & ok;
-            r &= allowed(lo, hi, pp.rev[j]) & ok;
+            const uint32_t lo = take32(lo0, lo1, j), hi = take32(hi0, hi1, j);
+            const uint32_t in = ~take32(t0, t1, j);         // inside the sequence
+            const uint32_t odd = take32(c0, c1, j);         // not ACGT
+            const uint32_t fa = (pp.fwd[j] & 16u) ? odd : 0u, ra = (pp.rev[j] & 16u) ? odd : 0u;
+            f &= in & ((allowed(lo, hi, pp.fwd[j]) & ~odd) | fa);
+            r &= in & ((allowed(lo, hi, pp.rev[j]) & ~odd) | ra);
         }
-        // a pattern that would run past total_len meets an invalid position
-        // (tail of the last word, or the all-invalid word after it): no match.
+        // a pattern that would run past total_len meets a position outside the sequence: no match
         out_fwd[w] = f;
         out_rev[w] = r;
     }
@@ -187,8 +191,8 @@ int grid_for(uint64_t items) {
     return (int)b;
 }
 
-uint8_t comp_mask(uint8_t m) {  // A<->T, C<->G
-    return (uint8_t)(((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3));
+uint8_t comp_mask(uint8_t m) {  // A<->T, C<->G; the any-character flag stays
+    return (uint8_t)(((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3) | (m & 16));
 }
 
 }  // namespace
@@ -206,7 +210,7 @@ int bc_pam_scan_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t
     PamParams pp;
     pp.len = pam_len;
     for (int j = 0; j < pam_len; ++j) {
-        if (pam_masks[j] == 0 || pam_masks[j] > 15) {
+        if ((pam_masks[j] & 15) == 0 || pam_masks[j] > 31) {
             set_error("bc_pam_scan_dev: pattern position %d has empty or invalid base set", j);
             return BC_EINVAL;
         }

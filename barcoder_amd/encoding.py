@@ -73,14 +73,19 @@ IUPAC = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15, "R": 5, "Y": 10, "S": 6, "W": 
          "B": 14, "D": 13, "H": 11, "V": 7}
 
 
-def pam_masks(pam: str, iupac: bool = False) -> np.ndarray:
+PAM_ANY_CHAR = 16  # BC_PAM_ANY_CHAR
+
+
+def pam_masks(pam: str, iupac: bool = False, n_is_dot: bool = False) -> np.ndarray:
     """PAM string -> 4-bit base sets.  Like the reference only N is a wildcard
     (PAMProcessor.py:31, design_guides.py:26, targets.py:224); pass iupac=True
-    to read the other IUPAC codes as sets (an extension)."""
+    to read the other IUPAC codes as sets (an extension).  n_is_dot=True gives N
+    the meaning targets.py:224 gives it ('.': any character, also a genome base
+    that is not ACGT) instead of PAMProcessor's / design_guides' [ATCG]."""
     out = np.zeros(len(pam), np.uint8)
     for i, c in enumerate(pam):
         if c in "ACGTN" or (iupac and c in IUPAC):
-            out[i] = IUPAC[c]
+            out[i] = IUPAC[c] | (PAM_ANY_CHAR if (n_is_dot and c == "N") else 0)
         else:
             raise ValueError(f"PAM character {c!r} can never match a genome base (only ACGT and N are supported)")
     return out

@@ -21,7 +21,9 @@ feature tables of the shipped plasmids; a GenBank reader is not included).
 """
 from __future__ import annotations
 
+import os
 import re
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -96,10 +98,28 @@ class Chromosome:
 
 
 # ------------------------------------------------------------------ the search
+_COMP_LUT = np.full(256, ord("N"), np.uint8)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP_LUT[_a] = _b
+
+
+def _windows_as_strings(topo: np.ndarray, starts: np.ndarray, width: int, revcomp):
+    """topo[starts[i] : starts[i] + width] for every i as upper-case str (reverse-complemented where asked)."""
+    if starts.size == 0 or width == 0:
+        return [""] * int(starts.size)
+    m = topo[starts[:, None] + np.arange(width, dtype=np.int64)[None, :]]
+    rc = _COMP_LUT[m[:, ::-1]]
+    m = np.where(np.asarray(revcomp, bool)[:, None], rc, m)
+    return m.view(f"S{width}").ravel().astype(str).tolist()
+
+
 def find_hits(guides, chromosomes, pam: str = "", num_mismatches: int = 0, pam_direction: str = "downstream",
-              device: int = 0):
+              device: int = 0, max_alignments: int | None = None, report_unaligned: bool = False):
     """All placements of every guide on every chromosome within `num_mismatches`
     substitutions whose adjacent PAM matches (`pam` empty or all-N: any).
+
+    guides: sequences, {name: sequence}, or [(name, sequence), ...] (the reads of
+    the reference's sgRNA FASTQ: several names may carry one sequence).
 
     Returns a list of dict rows with the keys parse_sam_output builds before the
     annotation join (targets.py:354-410): name, spacer, len, target, mismatches,
@@ -108,81 +128,136 @@ def find_hits(guides, chromosomes, pam: str = "", num_mismatches: int = 0, pam_d
     targets.py:44-46, shrinks to k + |pam| - 1 bases here) and coordinates are
     folded exactly as targets.py:380-384; every site is reported once
     (the reference removes the overhang duplicates with drop_duplicates, :607).
+
+    report_unaligned: a guide (name) with no placement that survives the PAM test
+    gets the bare row {name, spacer, len} the reference emits for unmapped and
+    PAM-rejected reads (targets.py:354-366) — what becomes a "non-targeting" row.
+
+    max_alignments: the reference runs `bowtie -k 100` (targets.py:499): at most
+    100 alignments per read, which ones being Bowtie's choice.  Here every
+    placement is reported (None); an integer keeps the first `max_alignments`
+    per guide in (chromosome order, position, strand) order — a deterministic
+    stand-in, not Bowtie's selection (documented deviation).
+
+    The whole search runs on the device per chromosome and strand: genome upload,
+    PAM bitmaps (bc_pam_scan_dev), windows (bc_windows_dev), PAM-gated all-hits
+    search (bc_match_all_pam_dev); only the surviving hit records come back.
     """
     if pam_direction not in ("downstream", "upstream"):
         raise ValueError("pam_direction must be 'upstream' or 'downstream'")
-    names = None
     if isinstance(guides, dict):
-        names, guides = list(guides.keys()), list(guides.values())
-    guides = list(guides)
-    labels = list(dict.fromkeys(guides))
-    k = len(labels[0])
+        pairs = list(guides.items())
+    else:
+        guides = list(guides)
+        pairs = guides if (guides and isinstance(guides[0], tuple)) else [(g, g) for g in guides]
+    pairs = [(nm, sq) for nm, sq in pairs]
+    by_seq = {}
+    for nm, sq in pairs:
+        by_seq.setdefault(sq, []).append(nm)
+    rows = []
+    # one library per guide length (a FASTA of guides may mix lengths; the packed matcher wants one k)
+    searchable = {}
+    for sq in by_seq:
+        if 1 <= len(sq) <= 32 and set(sq) <= set("ACGT"):
+            searchable.setdefault(len(sq), []).append(sq)
+    for k, labels in sorted(searchable.items()):
+        rows += _find_hits_k(labels, k, chromosomes, pam, num_mismatches, pam_direction, device, max_alignments)
+    hit_seqs = {r["spacer"] for r in rows}
+    rows = [dict(r, name=nm) for r in rows for nm in by_seq[r["spacer"]]]  # one row per (name, hit) like the SAM query names
+    rows.sort(key=lambda r: (r["chr"], min(r["tar_start"], r["tar_end"]), r["spacer"]))  # targets.py:629-630
+    if report_unaligned:
+        seen = set()
+        for nm, sq in pairs:
+            if sq not in hit_seqs and (nm, sq) not in seen:
+                seen.add((nm, sq))
+                rows.append({"name": nm, "spacer": sq, "len": len(sq)})
+    return rows
+
+
+def _find_hits_k(labels, k, chromosomes, pam, num_mismatches, pam_direction, device, max_alignments):
     lib = DeviceLibrary.from_strings(labels, device)
-    matcher = GpuMatcher(lib)
+    if num_mismatches >= k:
+        raise ValueError(f"{num_mismatches} mismatches on {k}-mers: every window would match")
     pl = len(pam)
     any_pam = (not pam) or pam == "N" * pl
-    rows = []
     L = N.load()
+    N.check(L.bc_dev_set(device))
+    out = []
+    per_guide = {}
     for ch in chromosomes:
         n = len(ch.seq)
+        if n == 0:
+            continue
         wrap = (k + pl - 1) if ch.circular else 0
         g = pack_genome(ch.seq, wrap)
         npos = n if ch.circular else max(0, n - k + 1)
         if npos == 0:
             continue
-        # PAM bitmaps over the padded sequence
-        if not any_pam:
-            masks = pam_masks(pam)
-            fwd_w = np.zeros(g.bases.size, np.uint32)
-            rev_w = np.zeros(g.bases.size, np.uint32)
-            N.check(L.bc_pam_scan_host(device, N.ptr(g.bases), N.ptr(g.invalid), g.total, N.ptr(masks), pl,
-                                       N.ptr(fwd_w), N.ptr(rev_w)))
-            pam_f, pam_r = _bits(fwd_w, g.total), _bits(rev_w, g.total)
-        for strand in (0, 1):
-            words, flags = genome_windows(g, npos, k, strand, device)
-            hits = matcher.all_hits(words, flags, num_mismatches)
-            if hits.size == 0:
-                continue
-            p = hits["query"].astype(np.int64)
-            # PAM footprint on forward coordinates for this strand / direction
-            if (strand == 0) == (pam_direction == "downstream"):
-                pp = p + k           # right of the window
-                pp_ok = pp + pl <= g.total
-            else:
-                pp = p - pl          # left of the window
+        nw = g.bases.size
+        topo = np.frombuffer((ch.seq + ch.seq[:wrap]).upper().encode("ascii", errors="replace"), np.uint8)
+        gate = not any_pam
+        with DevBuf.from_numpy(g.bases, device) as d_b, DevBuf.from_numpy(g.invalid, device) as d_i, \
+                DevBuf(nw * 4, device) as d_f, DevBuf(nw * 4, device) as d_r, \
+                DevBuf(npos * 8, device) as d_w, DevBuf(npos, device) as d_fl, DevBuf(8, device) as d_n:
+            if gate:
+                # N = '.' here (targets.py:224): an odd genome character under an N of the PAM still matches
+                masks = pam_masks(pam, n_is_dot=True)
+                N.check(L.bc_pam_scan_dev(d_b.ptr, d_i.ptr, g.total, N.ptr(masks), pl, d_f.ptr, d_r.ptr, None))
+            for strand in (0, 1):
+                right = (strand == 0) == (pam_direction == "downstream")  # PAM footprint right of the window
+                shift = k if right else -pl
+                N.check(L.bc_windows_dev(d_b.ptr, d_i.ptr, g.total, None, npos, 0, k, strand, d_w.ptr, d_fl.ptr, None))
+                cap = max(1024, 2 * len(labels))
+                while True:
+                    with DevBuf(cap * 12, device) as d_h:
+                        N.check(L.bc_dev_memset(d_n.ptr, 0, 8, None))
+                        if gate:
+                            N.check(L.bc_match_all_pam_dev(lib.handle, d_w.ptr, d_fl.ptr, npos, int(num_mismatches),
+                                                           (d_f if strand == 0 else d_r).ptr, shift, g.total - pl + 1,
+                                                           n if ch.circular else 0, d_h.ptr, cap, d_n.ptr, None))
+                        else:
+                            N.check(L.bc_match_all_dev(lib.handle, d_w.ptr, d_fl.ptr, npos, int(num_mismatches),
+                                                       d_h.ptr, cap, d_n.ptr, None))
+                        m = int(d_n.to_numpy(np.uint64, 1)[0])
+                        if m <= cap:
+                            hits = d_h.to_numpy(N.HIT_DTYPE, m) if m else np.zeros(0, N.HIT_DTYPE)
+                            break
+                    cap = m
+                if hits.size == 0:
+                    continue
+                hits = np.sort(hits, order=("query", "guide"))
+                p = hits["query"].astype(np.int64)
+                pp = p + shift
                 if ch.circular:
                     pp = np.where(pp < 0, pp + n, pp)
-                pp_ok = pp >= 0
-            if any_pam:
-                keep = pp_ok if pl else np.ones(p.size, bool)
-            else:
-                bm = pam_f if strand == 0 else pam_r
-                keep = pp_ok & bm[np.clip(pp, 0, g.total - 1)]
-            for h, pam_at in zip(hits[keep], pp[keep]):
-                pos, gi, dist = int(h["query"]), int(h["guide"]), int(h["dist"])
-                topo_end = pos + k
-                foot = _slice(ch, pos, topo_end)
-                target = foot if strand == 0 else rev_comp(foot)
-                ext = _slice(ch, int(pam_at), int(pam_at) + pl) if pl else None
-                if ext is not None and strand == 1:
-                    ext = rev_comp(ext)
-                tar_start, tar_end = pos % n, topo_end % n  # targets.py:380-384
-                if tar_end < tar_start:
-                    tar_start -= n
-                spacer = labels[gi]
-                rows.append({
-                    "name": spacer, "spacer": spacer, "len": k, "target": target, "mismatches": dist,
-                    "chr": ch.name, "tar_start": tar_start, "tar_end": tar_end, "sp_dir": "F" if strand == 0 else "R",
-                    "pam": ext, "coords": get_coords(tar_start, tar_end, n),
-                    "type": "mismatch" if dist > 0 else "perfect", "diff": get_diff(spacer, target),
-                })
-    if names is not None:  # one row per (name, hit) like the SAM query names
-        by_seq = {}
-        for nm, sq in zip(names, guides):
-            by_seq.setdefault(sq, []).append(nm)
-        rows = [dict(r, name=nm) for r in rows for nm in by_seq[r["spacer"]]]
-    rows.sort(key=lambda r: (r["chr"], min(r["tar_start"], r["tar_end"]), r["spacer"]))  # targets.py:629-630
-    return rows
+                if not gate and pl:  # all-N PAM: only its footprint has to exist (targets.py:219-224)
+                    keep = (pp >= 0) & (pp + pl <= g.total)
+                    hits, p, pp = hits[keep], p[keep], pp[keep]
+                gi = hits["guide"].astype(np.int64)
+                dist = hits["dist"].astype(np.int64)
+                if max_alignments is not None:
+                    sel = np.ones(p.size, bool)
+                    for j, gj in enumerate(gi.tolist()):
+                        c = per_guide.get(gj, 0)
+                        sel[j] = c < max_alignments
+                        per_guide[gj] = c + 1
+                    p, pp, gi, dist = p[sel], pp[sel], gi[sel], dist[sel]
+                rc = np.full(p.size, strand == 1)
+                targets = _windows_as_strings(topo, p, k, rc)
+                pams = _windows_as_strings(topo, pp, pl, rc) if pl else [None] * p.size
+                tar_start = p % n                               # targets.py:380-384
+                tar_end = (p + k) % n
+                tar_start = np.where(tar_end < tar_start, tar_start - n, tar_start)
+                sp_dir = "F" if strand == 0 else "R"
+                for j in range(p.size):
+                    spacer = labels[int(gi[j])]
+                    a, b, d = int(tar_start[j]), int(tar_end[j]), int(dist[j])
+                    out.append({"name": spacer, "spacer": spacer, "len": k, "target": targets[j], "mismatches": d,
+                                "chr": ch.name, "tar_start": a, "tar_end": b, "sp_dir": sp_dir, "pam": pams[j],
+                                "coords": get_coords(a, b, n), "type": "mismatch" if d > 0 else "perfect",
+                                "diff": get_diff(spacer, targets[j]) if d else None})
+    lib.close()
+    return out
 
 
 def _slice(ch: Chromosome, a: int, b: int) -> str:
@@ -254,7 +329,8 @@ def read_genes_tsv(path, seq_lens=None):
 def annotate(rows, genes):
     """The gene join of parse_sam_output (targets.py:412-462): a hit row is repeated for every gene
     that covers at least one base of [tar_start, tar_end); rows without a gene keep None fields.
-    The reference walks a per-base dict; interval overlap gives the same set."""
+    The reference walks a per-base dict; interval overlap gives the same set.  Bare rows of
+    unaligned guides ({name, spacer, len}, targets.py:354-366) pass through untouched."""
     by_chr = {}
     for g in genes:
         by_chr.setdefault(g.chrom, []).append(g)
@@ -264,6 +340,9 @@ def annotate(rows, genes):
         starts[c] = np.array([g.start for g in lst])
     out = []
     for r in rows:
+        if r.get("target") is None:
+            out.append(dict(r))
+            continue
         lst = by_chr.get(r["chr"], [])
         a, b = r["tar_start"], r["tar_end"]
         hit = []
@@ -298,28 +377,34 @@ def create_note(sites, genes, intergenic):
     return ", ".join(parts)
 
 
+ALL_KEYS = ["name", "spacer", "len", "target", "mismatches", "chr", "tar_start", "tar_end", "sp_dir", "pam",
+            "coords", "type", "diff", "locus_tag", "gene", "offset", "overlap", "tar_dir"]
+
+
 def final_table(rows, seq_lens):
     """The post-processing of targets.main (targets.py:605-688) on annotated rows:
-    de-duplicate, drop PAM-less rows of spacers that do target, sort by (chr, min_tar, spacer),
-    per-spacer site / gene / intergenic counts -> note, column selection.
-    Returns (columns, list of row dicts)."""
+    de-duplicate, drop the bare rows of spacers that do target, sort by (chr, min_tar, spacer)
+    with missing values last (pandas sort_values), per-spacer site / gene / intergenic counts ->
+    note, column selection.  Returns (columns, list of row dicts)."""
     def freeze(r, keys):
         return tuple(r.get(k) for k in keys)
-    all_keys = ["name", "spacer", "len", "target", "mismatches", "chr", "tar_start", "tar_end", "sp_dir", "pam",
-                "coords", "type", "diff", "locus_tag", "gene", "offset", "overlap", "tar_dir"]
-    rows = list({freeze(r, all_keys): r for r in rows}.values())                      # drop_duplicates (:607)
+    rows = list({freeze(r, ALL_KEYS): r for r in rows}.values())                      # drop_duplicates (:607)
     targeting = {r["spacer"] for r in rows if r.get("target") is not None}            # filter_offtargets_by_pam
     rows = [r for r in rows if not (r.get("target") is None and r["spacer"] in targeting)]
+    if not any(r.get("target") is not None for r in rows):
+        # the reference dies here: no row has a `target` column (KeyError in filter_offtargets_by_pam, :609-621)
+        raise KeyError("target")
 
     def min_tar(r):                                                                    # :624-628
         if r.get("tar_start") is None:
             return float("inf")
         return r["tar_start"] - seq_lens[r["chr"]] if r["tar_start"] > r["tar_end"] else r["tar_start"]
-    rows.sort(key=lambda r: (r.get("chr") or "", min_tar(r), r["spacer"]))            # :629-630
+    # sort_values(by=[chr, min_tar, spacer]): NaN last in each key
+    rows.sort(key=lambda r: (r.get("chr") is None, r.get("chr") or "", min_tar(r), r["spacer"]))   # :629-630
     names = {}
     for r in rows:
         names.setdefault(r["spacer"], set()).add(r["name"])
-    keys_wo_name = [k for k in all_keys if k != "name"]
+    keys_wo_name = [k for k in ALL_KEYS if k != "name"]
     rows = list({freeze(r, keys_wo_name): r for r in rows}.values())                  # :635
     sites, genes, inter = {}, {}, {}
     for r in rows:
@@ -335,12 +420,12 @@ def final_table(rows, seq_lens):
         out.append(dict(r, count=len(names[sp]),
                         note=create_note(len(sites.get(sp, ())), genes.get(sp, 0), inter.get(sp, 0))))
     cols = ["spacer", "locus_tag", "gene", "chr"]
-    if any(r["count"] != 1 for r in out):
+    if any(r["count"] != 1 for r in out):                                              # :672-673
         cols.append("count")
     pams = {r.get("pam") for r in out if r.get("pam") is not None}
-    if not (not pams or (len(pams) == 1 and all(r.get("pam") is not None for r in out))):
+    if len(pams) > 1:                                 # not (pam.isnull().all() or pam.nunique() == 1), :674-675
         cols.append("pam")
-    if any(r.get("mismatches") not in (0, None) for r in out):
+    if any(r.get("mismatches") != 0 for r in out):    # not (mismatches == 0).all(): a missing value is not 0, :676-677
         cols.append("mismatches")
     cols += ["target", "tar_start", "tar_end", "offset", "overlap", "sp_dir", "tar_dir", "note"]
     return cols, out
@@ -348,7 +433,182 @@ def final_table(rows, seq_lens):
 
 def to_tsv(cols, rows) -> str:
     """DataFrame.to_csv(sep='\\t', index=False, na_rep='None') of targets.py:701."""
-    lines = ["\t".join(cols)]
+    import csv
+    import io
+    buf = io.StringIO()
+    w = csv.writer(buf, delimiter="\t", lineterminator="\n", quoting=csv.QUOTE_MINIMAL)  # pandas' writer settings
+    w.writerow(cols)
     for r in rows:
-        lines.append("\t".join("None" if r.get(c) is None else str(r[c]) for c in cols))
-    return "\n".join(lines) + "\n"
+        w.writerow(["None" if r.get(c) is None else str(r[c]) for c in cols])
+    return buf.getvalue()
+
+
+def _json_str(s: str) -> str:
+    """a JSON string the way pandas' writer escapes it (ASCII only, '/' escaped)"""
+    import json
+    return json.dumps(str(s), ensure_ascii=True).replace("/", "\\/")
+
+
+def to_json(cols, rows) -> str:
+    """DataFrame.to_json(orient="records", indent=4) of targets.py:696-698: one object per row in
+    column order, missing values (and the nullable Int64 columns' <NA>) as null, `"key":value`
+    without a space, 4-space indentation."""
+    if not rows:
+        return "[\n\n]"
+    objs = []
+    for r in rows:
+        fields = []
+        for c in cols:
+            v = r.get(c)
+            if v is None:
+                txt = "null"
+            elif isinstance(v, bool):
+                txt = "true" if v else "false"
+            elif isinstance(v, (int, np.integer)):
+                txt = str(int(v))
+            elif isinstance(v, (float, np.floating)):
+                txt = "null" if v != v else repr(float(v))
+            else:
+                txt = _json_str(v)
+            fields.append(f"        {_json_str(c)}:{txt}")
+        objs.append("    {\n" + ",\n".join(fields) + "\n    }")
+    return "[\n" + ",\n".join(objs) + "\n]"
+
+
+# ------------------------------------------------------------------ GenBank input + the script's main()
+def chromosomes_and_genes(genbank_path):
+    """(chromosomes, genes, seq_lens, organisms, topologies, gene_counts) from a GenBank file: what
+    create_topological_fasta (targets.py:35-56) and create_locus_map (:76-165) derive from it.  A `gene`
+    feature in several parts contributes one interval per part, except a compound location that touches both
+    ends of the record, which becomes ONE interval from the start of its last part to the end of its first
+    part + len(record) (:105-128)."""
+    from .genbank import read_genbank
+    chroms, genes, seq_lens, organisms, topologies, counts = [], [], {}, {}, {}, {}
+    for rec in read_genbank(genbank_path):
+        n = len(rec.seq)
+        chroms.append(Chromosome(rec.id, rec.seq, rec.topology == "circular"))
+        seq_lens[rec.id], organisms[rec.id], topologies[rec.id] = n, rec.organism, rec.topology
+        cnt = 0
+        for ft in rec.features:
+            if ft.key != "gene":
+                continue
+            cnt += 1
+            lt = (ft.qualifiers.get("locus_tag") or [None])[0]
+            gn = (ft.qualifiers.get("gene") or [None])[0]
+            parts = ft.parts
+            if len(parts) > 1 and any(a == 0 or b == n for a, b in parts):
+                tail = next((p for p in parts if p[1] == n), None)
+                head = next((p for p in parts if p[0] == 0), None)
+                if tail is None or head is None:
+                    raise ValueError(f"gene {lt}: a compound location that touches only one end of {rec.id}")  # the reference's next() raises there (:112-119)
+                genes.append(Gene(rec.id, tail[0], head[1] + n, ft.strand, lt, gn))
+                continue
+            genes += [Gene(rec.id, a, b, ft.strand, lt, gn) for a, b in parts]
+        counts[rec.id] = cnt
+    return chroms, genes, seq_lens, organisms, topologies, counts
+
+
+def read_guides(path):
+    """[(name, sequence)] of the sgRNA file as the reference feeds it to Bowtie (targets.py:567-580):
+    a FASTQ as it is, a FASTA (optionally .gz) record by record; the name is the first word of the header."""
+    import gzip
+    base = os.path.basename(path)
+    op = gzip.open if path.endswith(".gz") else open
+    out = []
+    if ".fastq" in base:
+        with op(path, "rt") as fh:
+            lines = fh.read().splitlines()
+        for i in range(0, len(lines) - 1, 4):
+            if lines[i].startswith("@"):
+                out.append((lines[i][1:].split()[0] if lines[i][1:].split() else "", lines[i + 1].strip()))
+        return out
+    if base.endswith(".fasta") or base.endswith(".fasta.gz"):
+        name, seq = None, []
+        with op(path, "rt") as fh:
+            for line in fh:
+                line = line.rstrip("\r\n")
+                if line.startswith(">"):
+                    if name is not None:
+                        out.append((name, "".join(seq)))
+                    w = line[1:].split()
+                    name, seq = (w[0] if w else ""), []
+                elif name is not None:
+                    seq.append(line.strip())
+        if name is not None:
+            out.append((name, "".join(seq)))
+        return out
+    raise ValueError("File extension not recognized.")
+
+
+def main(args, device: int = 0, out=None):
+    """The script (targets.py:560-701, :864-885): sgRNA FASTA/FASTQ + GenBank genome + PAM + mismatches ->
+    the annotated hit table on stdout as TSV, or JSON with --json; progress and a short summary on stderr.
+    Bowtie is bypassed: the search is find_hits."""
+    out = out or sys.stdout
+    log = lambda msg: print(msg, file=sys.stderr)  # noqa: E731
+    log("Initializing barcode target seeker")
+    try:
+        guides = read_guides(args.sgrna_file)
+    except ValueError as e:
+        log(str(e))
+        sys.exit(1)
+    log("Generating topological coordinate maps...")
+    chroms, genes, seq_lens, organisms, topologies, gene_counts = chromosomes_and_genes(args.genome_file)
+    log("Aligning annotations to genome...")
+    rows = find_hits([(nm, sq.upper()) for nm, sq in guides], chroms, pam=args.pam, num_mismatches=args.mismatches,
+                     pam_direction=args.pam_direction, device=device, report_unaligned=True)
+    if not rows:
+        raise RuntimeError("No results were returned from the search. Check your input files and parameters.")
+    log("Finding matches...")
+    try:
+        cols, table = final_table(annotate(rows, genes), seq_lens)
+    except KeyError as e:
+        log(f"The following critical attribute is missing for every barcode: {e}")
+        log(f"Are you sure your PAM should be '{args.pam}' '{args.pam_direction}' of the spacer?")
+        log(f"The genome file '{args.genome_file}' has definitions for these chromosomes:")
+        import json
+        log(json.dumps(organisms, indent=4))
+        sys.exit(1)
+    if getattr(args, "json", False):
+        log("Writing to JSON...")
+        print(to_json(cols, table), file=out)
+    else:
+        log("Writing to TSV...")
+        out.write(to_tsv(cols, table))
+    lens = sorted({r["len"] for r in table})
+    targeting = {r["spacer"] for r in table if r.get("target") is not None}
+    summary = [("Barcodes", os.path.basename(args.sgrna_file)), ("Genbank Genome File", os.path.basename(args.genome_file)),
+               ("PAM", args.pam), ("PAM Direction", args.pam_direction.capitalize()),
+               ("Number of Mismatches", args.mismatches), ("Spacer Lengths", ",".join(str(x) for x in lens)),
+               ("Organism", ", ".join(sorted({str(o) for o in organisms.values()})) or "Unknown"),
+               ("Topology", ", ".join(sorted({str(t) for t in topologies.values()}))),
+               ("Chromosomes", len(seq_lens)), ("Total Genes", f"{sum(gene_counts.values()):,}"),
+               ("Chromosomes Targeted", len({r["chr"] for r in table if r.get("chr")})),
+               ("Genes Targeted", len({r["locus_tag"] for r in table if r.get("locus_tag")})),
+               ("Unique Barcodes", len({r["spacer"] for r in table})),
+               ("Intergenic Barcodes", len({r["spacer"] for r in table if r.get("locus_tag") is None and r.get("chr")})),
+               ("Off-targeting Barcodes", sum(1 for sp in targeting
+                                              if len({r["coords"] for r in table if r["spacer"] == sp and r.get("target")}) > 1)
+                if len(targeting) < 20000 else "n/a"),
+               ("Non-targeting Barcodes", len({r["spacer"] for r in table if r.get("target") is None}))]
+    for k_, v in summary:
+        log(f"{k_:>30}  {v}")
+
+
+def _cli():
+    import argparse
+    p = argparse.ArgumentParser(description="Map barcodes to a circular genome")
+    p.add_argument("sgrna_file", help="Path to sgrna_fasta_file", type=str)
+    p.add_argument("genome_file", help="Path to genome_gb_file", type=str)
+    p.add_argument("pam", help="PAM sequence", type=str)
+    p.add_argument("mismatches", help="Number of allowed mismatches", type=int)
+    p.add_argument("--pam_direction", choices=["upstream", "downstream"], default="downstream",
+                   help="Direction of the PAM sequence")
+    p.add_argument("--json", action="store_true", default=False, help="Output results in JSON format")
+    p.add_argument("--device", type=int, default=0)
+    a = p.parse_args()
+    main(a, device=a.device)
+
+
+if __name__ == "__main__":
+    _cli()

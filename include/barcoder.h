@@ -59,6 +59,9 @@ extern "C" {
 #define BC_ALGO_BRUTE 3 /* LDS-tiled all-pairs XOR+popcount, any d          */
 #define BC_ALGO_SEED_CSR 4 /* the seed index in its CSR layout, always      */
 
+/* PAM pattern position: also accept a genome character that is not ACGT */
+#define BC_PAM_ANY_CHAR 16
+
 /* window status written by bc_pack_windows */
 #define BC_WIN_OK 0       /* flanks present, k-mer packed                        */
 #define BC_WIN_SKIP 1     /* 'N' in read, or flanks absent: contributes nothing  */
@@ -232,6 +235,18 @@ int bc_match_all_dev(bc_lib *lib, const uint64_t *d_queries, const uint8_t *d_fl
                      uint64_t n, int max_mismatch, bc_hit *d_hits, uint64_t cap,
                      uint64_t *d_n_hits, void *stream);
 
+/* Same search gated by a PAM bitmap: query i is the genome window at position i
+ * and is searched only if bit (i + pam_shift) of d_pam_bits is set — a bitmap
+ * from bc_pam_scan_dev for the window's strand; positions outside
+ * [0, pam_limit) fail, negative ones wrap once by wrap_len when it is non-zero
+ * (circular sequence).  This is the PAM test of targets.py:325-352
+ * (extract_downstream_pam / extract_upstream_pam + pam_matches) applied before
+ * the search instead of to every alignment after it. */
+int bc_match_all_pam_dev(bc_lib *lib, const uint64_t *d_windows, const uint8_t *d_flags,
+                         uint64_t n, int max_mismatch, const uint32_t *d_pam_bits,
+                         int64_t pam_shift, uint64_t pam_limit, uint64_t wrap_len,
+                         bc_hit *d_hits, uint64_t cap, uint64_t *d_n_hits, void *stream);
+
 /* ---- genome encoding + PAM site scan (K4) --------------------------------
  * bc_genome_pack: ASCII bases -> one uint64 per 32 positions in the same plane
  * form as a 32-mer (word w = positions 32w..32w+31; low half = low code bits,
@@ -250,8 +265,10 @@ int bc_genome_pack(const char *h_seq, uint64_t len, uint64_t wrap, uint64_t *h_b
  * whether revcomp(PAM) matches there, i.e. a PAM on the reverse strand (bitmap
  * rev).  Bit p%32 of word p/32; ceil(total_len/32) words each.
  * `pam_masks[j]` is the IUPAC set of pattern position j as a 4-bit mask
- * (bit0=A bit1=C bit2=G bit3=T; N = 15).  Non-ACGT genome characters and
- * positions past total_len never match.
+ * (bit0=A bit1=C bit2=G bit3=T; N = 15).  Positions past total_len never
+ * match; a genome character that is not ACGT matches only a pattern position
+ * that carries BC_PAM_ANY_CHAR as well (the '.' targets.py:224 writes for N;
+ * PAMProcessor.py:31 and design_guides.py:26 write [ATCG], i.e. no flag).
  * This is the per-position test of PAMProcessor.py:34-57
  * (GuideFinder.find_guides_from_pam), design_guides.py:22-49
  * (find_sequences_with_barcode_and_pam) and targets.py:219-224 (pam_matches);

@@ -247,3 +247,138 @@ def test_design_guides_pipeline(gpu_device, plasmids, oracle):
     assert got_first == first
     assert len(rows) < len(untiled) // 2 and len(untiled) < len(full)
     assert T.to_tsv(cols, rows).startswith("spacer\tlocus_tag\tgene\tchr")
+
+
+def _plasmid_genbank(tmp_path, plasmids):
+    """The shipped plasmids (sequence + SnapGene gene table) in the CLI's input format."""
+    from barcoder_amd import genbank as GB
+    feats = {c.name: [] for c in plasmids}
+    with open(os.path.join(GOLDEN, "plasmid_genes.tsv")) as fh:
+        next(fh)
+        for line in fh:
+            c, parts, strand, lt, gn = line.rstrip("\n").split("\t")
+            iv = [tuple(int(x) for x in part.split("-")) for part in parts.split(";")]
+            if int(strand) == -1:
+                iv = iv[::-1]  # complement(join(...)): parts last-first, as the reader hands them out
+            q = {}
+            if lt != "None":
+                q["locus_tag"] = [lt]
+            if gn != "None":
+                q["gene"] = [gn]
+            feats[c].append(GB.GbFeature("gene", iv, int(strand), q))
+    recs = [GB.GbRecord(c.name, c.name.split(".")[0], c.seq, "circular", "Zymomonas mobilis", feats[c.name]) for c in plasmids]
+    path = tmp_path / "plasmids.gb"
+    GB.write_genbank(path, recs)
+    return str(path)
+
+
+def test_genbank_round_trip(tmp_path, plasmids, gpu_device):
+    from barcoder_amd import genbank as GB, targets as T
+    path = _plasmid_genbank(tmp_path, plasmids)
+    recs = GB.read_genbank(path)
+    assert [r.id for r in recs] == NAMES and all(r.topology == "circular" for r in recs)
+    assert [r.seq for r in recs] == [c.seq.upper() for c in plasmids]
+    chroms, genes, lens, org, topo, counts = T.chromosomes_and_genes(path)
+    want = T.read_genes_tsv(os.path.join(GOLDEN, "plasmid_genes.tsv"), lens)
+    key = lambda g: (g.chrom, g.start, g.end, g.strand, g.locus_tag, g.gene)
+    assert sorted(map(key, genes)) == sorted(map(key, want)) and len(genes) == 160
+    assert set(org.values()) == {"Zymomonas mobilis"} and sum(counts.values()) >= 150
+
+
+def test_cli_twin_tsv_json_and_non_targeting(gpu_device, tmp_path, plasmids):
+    """`python -m barcoder_amd.targets guides.fasta genome.gb NGNC 0 [--json]` (targets.py:864-885): the TSV carries the
+    shipped rows; the JSON (to_json, records / indent 4 / nulls) parses to the same table; a guide that is absent
+    from the genome comes out as ONE non-targeting row with empty coordinates (targets.py:354-366, :547-557), which
+    also switches the `mismatches` column on (its missing value is not 0, :676-677)."""
+    import json
+    import subprocess
+    import sys
+    from barcoder_amd import design as D, targets as T
+    gold = _golden_rows()
+    gb = _plasmid_genbank(tmp_path, plasmids)
+    spacers = list(dict.fromkeys(r["spacer"] for r in gold))
+    absent = "ACGT" * 8
+    assert all(absent not in (c.seq + c.seq[:40]).upper() for c in plasmids)
+    fa = tmp_path / "guides.fasta"
+    fa.write_text("".join(f">g{i} some description\n{s}\n" for i, s in enumerate(spacers)) + f">nowhere\n{absent}\n>nowhere_twin\n{absent}\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *extra: subprocess.run([sys.executable, "-m", "barcoder_amd.targets", str(fa), gb, "NGNC", "0", *extra],
+                                        cwd=root, capture_output=True, text=True, timeout=600)
+    tsv = run()
+    assert tsv.returncode == 0, tsv.stderr[-1500:]
+    lines = tsv.stdout.splitlines()
+    cols = lines[0].split("\t")
+    assert cols == ["spacer", "locus_tag", "gene", "chr", "count", "pam", "mismatches", "target", "tar_start", "tar_end",
+                    "offset", "overlap", "sp_dir", "tar_dir", "note"]
+    table = [dict(zip(cols, ln.split("\t"))) for ln in lines[1:]]
+    bare = [r for r in table if r["spacer"] == absent]
+    assert len(bare) == 1 and bare[0]["note"] == "non-targeting" and bare[0]["count"] == "2"
+    assert all(bare[0][c] == "None" for c in cols if c not in ("spacer", "count", "note"))
+    assert table[-1] is bare[0] or table[-1]["spacer"] == absent          # missing chr sorts last (pandas sort_values)
+    # the targeting part equals the shipped rows once the library's own design filter is applied
+    hit_rows = [dict(r, count=None) for r in table if r["spacer"] != absent]
+    common = [c for c in cols if c not in ("note", "count")]
+    _, kept = D.filter_guides(cols, hit_rows, 32, orientation="forward")
+    from collections import Counter
+    got = Counter(tuple(str(r[c]) for c in common) for r in kept)
+    want = Counter(tuple(r[c] for c in common) for r in gold)
+    assert got == want and sum(got.values()) == 772
+    assert "Non-targeting Barcodes" in tsv.stderr and "Writing to TSV" in tsv.stderr
+    # JSON: same table, typed
+    js = run("--json")
+    assert js.returncode == 0, js.stderr[-1500:]
+    recs = json.loads(js.stdout)
+    assert len(recs) == len(table) and list(recs[0]) == cols
+    ints = {"count", "mismatches", "tar_start", "tar_end", "offset", "overlap"}
+    for r_t, r_j in zip(table, recs):
+        for c in cols:
+            want_v = None if r_t[c] == "None" else (int(r_t[c]) if c in ints else r_t[c])
+            assert r_j[c] == want_v, (c, r_t[c], r_j[c])
+    assert js.stdout.startswith('[\n    {\n        "spacer":"') and '"locus_tag":null' in js.stdout
+    # unknown sgRNA extension: message + exit status 1 (targets.py:579-581)
+    bad = subprocess.run([sys.executable, "-m", "barcoder_amd.targets", str(tmp_path / "x.txt"), gb, "NGG", "0"], cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 1 and "File extension not recognized" in bad.stderr
+
+
+def test_to_json_equals_pandas(gpu_device, plasmids):
+    """to_json against pandas' own DataFrame.to_json(orient="records", indent=4) (the call at targets.py:698) on a
+    table with missing values, nullable integer columns and characters pandas escapes."""
+    import pandas as pd
+    from barcoder_amd import targets as T
+    gold = _golden_rows()
+    spacers = list(dict.fromkeys(r["spacer"] for r in gold))[:40] + ["ACGT" * 8]
+    lens = {c.name: len(c.seq) for c in plasmids}
+    genes = T.read_genes_tsv(os.path.join(GOLDEN, "plasmid_genes.tsv"), lens)
+    rows = T.find_hits(spacers, plasmids, pam="NGNC", num_mismatches=1, device=gpu_device, report_unaligned=True)
+    cols, table = T.final_table(T.annotate(rows, genes), lens)
+    table[0] = dict(table[0], gene='a/b "q" é')
+    df = pd.DataFrame(table).reindex(columns=cols)
+    for c in ("mismatches", "offset", "overlap", "tar_start", "tar_end"):
+        if c in df.columns:
+            df[c] = df[c].astype("Int64")
+    assert T.to_json(cols, table) == df.to_json(orient="records", indent=4)
+    assert T.to_tsv(cols, table) == df.to_csv(sep="\t", index=False, na_rep="None")
+
+
+def test_pam_dot_semantics_and_alignment_cap(gpu_device):
+    """targets.py:224 turns N into '.', so a genome character that is not ACGT under an N of the PAM still matches
+    (PAMProcessor.py:31 / design_guides.py:26 write [ATCG]: it does not, there).  max_alignments keeps the first
+    hits per guide in (chromosome, position, strand) order — the documented stand-in for `bowtie -k 100`."""
+    from barcoder_amd import pam as P, targets as T
+    from barcoder_amd.encoding import pam_masks
+    guide = "ACGTTGCAAGGCTTACGATC"
+    seq = "TT" + guide + "RGG" + "CCCC" + guide + "AGG" + "TTTT" + guide + "AGA" + "GG"
+    ch = [T.Chromosome("c", seq, False)]
+    rows = T.find_hits([guide], ch, pam="NGG", num_mismatches=0, device=gpu_device)
+    assert [(r["tar_start"], r["pam"]) for r in rows] == [(2, "RGG"), (29, "AGG")]
+    fwd, _ = P.pam_scan(seq, "NGG", device=gpu_device)                 # GuideFinder flavour: [ATCG]GG
+    assert not fwd[22] and fwd[49]
+    assert pam_masks("NGG", n_is_dot=True).tolist() == [31, 4, 4] and pam_masks("NGG").tolist() == [15, 4, 4]
+    many = T.Chromosome("m", ("AA" + guide + "TGGC") * 30, False)
+    full = T.find_hits([guide], [many], pam="NGG", num_mismatches=0, device=gpu_device)
+    capped = T.find_hits([guide], [many], pam="NGG", num_mismatches=0, device=gpu_device, max_alignments=7)
+    assert len(full) == 30 and capped == full[:7]
+    both = T.find_hits([("a", guide), ("b", guide), ("c", "T" * 20)], [many], pam="NGG", num_mismatches=0,
+                       device=gpu_device, report_unaligned=True)
+    assert len(both) == 61 and both[-1] == {"name": "c", "spacer": "T" * 20, "len": 20}
