@@ -1,0 +1,539 @@
+// bc_stream.hip — a reads file straight through the device: the raw bytes of an
+// uncompressed .reads / .fastq file are uploaded in chunks and everything process_chunk does per read
+// (heuristicount.py:428-562) happens in HBM: line splitting, whitespace strip (:127,:138), N-skip (:524), window
+// slice (:527), flank test (:458-460), 2-bit packing, optional reverse complement (:532-533), the library match
+// with its per-guide tally, and the collection of the flank-valid windows that match nothing (the "undocumented"
+// barcodes, :455-457), which are grouped at the end by one device sort + run-length pass instead of per-chunk
+// host work.  Only counts, first-seen keys, the undocumented table and the rare odd windows (flanks present but
+// the window short or not pure ACGT: string semantics, handled by the caller) return to the host.
+//
+// Host side: worker threads take fixed byte chunks of the file in turn — pread into a pinned buffer, count the
+// newlines that the chunk owns, upload, launch — each on its own stream with its own device buffers, so file
+// reads, PCIe and kernels overlap.  A chunk owns the lines whose preceding newline lies in it (the line at the
+// start of the range is owned by the first chunk); it is uploaded with one byte of left context and a slack of
+// SLACK bytes on the right so that its last line is complete.
+#include <fcntl.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "bc_device.h"
+
+using namespace bc;
+
+namespace {
+
+constexpr uint64_t CHUNK = 16ull << 20;   // bytes of file per device pass
+constexpr uint64_t SLACK = 1ull << 20;    // longest line that may run past a chunk's end
+
+struct Geometry {
+    int64_t start;
+    int L_len, R_len, k, reverse, fastq;
+    char L[16], R[16];
+};
+
+// 1 bit per byte: is it '\n'?  One lane covers 32 bytes (two 16-byte loads).
+__global__ __launch_bounds__(BLOCK) void k_nl_bitmap(const uint8_t* __restrict__ text, uint64_t nbytes,
+                                                     uint32_t* __restrict__ bits, uint64_t n_words) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t w = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += stride) {
+        const uint64_t a = w * 32;
+        uint32_t m = 0;
+        if (a + 32 <= nbytes) {
+            const uint4* p = reinterpret_cast<const uint4*>(text + a);
+            const uint4 v0 = p[0], v1 = p[1];
+            const uint32_t d[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t x = d[q] ^ 0x0A0A0A0Au;  // a zero byte <=> newline
+#pragma unroll
+                for (int b = 0; b < 4; ++b) m |= (((x >> (8 * b)) & 0xFFu) == 0u ? 1u : 0u) << (4 * q + b);
+            }
+        } else {
+            for (int j = 0; j < 32 && a + j < nbytes; ++j) m |= (text[a + j] == '\n' ? 1u : 0u) << j;
+        }
+        bits[w] = m;
+    }
+}
+
+__device__ __forceinline__ bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+__device__ __forceinline__ int dev_base_code(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+
+struct OddRec { uint32_t begin, len; uint64_t key; };
+
+// One thread per owned line.  Line t begins after newline (t - virt) (or at buffer offset 0 for the virtual newline
+// in front of the range) and ends at the next newline, or at `nbytes` when the file ends first.
+// A FASTQ keeps the lines with (line_base + t) % 4 == 1.  Read r of the chunk = global read - gri0.
+// n_nl_p: number of newlines the expand pass found in the buffer (device scalar); more_file: the buffer stops short
+// of the end of the file, so a line without a closing newline in it is longer than the slack -> flags[1].
+__global__ __launch_bounds__(BLOCK) void k_lines_to_windows(const uint8_t* __restrict__ text, uint64_t nbytes,
+                                                            const uint32_t* __restrict__ nl,
+                                                            const uint64_t* __restrict__ n_nl_p, uint64_t nl_cap,
+                                                            uint64_t n_own, int virt, int more_file, uint64_t line_base,
+                                                            uint64_t gri0, Geometry g, uint64_t key0,
+                                                            uint64_t* __restrict__ packed, uint8_t* __restrict__ status,
+                                                            OddRec* __restrict__ odd, uint32_t odd_cap,
+                                                            uint32_t* __restrict__ flags) {
+    uint32_t* n_odd = flags;
+    const uint64_t n_nl = *n_nl_p;
+    if (n_nl > nl_cap) {  // the position list was cut short: refuse
+        if (blockIdx.x == 0 && threadIdx.x == 0) flags[1] = 2u;
+        return;
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    const int64_t wlen = (int64_t)g.L_len + g.k + g.R_len;
+    for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n_own; t += stride) {
+        const uint64_t gl = line_base + t;
+        uint64_t r;
+        if (g.fastq) {
+            if ((gl & 3u) != 1u) continue;
+            r = (gl >> 2) - gri0;
+        } else {
+            r = gl - gri0;
+        }
+        const int64_t bi = (int64_t)t - virt;               // newline in front of the line
+        uint64_t a = bi < 0 ? 0 : (uint64_t)nl[bi] + 1;
+        uint64_t b = nbytes;
+        if ((uint64_t)(bi + 1) < n_nl) b = (uint64_t)nl[bi + 1];
+        else if (more_file) flags[1] = 1u;                  // no end of line inside the slack
+        while (a < b && is_space(text[a])) ++a;              // str.strip()
+        while (b > a && is_space(text[b - 1])) --b;
+        const int64_t len = (int64_t)(b - a);
+        uint64_t w = BC_SKIP_BIT;
+        uint8_t st = BC_WIN_SKIP;
+        bool has_n = false;
+        for (uint64_t i = a; i < b; ++i) has_n = has_n || text[i] == 'N';
+        if (!has_n) {
+            const int64_t ws = min((int64_t)g.start, len), we = min((int64_t)g.start + wlen, len);
+            const int64_t n = we - ws;
+            const uint8_t* win = text + a + ws;
+            bool has = n >= g.L_len && n >= g.R_len;
+            for (int j = 0; has && j < g.L_len; ++j) has = win[j] == (uint8_t)g.L[j];
+            for (int j = 0; has && j < g.R_len; ++j) has = win[n - g.R_len + j] == (uint8_t)g.R[j];
+            if (has) {
+                st = BC_WIN_ODD;  // flanks present: a short window or an odd character keeps string semantics
+                if (n == wlen) {
+                    uint32_t lo = 0, hi = 0;
+                    bool bad = false;
+                    for (int j = 0; j < g.k; ++j) {
+                        const int c = dev_base_code(win[g.L_len + j]);
+                        bad = bad || c > 3;
+                        lo |= (uint32_t)(c & 1) << j;
+                        hi |= (uint32_t)((c >> 1) & 1) << j;
+                    }
+                    if (!bad) {
+                        if (g.reverse) {
+                            const uint32_t km = g.k >= 32 ? 0xFFFFFFFFu : ((1u << g.k) - 1u);
+                            lo = (__brev(~lo) >> (32 - g.k)) & km;
+                            hi = (__brev(~hi) >> (32 - g.k)) & km;
+                        }
+                        w = (uint64_t)lo | ((uint64_t)hi << 32);
+                        st = BC_WIN_OK;
+                    }
+                }
+                if (st == BC_WIN_ODD) {
+                    const uint32_t at = atomicAdd(n_odd, 1u);
+                    if (at < odd_cap) odd[at] = OddRec{(uint32_t)a, (uint32_t)len, key0 + r};
+                }
+            }
+        }
+        if (st != BC_WIN_OK) w = (g.k <= 31) ? BC_SKIP_BIT : 0;
+        packed[r] = w;
+        status[r] = st;
+    }
+}
+
+// flank-valid windows that matched nothing -> (word, key) pairs appended to the run-wide list
+__global__ __launch_bounds__(BLOCK) void k_collect_misses(const int32_t* __restrict__ best_idx,
+                                                          const uint64_t* __restrict__ packed, uint64_t n, uint64_t kmask,
+                                                          uint64_t key0, uint64_t* __restrict__ m_words,
+                                                          uint64_t* __restrict__ m_keys,
+                                                          unsigned long long* __restrict__ cursor) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    const uint64_t n_round = (n + 63) & ~63ull;  // whole waves stay together for the ballots
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_round; r += stride) {
+        const bool miss = r < n && best_idx[r] == BC_IDX_MISS;
+        const unsigned long long m = __ballot(miss);
+        if (m == 0ull) continue;
+        const uint32_t lane = threadIdx.x & 63u;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader);
+        if (miss) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            m_words[base + rank] = packed[r] & kmask;
+            m_keys[base + rank] = key0 + r;
+        }
+    }
+}
+
+int grid_for(uint64_t items) {
+    uint64_t b = (items + BLOCK - 1) / BLOCK;
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(b, 4096));
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return BC_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        BC_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return BC_OK;
+    }
+};
+
+struct Slot {  // one worker's buffers
+    uint8_t* h_text = nullptr;   // pinned, 1 + CHUNK + SLACK
+    hipStream_t st = nullptr;
+    DevBuf text, bits, nl, tmp, packed, status, best, odd;
+    uint64_t* d_n = nullptr;     // expand count
+    uint32_t* d_nodd = nullptr;
+    ~Slot() {
+        if (h_text) (void)hipHostFree(h_text);
+        if (st) (void)hipStreamDestroy(st);
+        if (d_n) (void)hipFree(d_n);
+        if (d_nodd) (void)hipFree(d_nodd);
+    }
+};
+
+}  // namespace
+
+struct bc_stream_result {
+    uint64_t n_reads = 0;
+    double seconds = 0;
+    std::vector<uint64_t> u_words, u_counts, u_first;
+    std::vector<uint64_t> odd_keys, odd_off;  // odd_off: n_odd + 1 offsets into odd_text
+    std::string odd_text;
+};
+
+extern "C" {
+
+int bc_stream_result_free(bc_stream_result* r) {
+    delete r;
+    return BC_OK;
+}
+
+int bc_stream_result_info(const bc_stream_result* r, uint64_t* n_reads, uint64_t* n_undoc, uint64_t* n_odd,
+                          uint64_t* odd_bytes, double* seconds) {
+    if (!r) { set_error("bc_stream_result_info: null"); return BC_EINVAL; }
+    if (n_reads) *n_reads = r->n_reads;
+    if (n_undoc) *n_undoc = r->u_words.size();
+    if (n_odd) *n_odd = r->odd_keys.size();
+    if (odd_bytes) *odd_bytes = r->odd_text.size();
+    if (seconds) *seconds = r->seconds;
+    return BC_OK;
+}
+
+int bc_stream_result_undoc(const bc_stream_result* r, uint64_t* words, uint64_t* counts, uint64_t* first) {
+    if (!r || ((!words || !counts || !first) && !r->u_words.empty())) { set_error("bc_stream_result_undoc: null"); return BC_EINVAL; }
+    std::copy(r->u_words.begin(), r->u_words.end(), words);
+    std::copy(r->u_counts.begin(), r->u_counts.end(), counts);
+    std::copy(r->u_first.begin(), r->u_first.end(), first);
+    return BC_OK;
+}
+
+int bc_stream_result_odd(const bc_stream_result* r, uint64_t* keys, uint64_t* off, char* text) {
+    if (!r) { set_error("bc_stream_result_odd: null"); return BC_EINVAL; }
+    std::copy(r->odd_keys.begin(), r->odd_keys.end(), keys);
+    std::copy(r->odd_off.begin(), r->odd_off.end(), off);
+    std::copy(r->odd_text.begin(), r->odd_text.end(), text);
+    return BC_OK;
+}
+
+int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uint64_t byte_end, int64_t start,
+                         const char* L, int L_len, const char* R, int R_len, int reverse, int max_mismatch, int algo,
+                         uint64_t key_base, int n_threads, uint64_t* h_counts, uint64_t* h_first_seen,
+                         bc_stream_result** out) {
+    if (!lib || !path || !out || start < 0 || L_len < 0 || R_len < 0 || L_len > 15 || R_len > 15 || (L_len && !L) ||
+        (R_len && !R)) {
+        set_error("bc_stream_count_file: bad argument (flanks are at most 15 characters)");
+        return BC_EINVAL;
+    }
+    uint32_t G = 0; int k = 0, device = 0;
+    bc_lib_info(lib, &G, &k, &device);
+    std::string p(path);
+    auto ends = [&](const char* suf) { size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
+    Geometry g{};
+    if (ends(".fastq")) g.fastq = 1;
+    else if (ends(".reads")) g.fastq = 0;
+    else { set_error("bc_stream_count_file: an uncompressed .fastq or .reads file is needed, got %s", path); return BC_EINVAL; }
+    g.start = start; g.L_len = L_len; g.R_len = R_len; g.k = k; g.reverse = reverse ? 1 : 0;
+    memcpy(g.L, L ? L : "", (size_t)L_len);
+    memcpy(g.R, R ? R : "", (size_t)R_len);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { set_error("cannot open %s", path); return BC_EINVAL; }
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { set_error("cannot stat %s", path); return BC_EINVAL; }
+    const uint64_t fsize = (uint64_t)sb.st_size;
+    byte_end = std::min(byte_end, fsize);
+    if (byte_begin > byte_end) byte_begin = byte_end;
+    const auto t_begin = std::chrono::steady_clock::now();
+    BC_HIP(hipSetDevice(device));
+
+    const uint64_t span = byte_end - byte_begin;
+    const uint64_t n_chunks = (span + CHUNK - 1) / CHUNK;
+    int T = n_threads > 0 ? n_threads : 4;
+    T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)T, std::max<uint64_t>(n_chunks, 1)));
+    const uint64_t kmask = kmer_mask(k);
+
+    // run-wide device state
+    DevBuf d_counts, d_first, m_words, m_keys, d_cursor;
+    int rc;
+    if ((rc = d_counts.reserve((size_t)G * 4)) != BC_OK) return rc;
+    if ((rc = d_first.reserve((size_t)G * 8)) != BC_OK) return rc;
+    if ((rc = d_cursor.reserve(16)) != BC_OK) return rc;
+    BC_HIP(hipMemset(d_counts.p, 0, (size_t)G * 4));
+    BC_HIP(hipMemset(d_first.p, 0xFF, (size_t)G * 8));
+    BC_HIP(hipMemset(d_cursor.p, 0, 16));
+    uint64_t miss_cap = span / 24 + 65536;  // grown when a file has shorter reads than that
+    if ((rc = m_words.reserve(miss_cap * 8)) != BC_OK) return rc;
+    if ((rc = m_keys.reserve(miss_cap * 8)) != BC_OK) return rc;
+
+    std::vector<Slot> slots((size_t)T);
+    // ordered hand-over of the running line / read totals (a chunk needs the number of lines in front of it)
+    std::mutex order_m;
+    std::condition_variable order_cv;
+    uint64_t next_to_publish = 0, lines_before = 0, reads_launched = 0;
+    std::atomic<uint64_t> next_chunk{0};
+    std::atomic<int> first_rc{BC_OK};
+    std::string err;
+    std::mutex err_m, grow_m, odd_m;
+    bc_stream_result* res = new bc_stream_result();
+    struct OddOut { uint64_t key; std::string text; };
+    std::vector<OddOut> odd_all;
+
+    auto fail = [&](int code) {
+        int expect = BC_OK;
+        if (first_rc.compare_exchange_strong(expect, code)) {
+            std::lock_guard<std::mutex> lk(err_m);
+            err = bc_last_error();
+        }
+        order_cv.notify_all();
+    };
+
+    auto work = [&](int ti) {
+        Slot& s = slots[(size_t)ti];
+        auto body = [&]() -> int {
+            BC_HIP(hipSetDevice(device));
+            BC_HIP(hipHostMalloc((void**)&s.h_text, 1 + CHUNK + SLACK + 32, hipHostMallocDefault));
+            BC_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+            BC_HIP(hipMalloc((void**)&s.d_n, 16));
+            BC_HIP(hipMalloc((void**)&s.d_nodd, 16));
+            int rc2;
+            if ((rc2 = s.text.reserve(1 + CHUNK + SLACK + 64)) != BC_OK) return rc2;
+            for (;;) {
+                const uint64_t c = next_chunk.fetch_add(1);
+                if (c >= n_chunks || first_rc.load() != BC_OK) break;
+                // ---- read: bytes [base, hi) of the file; the chunk owns newlines in [own_lo, own_hi)
+                const uint64_t core_lo = byte_begin + c * CHUNK, core_hi = std::min(byte_end, core_lo + CHUNK);
+                const int virt = (c == 0) ? 1 : 0;                 // the line at the start of the range
+                const uint64_t base = virt ? core_lo : core_lo - 1;
+                const uint64_t hi = std::min(fsize, core_hi + SLACK);
+                const uint64_t nbytes = hi - base;
+                uint64_t got = 0;
+                while (got < nbytes) {
+                    ssize_t n = pread(fd, s.h_text + got, nbytes - got, (off_t)(base + got));
+                    if (n <= 0) { set_error("read error in %s", path); return BC_EINVAL; }
+                    got += (uint64_t)n;
+                }
+                // owned newlines: file positions [core_lo - 1, core_hi - 1) = buffer offsets [0, own_hi); the first chunk
+                // starts at the range's first line instead (a virtual newline in front of it).  The newline at
+                // core_hi - 1 belongs to the next chunk — or to the next range, or ends the file.
+                const uint64_t own_hi = core_hi - 1 - base;
+                uint64_t n_real = 0;
+                for (uint64_t i = 0; i < own_hi; ++i) n_real += (s.h_text[i] == '\n');
+                const uint64_t n_own = n_real + (uint64_t)virt;
+                // ---- position in the run: lines and reads in front of this chunk
+                uint64_t line_base, reads_before;
+                {
+                    std::unique_lock<std::mutex> lk(order_m);
+                    order_cv.wait(lk, [&] { return next_to_publish == c || first_rc.load() != BC_OK; });
+                    if (first_rc.load() != BC_OK) return BC_OK;
+                    line_base = lines_before;
+                    lines_before += n_own;
+                    const uint64_t gri0_ = g.fastq ? ((line_base + 2) >> 2) : line_base;
+                    const uint64_t gri1_ = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
+                    reads_before = reads_launched;
+                    reads_launched += gri1_ - gri0_;
+                    ++next_to_publish;
+                }
+                order_cv.notify_all();
+                const uint64_t gri0 = g.fastq ? ((line_base + 2) >> 2) : line_base;
+                const uint64_t gri1 = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
+                const uint64_t n_reads = gri1 - gri0;
+                if (n_own == 0 || n_reads == 0) continue;
+                {   // room for this chunk's misses in the run-wide list (every read could be one)
+                    std::lock_guard<std::mutex> lk(grow_m);
+                    if (reads_before + n_reads > miss_cap) {
+                        BC_HIP(hipDeviceSynchronize());
+                        unsigned long long used = 0;
+                        BC_HIP(hipMemcpy(&used, d_cursor.p, 8, hipMemcpyDeviceToHost));
+                        const uint64_t ncap = std::max<uint64_t>(miss_cap * 2, reads_before + n_reads + 65536);
+                        DevBuf nw, nk;
+                        if ((rc2 = nw.reserve(ncap * 8)) != BC_OK) return rc2;
+                        if ((rc2 = nk.reserve(ncap * 8)) != BC_OK) return rc2;
+                        BC_HIP(hipMemcpy(nw.p, m_words.p, used * 8, hipMemcpyDeviceToDevice));
+                        BC_HIP(hipMemcpy(nk.p, m_keys.p, used * 8, hipMemcpyDeviceToDevice));
+                        std::swap(nw.p, m_words.p); std::swap(nw.cap, m_words.cap);
+                        std::swap(nk.p, m_keys.p); std::swap(nk.cap, m_keys.cap);
+                        miss_cap = ncap;
+                    }
+                }
+                // ---- device pass
+                const uint64_t n_words = (nbytes + 31) / 32;
+                const uint64_t nl_cap = n_real + SLACK + 64;
+                const uint32_t odd_cap = 1u << 16;
+                if ((rc2 = s.bits.reserve(n_words * 4 + 64)) != BC_OK) return rc2;
+                if ((rc2 = s.nl.reserve(nl_cap * 4)) != BC_OK) return rc2;
+                if ((rc2 = s.tmp.reserve((n_words / 1024 + 2) * 4)) != BC_OK) return rc2;
+                if ((rc2 = s.packed.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;
+                if ((rc2 = s.status.reserve(n_reads + 64)) != BC_OK) return rc2;
+                if ((rc2 = s.best.reserve(n_reads * 4 + 64)) != BC_OK) return rc2;
+                if ((rc2 = s.odd.reserve((size_t)odd_cap * sizeof(OddRec))) != BC_OK) return rc2;
+                BC_HIP(hipMemcpyAsync(s.text.p, s.h_text, nbytes, hipMemcpyHostToDevice, s.st));
+                BC_HIP(hipMemsetAsync(s.d_nodd, 0, 8, s.st));
+                hipLaunchKernelGGL(k_nl_bitmap, dim3(grid_for(n_words)), dim3(BLOCK), 0, s.st, (const uint8_t*)s.text.p, nbytes,
+                                   (uint32_t*)s.bits.p, n_words);
+                if ((rc2 = bc_sites_expand_dev((const uint32_t*)s.bits.p, n_words, (uint32_t*)s.nl.p, nl_cap, s.d_n,
+                                               (uint32_t*)s.tmp.p, s.st)) != BC_OK) return rc2;
+                // the device's list holds every newline of the buffer in ascending order: the owned ones come first,
+                // the slack's after them (the end of the last owned line is among those)
+                const uint64_t key0 = key_base + gri0;
+                hipLaunchKernelGGL(k_lines_to_windows, dim3(grid_for(n_own)), dim3(BLOCK), 0, s.st, (const uint8_t*)s.text.p,
+                                   nbytes, (const uint32_t*)s.nl.p, (const uint64_t*)s.d_n, nl_cap, n_own, virt,
+                                   hi < fsize ? 1 : 0, line_base, gri0, g, key0, (uint64_t*)s.packed.p,
+                                   (uint8_t*)s.status.p, (OddRec*)s.odd.p, odd_cap, s.d_nodd);
+                BC_HIP(hipGetLastError());
+                if ((rc2 = bc_match_dev(lib, (const uint64_t*)s.packed.p, (const uint8_t*)s.status.p, n_reads, max_mismatch,
+                                        algo, (int32_t*)s.best.p, nullptr, nullptr, (uint32_t*)d_counts.p,
+                                        (uint64_t*)d_first.p, key0, s.st)) != BC_OK) return rc2;
+                hipLaunchKernelGGL(k_collect_misses, dim3(grid_for(n_reads)), dim3(BLOCK), 0, s.st, (const int32_t*)s.best.p,
+                                   (const uint64_t*)s.packed.p, n_reads, kmask, key0, (uint64_t*)m_words.p,
+                                   (uint64_t*)m_keys.p, (unsigned long long*)d_cursor.p);
+                BC_HIP(hipGetLastError());
+                // ---- odd windows: their text is still in the pinned buffer
+                uint32_t fl[2] = {0, 0};
+                BC_HIP(hipMemcpyAsync(fl, s.d_nodd, 8, hipMemcpyDeviceToHost, s.st));
+                BC_HIP(hipStreamSynchronize(s.st));
+                if (fl[1]) { set_error("%s: a line longer than %llu bytes", path, (unsigned long long)SLACK); return BC_EINVAL; }
+                const uint32_t n_odd = fl[0];
+                if (n_odd > odd_cap) { set_error("%s: more than %u odd windows in one chunk", path, odd_cap); return BC_EINVAL; }
+                if (n_odd) {
+                    std::vector<OddRec> recs(n_odd);
+                    BC_HIP(hipMemcpy(recs.data(), s.odd.p, (size_t)n_odd * sizeof(OddRec), hipMemcpyDeviceToHost));
+                    std::lock_guard<std::mutex> lk(odd_m);
+                    for (const OddRec& o : recs)
+                        odd_all.push_back(OddOut{o.key, std::string((const char*)s.h_text + o.begin, o.len)});
+                }
+            }
+            BC_HIP(hipStreamSynchronize(s.st));
+            return BC_OK;
+        };
+        const int code = body();
+        if (code != BC_OK) fail(code);
+    };
+    if (T == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int ti = 0; ti < T; ++ti) th.emplace_back(work, ti);
+        for (auto& t : th) t.join();
+    }
+    if (first_rc.load() != BC_OK) {
+        set_error("%s", err.c_str());
+        delete res;
+        return first_rc.load();
+    }
+    auto finish = [&]() -> int {
+        BC_HIP(hipDeviceSynchronize());
+        res->n_reads = reads_launched;
+        // documented: counts / first-seen keys
+        if (h_counts) {
+            std::vector<uint32_t> c32(G);
+            BC_HIP(hipMemcpy(c32.data(), d_counts.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < G; ++i) h_counts[i] += c32[i];
+        }
+        if (h_first_seen) {
+            std::vector<uint64_t> fs(G);
+            BC_HIP(hipMemcpy(fs.data(), d_first.p, (size_t)G * 8, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < G; ++i) h_first_seen[i] = std::min(h_first_seen[i], fs[i]);
+        }
+        // undocumented: sort the (word, key) pairs by word, then one pass gives every distinct word its count and
+        // smallest key
+        unsigned long long n_miss = 0;
+        BC_HIP(hipMemcpy(&n_miss, d_cursor.p, 8, hipMemcpyDeviceToHost));
+        if (n_miss) {
+            DevBuf w2, k2, tmp, uw, uf, uc, un;
+            int rc3;
+            if ((rc3 = w2.reserve(n_miss * 8)) != BC_OK) return rc3;
+            if ((rc3 = k2.reserve(n_miss * 8)) != BC_OK) return rc3;
+            if ((rc3 = uw.reserve(n_miss * 8)) != BC_OK) return rc3;
+            if ((rc3 = uf.reserve(n_miss * 8)) != BC_OK) return rc3;
+            if ((rc3 = uc.reserve(n_miss * 8)) != BC_OK) return rc3;
+            if ((rc3 = un.reserve(16)) != BC_OK) return rc3;
+            size_t tb = 0;
+            BC_HIP(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)m_words.p, (uint64_t*)w2.p, (uint64_t*)m_keys.p,
+                                             (uint64_t*)k2.p, (size_t)n_miss, 0, 64, 0));
+            if ((rc3 = tmp.reserve(tb)) != BC_OK) return rc3;
+            BC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t*)m_words.p, (uint64_t*)w2.p, (uint64_t*)m_keys.p,
+                                             (uint64_t*)k2.p, (size_t)n_miss, 0, 64, 0));
+            // every run of equal words: its smallest key, and its length (a sum of ones)
+            size_t tb2 = 0;
+            BC_HIP(rocprim::reduce_by_key(nullptr, tb2, (uint64_t*)w2.p, (uint64_t*)k2.p, (size_t)n_miss, (uint64_t*)uw.p,
+                                          (uint64_t*)uf.p, (uint64_t*)un.p, rocprim::minimum<uint64_t>(),
+                                          rocprim::equal_to<uint64_t>(), 0));
+            if ((rc3 = tmp.reserve(tb2)) != BC_OK) return rc3;
+            BC_HIP(rocprim::reduce_by_key(tmp.p, tb2, (uint64_t*)w2.p, (uint64_t*)k2.p, (size_t)n_miss, (uint64_t*)uw.p,
+                                          (uint64_t*)uf.p, (uint64_t*)un.p, rocprim::minimum<uint64_t>(),
+                                          rocprim::equal_to<uint64_t>(), 0));
+            size_t tb4 = 0;
+            auto ones_it = rocprim::make_constant_iterator<uint64_t>(1);
+            BC_HIP(rocprim::reduce_by_key(nullptr, tb4, (uint64_t*)w2.p, ones_it, (size_t)n_miss, (uint64_t*)uw.p,
+                                          (uint64_t*)uc.p, (uint64_t*)un.p, rocprim::plus<uint64_t>(),
+                                          rocprim::equal_to<uint64_t>(), 0));
+            if ((rc3 = tmp.reserve(tb4)) != BC_OK) return rc3;
+            BC_HIP(rocprim::reduce_by_key(tmp.p, tb4, (uint64_t*)w2.p, ones_it, (size_t)n_miss, (uint64_t*)uw.p,
+                                          (uint64_t*)uc.p, (uint64_t*)un.p, rocprim::plus<uint64_t>(),
+                                          rocprim::equal_to<uint64_t>(), 0));
+            BC_HIP(hipDeviceSynchronize());
+            uint64_t n_u = 0;
+            BC_HIP(hipMemcpy(&n_u, un.p, 8, hipMemcpyDeviceToHost));
+            res->u_words.resize(n_u); res->u_first.resize(n_u); res->u_counts.resize(n_u);
+            BC_HIP(hipMemcpy(res->u_words.data(), uw.p, n_u * 8, hipMemcpyDeviceToHost));
+            BC_HIP(hipMemcpy(res->u_first.data(), uf.p, n_u * 8, hipMemcpyDeviceToHost));
+            BC_HIP(hipMemcpy(res->u_counts.data(), uc.p, n_u * 8, hipMemcpyDeviceToHost));
+        }
+        std::sort(odd_all.begin(), odd_all.end(), [](const OddOut& a, const OddOut& b) { return a.key < b.key; });
+        res->odd_off.push_back(0);
+        for (const OddOut& o : odd_all) {
+            res->odd_keys.push_back(o.key);
+            res->odd_text += o.text;
+            res->odd_off.push_back(res->odd_text.size());
+        }
+        return BC_OK;
+    };
+    rc = finish();
+    if (rc != BC_OK) { delete res; return rc; }
+    res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    *out = res;
+    return BC_OK;
+}
+
+}  // extern "C"

@@ -435,28 +435,63 @@ class ChunkResult:
 class PackedCounter:
     """Counter-like view over undocumented windows kept packed (millions of
     distinct keys would cost minutes as Python strings): supports len(),
-    values(), most_common(k), items() and `key in`."""
+    values(), most_common(k), items() and `key in`.  items() runs in first-seen
+    order; the ordering is only computed when something asks for it."""
 
     def __init__(self, k, words, counts, first, extra: Counter):
-        order = np.argsort(first, kind="stable")
-        self.k, self.words, self.counts, self.first, self.extra = k, words[order], counts[order], first[order], extra
+        self.k, self._words, self._counts, self._first, self.extra = k, words, counts, first, extra
+        self._ordered = False
+
+    def _order(self):
+        if not self._ordered:
+            order = np.argsort(self._first, kind="stable")
+            self._words, self._counts, self._first = self._words[order], self._counts[order], self._first[order]
+            self._ordered = True
+
+    @property
+    def words(self):
+        self._order()
+        return self._words
+
+    @property
+    def counts(self):
+        self._order()
+        return self._counts
+
+    @property
+    def first(self):
+        self._order()
+        return self._first
 
     def __len__(self):
-        return int(self.words.size) + len(self.extra)
+        return int(self._words.size) + len(self.extra)
 
     def values(self):
-        return list(self.counts.tolist()) + list(self.extra.values())
+        return list(self._counts.tolist()) + list(self.extra.values())
 
     def total(self):
-        return int(self.counts.sum()) + sum(self.extra.values())
+        return int(self._counts.sum()) + sum(self.extra.values())
 
     def most_common(self, k=None):
+        n = int(self._counts.size)
         if k is None:
             k = len(self)
-        top = np.argsort(-self.counts.astype(np.int64), kind="stable")[:k]
-        cand = [(s + "*", int(c)) for s, c in zip(unpack_kmers(self.words[top], self.k), self.counts[top].tolist())]
-        cand += list(self.extra.items())
-        return sorted(cand, key=lambda kv: -kv[1])[:k]
+        c = self._counts.astype(np.int64)
+        if 0 < k < n:  # top k without sorting millions of entries: partition, then order the few candidates
+            kth = np.partition(c, n - k)[n - k]
+            gt = np.flatnonzero(c > kth)
+            eq = np.flatnonzero(c == kth)
+            need = k - gt.size
+            if eq.size > need:  # many ties at the cut (say, millions of singletons): the earliest-seen ones win
+                eq = eq[np.argpartition(self._first[eq], need - 1)[:need]]
+            cand = np.concatenate([gt, eq])
+        else:
+            cand = np.arange(n)
+        # ties resolve towards the earlier first-seen entry, like Counter.most_common on insertion order
+        top = cand[np.lexsort((self._first[cand], -c[cand]))][:k]
+        out = [(s + "*", int(v)) for s, v in zip(unpack_kmers(self._words[top], self.k), self._counts[top].tolist())]
+        out += list(self.extra.items())
+        return sorted(out, key=lambda kv: -kv[1])[:k]
 
     def items(self):
         yield from ((s + "*", int(c)) for s, c in zip(unpack_kmers(self.words, self.k), self.counts.tolist()))
@@ -505,6 +540,8 @@ def merge_undocumented(tables):
     if not tables:
         z = np.zeros(0, np.uint64)
         return z, z, z
+    if len(tables) == 1 and (tables[0][0].size < 2 or bool((tables[0][0][1:] > tables[0][0][:-1]).all())):
+        return tuple(np.asarray(x, np.uint64) for x in tables[0])  # already one sorted table of distinct words
     w = np.concatenate([t[0] for t in tables])
     c = np.concatenate([t[1] for t in tables]).astype(np.uint64)
     f = np.concatenate([t[2] for t in tables]).astype(np.uint64)
@@ -534,6 +571,8 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     first-seen keys are all-reduced (dist.count_sharded), which replaces the Pool fan-out and
     Counter merge of heuristicount.py:703-737.  Every rank returns the job-wide result."""
     from . import dist as D
+    import time as _time
+    t_start = _time.perf_counter()
     barcodes = read_fasta(fasta_file)
     validate_barcodes(barcodes)
     lengths = {len(b) for b in barcodes}
@@ -579,15 +618,20 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
         raise ValueError("A critical error occurred: Flank complementarity violation")
 
     log.info("Executing high-throughput read analysis...")
+    t_sampled = _time.perf_counter()
     cc = ChunkCounter(ordered, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
                       device=device, max_mismatch=max_mismatch)
+    t_lib = _time.perf_counter()
     G = len(cc.labels)
     plan = shard_plan(file1, file2, world)
+    # the device path takes a single uncompressed file whose start offset is known (not None after sampling)
+    device_ingest = (not is_paired and not file1.endswith((".gz", ".zst")) and (plan == "bytes" or world == 1)
+                     and (bc_start2 if need_swap else bc_start1) is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
+                     and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     undoc_tables, odd_events = [], []
     n_mine = [0]
     t_bulk = [0.0]
     from .ingest import NativeReader
-    import time as _time
 
     def bulk(a, b):
         """dist.count_sharded's match_shard.  Plan "bytes": [a, b) is a byte range of file1; plan
@@ -599,6 +643,31 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
         counts = np.zeros(G + 1, np.uint64)  # last element: reads seen by this rank
         first_seen = np.full(G + 1, np.iinfo(np.uint64).max, np.uint64)
         t0 = _time.perf_counter()
+        if device_ingest:
+            # single uncompressed file: raw bytes -> HBM, everything per read on the device (bc_stream_count_file).
+            # Nominal byte cuts become record-aligned ranges; the key of a read = range start + its ordinal.
+            from .ingest import record_boundary, stream_count_file
+            if plan == "bytes":
+                lo, hi = record_boundary(file1, a), record_boundary(file1, b)
+            else:
+                lo, hi = 0, os.path.getsize(file1)
+            s1, s2, Lf, Rf, Lr, Rr = cc.geom
+            reverse = bool(need_swap)
+            start, L, R, lib_set = (s2, Lr, Rr, cc.rev_set) if reverse else (s1, Lf, Rf, cc.fwd_set)
+            c64, f64 = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
+            sr = stream_count_file(cc.lib.handle, file1, lo, hi, start, L, R, reverse, max_mismatch, cc.algo, lo, c64, f64)
+            counts[:G], first_seen[:G] = c64, f64
+            undoc_tables.append((sr.u_words, sr.u_counts, sr.u_first))
+            for key, text in sr.odd:  # string semantics for windows that cannot be packed (ChunkCounter._windows)
+                w = text[start:start + len(L) + bc_len + len(R)]
+                seq = w[len(L):len(w) - len(R)]
+                if reverse:
+                    seq = rev_comp(seq)
+                odd_events.append((key, seq if w in lib_set else seq + "*"))
+            n_mine[0] = sr.n_reads
+            counts[G] = sr.n_reads
+            t_bulk[0] = _time.perf_counter() - t0
+            return counts, first_seen
         rng = (a, b) if plan == "bytes" else None
         seen = 0
         with NativeReader(file1, max_reads=chunk_reads, byte_range=rng) as r1, \
@@ -658,7 +727,9 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     return dict(doc=doc, undoc=undoc, total_reads=total_reads, barcodes=barcodes, bc_len=bc_len,
                 bc_start1=bc_start1, bc_start2=bc_start2, flanks_fwd=(L_fwd, R_fwd), flanks_rev=(L_rev, R_rev),
                 need_swap=need_swap, forward_name=fwd_name, reverse_name=rev_name, shard_plan=plan,
-                bulk_mreads_per_s=(n_mine[0] / t_bulk[0] / 1e6 if t_bulk[0] > 0 else None))
+                bulk_mreads_per_s=(n_mine[0] / t_bulk[0] / 1e6 if t_bulk[0] > 0 else None),
+                seconds=dict(sampling=t_sampled - t_start, library=t_lib - t_sampled, bulk=t_bulk[0],
+                             merge=_time.perf_counter() - t_lib - t_bulk[0]))
 
 
 def summary_lines(r, fasta_file):

@@ -4,6 +4,7 @@ Host-side replacement for the per-line Python loop of heuristicount.py:100-153."
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -95,3 +96,55 @@ def read_all(path: str):
             o = off.astype(np.int64)
             out.extend(b[o[i]:o[i + 1]].decode("ascii", errors="replace") for i in range(o.size - 1))
     return out
+
+
+def record_boundary(path: str, offset: int) -> int:
+    """Offset of the first record of an uncompressed reads file that starts at or after `offset`
+    (bc_reader_open_range + bc_reader_tell): how nominal byte cuts become record-aligned ranges."""
+    size = os.path.getsize(path)
+    if offset <= 0:
+        return 0
+    if offset >= size:
+        return size
+    with NativeReader(path, max_reads=1, byte_range=(offset, size)) as r:
+        return min(r.tell(), size)
+
+
+class StreamResult:
+    """What bc_stream_count_file leaves on the host: read count, undocumented table (packed words sorted,
+    counts, smallest keys) and the odd windows' (key, text)."""
+
+    def __init__(self, n_reads, seconds, u_words, u_counts, u_first, odd):
+        self.n_reads, self.seconds = n_reads, seconds
+        self.u_words, self.u_counts, self.u_first, self.odd = u_words, u_counts, u_first, odd
+
+
+def stream_count_file(lib_handle, path: str, byte_begin: int, byte_end: int, start: int, L: str, R: str, reverse: bool,
+                      max_mismatch: int, algo: str, key_base: int, counts: np.ndarray, first_seen: np.ndarray,
+                      n_threads: int = 0) -> StreamResult:
+    """The device path for an uncompressed single-end file: raw bytes in, counts / first-seen (accumulated into the
+    given uint64 arrays), undocumented table and odd windows out."""
+    lib = N.load()
+    h = N.vp()
+    Lb, Rb = L.encode("ascii"), R.encode("ascii")
+    N.check(lib.bc_stream_count_file(lib_handle, path.encode(), int(byte_begin), int(byte_end), int(start), Lb, len(Lb),
+                                     Rb, len(Rb), 1 if reverse else 0, int(max_mismatch), N.ALGOS[algo], int(key_base),
+                                     int(n_threads), N.ptr(counts), N.ptr(first_seen), C.byref(h)))
+    try:
+        n, nu, no, ob, sec = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
+        N.check(lib.bc_stream_result_info(h, C.byref(n), C.byref(nu), C.byref(no), C.byref(ob), C.byref(sec)))
+        uw, uc, uf = (np.empty(nu.value, np.uint64) for _ in range(3))
+        if nu.value:
+            N.check(lib.bc_stream_result_undoc(h, N.ptr(uw), N.ptr(uc), N.ptr(uf)))
+        odd = []
+        if no.value:
+            keys = np.empty(no.value, np.uint64)
+            off = np.empty(no.value + 1, np.uint64)
+            text = np.empty(max(ob.value, 1), np.uint8)
+            N.check(lib.bc_stream_result_odd(h, N.ptr(keys), N.ptr(off), N.ptr(text)))
+            raw = text.tobytes()
+            o = off.astype(np.int64)
+            odd = [(int(keys[i]), raw[o[i]:o[i + 1]].decode("ascii", errors="replace")) for i in range(no.value)]
+        return StreamResult(int(n.value), float(sec.value), uw, uc, uf, odd)
+    finally:
+        lib.bc_stream_result_free(h)

@@ -128,6 +128,36 @@ int bc_reader_next(bc_reader *r, uint64_t max_reads, char *h_text, uint64_t text
                    uint64_t *h_off /* max_reads + 1 */, uint64_t *n_out);
 int bc_reader_close(bc_reader *r);
 
+/* ---- a reads file straight through the device --------------------------------
+ * bc_stream_count_file: everything process_chunk does per read
+ * (heuristicount.py:428-562) for the records of an UNCOMPRESSED .reads / .fastq
+ * file that lie in [byte_begin, byte_end) — a range that starts at a record
+ * boundary (0, or a bc_reader_open_range / bc_reader_tell position) — with the
+ * raw bytes uploaded in chunks and line splitting, strip, N-skip (:524), window
+ * slice (:527), flank test (:458-460), packing, reverse complement (:532-533),
+ * match, per-guide tally and the grouping of the unmatched flank-valid windows
+ * (the "undocumented" barcodes, :455-457) all done in HBM.  Single-end
+ * geometry as bc_pack_windows (start, L, R, reverse); k is the library's.
+ *   key_base       : first-seen key of read i of the range = key_base + i
+ *   h_counts       : uint64[n_guides], ADDED to; h_first_seen: uint64[n_guides], min'ed
+ *   n_threads      : host reader / launcher threads (<= 0: 4)
+ * The result object holds the read count, the undocumented table (packed word,
+ * count, smallest key; sorted by word) and the text + key of the odd windows
+ * (status BC_WIN_ODD: flanks present but the window short or not pure ACGT),
+ * which keep the reference's string semantics on the caller's side. */
+typedef struct bc_stream_result bc_stream_result;
+int bc_stream_count_file(bc_lib *lib, const char *path, uint64_t byte_begin, uint64_t byte_end,
+                         int64_t start, const char *L, int L_len, const char *R, int R_len,
+                         int reverse, int max_mismatch, int algo, uint64_t key_base, int n_threads,
+                         uint64_t *h_counts, uint64_t *h_first_seen, bc_stream_result **out);
+int bc_stream_result_info(const bc_stream_result *r, uint64_t *n_reads, uint64_t *n_undoc,
+                          uint64_t *n_odd, uint64_t *odd_bytes, double *seconds);
+int bc_stream_result_undoc(const bc_stream_result *r, uint64_t *words, uint64_t *counts,
+                           uint64_t *first);
+int bc_stream_result_odd(const bc_stream_result *r, uint64_t *keys, uint64_t *off /* n_odd + 1 */,
+                         char *text);
+int bc_stream_result_free(bc_stream_result *r);
+
 /* ---- sampling (host) --------------------------------------------------------
  * bc_sample_data: orientation / barcode offset discovery on the first chunks of
  * the reads file(s), heuristicount.py:156-379 (sample_data).  `barcodes` = G

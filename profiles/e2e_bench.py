@@ -9,7 +9,7 @@ from barcoder_amd import encoding as E, synth as S, heuristicount as H
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
-d = tempfile.mkdtemp(prefix="bc_e2e_")
+d = tempfile.mkdtemp(prefix="bc_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 lib = S.library(G, 20)
 labels = E.unpack_kmers(lib, 20)
 fa = os.path.join(d, "lib.fasta")
@@ -42,19 +42,11 @@ print({"reads": n, "guides": G, "seconds": round(dt, 2), "Mreads_per_s": round(n
        "documented_reads": sum(r["doc"].values()), "undocumented_reads": r["undoc"].total(),
        "offset": r["bc_start1"], "flanks": r["flanks_fwd"]})
 
-# phase timing (second run, warm): sampling vs bulk
-import time as _t
-t0 = _t.perf_counter(); lib_set = H.read_fasta(fa); sd = H.sample_data(rd, None, lib_set, False); t1 = _t.perf_counter()
-fl = H.find_flanks(sd[3], sd[1], 20); t2 = _t.perf_counter()
-from barcoder_amd.ingest import NativeReader
-cc = H.ChunkCounter(labels, 20, sd[1] - len(fl[0] or ""), None, fl[0], fl[1], None, None, False)
-t3 = _t.perf_counter(); tot = 0; tr = tp = tm = 0.0
-with NativeReader(rd) as r:
-    while True:
-        a = _t.perf_counter(); b1 = r.next(); b = _t.perf_counter(); tr += b - a
-        if b1[1].size <= 1: break
-        res = cc.match_buffers(b1, None, first_index=tot); tot += res.n; tm += _t.perf_counter() - b
-t4 = _t.perf_counter()
-print({"sample_data_s": round(t1 - t0, 2), "find_flanks_s": round(t2 - t1, 2), "lib_build_s": round(t3 - t2, 2),
-       "bulk_s": round(t4 - t3, 2), "of_which_reader_s": round(tr, 2), "pack+match+group_s": round(tm, 2),
-       "bulk_Mreads_per_s": round(tot / (t4 - t3) / 1e6, 2)})
+print({"bulk_pass": "device ingest (bc_stream_count_file)" if r["shard_plan"] == "stride" and os.environ.get("BC_DEVICE_INGEST", "1") != "0" else "host front half",
+       "bulk_Mreads_per_s": round(r["bulk_mreads_per_s"], 1), "bulk_GB_per_s_of_file": round(r["bulk_mreads_per_s"] * 46e6 / 1e9, 2),
+       "undocumented_barcodes": len(r["undoc"]), "seconds": {k_: round(v, 2) for k_, v in r["seconds"].items()}})
+t0 = time.perf_counter()
+lines = H.summary_lines(r, fa)
+print({"summary_lines_s": round(time.perf_counter() - t0, 2), "top_undocumented": lines[-1].strip()})
+import shutil
+shutil.rmtree(d, ignore_errors=True)

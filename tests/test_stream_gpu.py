@@ -1,0 +1,121 @@
+"""GPU: bc_stream_count_file (raw file bytes -> HBM -> counts) against the host front half (bc_reader_* +
+bc_pack_windows + per-chunk grouping, itself pinned by the reference's golden vectors): same documented counts
+in the same first-seen order, same undocumented table, same read total — on files that span several device
+chunks, with ragged / blank / CRLF lines, N reads, short reads, odd characters inside the window, a last line
+without newline, FASTQ quality lines that look like headers, forward and reverse geometry, byte ranges."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L_FLANK, R_FLANK = "CCGGATTCAG", "GTTTTAGAGC"
+
+
+def _make_file(tmp_path, name, n, k, fastq, rng, lib_s, reverse=False, trailing_newline=True):
+    from barcoder_amd.heuristicount import rev_comp
+    lines = []
+    for i in range(n):
+        u = rng.random()
+        bc = lib_s[int(rng.integers(0, len(lib_s)))]
+        if u < 0.10:                                    # not in the library (usually)
+            bc = "".join(rng.choice(list("ACGT"), size=k))
+        mid = L_FLANK + bc + R_FLANK
+        if reverse:
+            mid = rev_comp(mid)
+        pre = "".join(rng.choice(list("ACGT"), size=5))
+        r = pre + mid + "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 9))))
+        v = rng.random()
+        if v < 0.01:
+            p = int(rng.integers(0, len(r)))
+            r = r[:p] + "N" + r[p + 1:]
+        elif v < 0.02:
+            r = r[:int(rng.integers(0, len(r)))]            # cut short: window clamped, flanks usually gone
+        elif v < 0.03:
+            p = 15 + int(rng.integers(0, k))
+            r = r[:p] + "a" + r[p + 1:]                     # odd character inside the window
+        elif v < 0.035:
+            r = ""                                          # blank line
+        elif v < 0.045:
+            r = "  " + r + " \t"                            # stripped by the reader
+        elif v < 0.05:
+            r = r[:len(pre) + len(mid) - 3]                 # right flank cut: fails the flank test
+        lines.append(r)
+    path = tmp_path / name
+    nl = "\n"
+    with open(path, "w", newline="") as f:
+        for i, r in enumerate(lines):
+            end = nl if (trailing_newline or i < n - 1) else ""
+            eol = "\r\n" if (i % 97 == 0 and end) else end
+            if fastq:
+                q = "@" * len(r) if i % 50 == 0 else "+" * len(r) if i % 51 == 0 else "I" * len(r)
+                f.write(f"@r{i}\n{r}\n+\n{q}{eol}")
+            else:
+                f.write(r + eol)
+    return str(path)
+
+
+@pytest.mark.parametrize("fastq,reverse,k,trailing", [(False, False, 20, True), (True, False, 20, False), (False, True, 24, False),
+                                                      (True, True, 32, True)])
+def test_device_ingest_equals_host_front_half(gpu_device, tmp_path, monkeypatch, fastq, reverse, k, trailing):
+    from barcoder_amd import encoding as E, heuristicount as H, synth as S
+    rng = np.random.default_rng(11 + k + fastq)
+    lib = S.library(3000, k)
+    lib_s = E.unpack_kmers(lib, k)
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">g{i}\n{s}\n" for i, s in enumerate(lib_s)))
+    n = 420_000 if fastq else 900_000                  # > 2 device chunks of 16 MiB either way
+    path = _make_file(tmp_path, "r.fastq" if fastq else "r.reads", n, k, fastq, rng, lib_s, reverse, trailing)
+    assert os.path.getsize(path) > 34 << 20
+    for mm in (0, 1):
+        monkeypatch.setenv("BC_DEVICE_INGEST", "1")
+        dev = H.count_barcodes(str(fa), path, device=gpu_device, max_mismatch=mm)
+        monkeypatch.setenv("BC_DEVICE_INGEST", "0")
+        host = H.count_barcodes(str(fa), path, device=gpu_device, max_mismatch=mm, chunk_reads=100_003)
+        assert dev["total_reads"] == host["total_reads"] == n
+        assert dev["need_swap"] == host["need_swap"] == reverse
+        assert list(dev["doc"].items()) == list(host["doc"].items())          # counts AND first-seen order
+        assert sum(dev["doc"].values()) > 0.7 * n
+        assert dict(dev["undoc"].items()) == dict(host["undoc"].items())
+        assert [k_ for k_, _ in dev["undoc"].items()] == [k_ for k_, _ in host["undoc"].items()]
+        assert len(dev["undoc"]) > 1000
+        assert dev["undoc"].extra == host["undoc"].extra and len(dev["undoc"].extra) > 0   # the odd windows
+    assert dev["bulk_mreads_per_s"] > 0
+
+
+def test_stream_byte_ranges_tile_the_file(gpu_device, tmp_path):
+    """Record-aligned byte ranges (what the ranks of `--gpus N` get) add up to the whole file: counts summed, keys
+    min'ed, undocumented tables merged — for .reads and FASTQ."""
+    from barcoder_amd import DeviceLibrary, encoding as E, heuristicount as H, ingest as I, synth as S
+    rng = np.random.default_rng(5)
+    k = 20
+    lib = S.library(2000, k)
+    lib_s = E.unpack_kmers(lib, k)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    for fastq in (False, True):
+        path = _make_file(tmp_path, "t.fastq" if fastq else "t.reads", 60_000, k, fastq, rng, lib_s)
+        size = os.path.getsize(path)
+
+        def run(cuts):
+            G = lib.size
+            c, f = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
+            tabs, n, odd = [], 0, []
+            for a, b in zip(cuts, cuts[1:]):
+                lo, hi = I.record_boundary(path, a), I.record_boundary(path, b)
+                r = I.stream_count_file(dl.handle, path, lo, hi, 5, L_FLANK, R_FLANK, False, 0, "auto", lo, c, f, n_threads=2)
+                tabs.append((r.u_words, r.u_counts, r.u_first))
+                n += r.n_reads
+                odd += [t for _k, t in r.odd]
+            uw, uc, uf = H.merge_undocumented(tabs)
+            return n, c, np.argsort(f, kind="stable")[:int((c > 0).sum())], uw, uc, odd
+        whole = run([0, size])
+        assert whole[0] == 60_000
+        for cuts in ([0, size // 3, size // 2 + 7, size], [0, 1, 2, 3, size - 2, size], [0, size // 7 * 3, size]):
+            part = run(cuts)
+            assert part[0] == whole[0]
+            np.testing.assert_array_equal(part[1], whole[1])
+            np.testing.assert_array_equal(part[2], whole[2])       # first-seen ORDER survives the range keys
+            np.testing.assert_array_equal(part[3], whole[3])
+            np.testing.assert_array_equal(part[4], whole[4])
+            assert part[5] == whole[5]
