@@ -75,20 +75,30 @@ constexpr int NBR_CAP = 8;
 constexpr int NBR_RADIUS = 4;
 constexpr uint32_t NBR_NONE = 0xFFFFFFFFu;  // no guide within NBR_RADIUS
 constexpr uint32_t NBR_OVER = 0xFFFFFFFEu;  // more than NBR_CAP of them: take the exact path
+// Table-2 filter of the d = 2 index (nseg = 3).  A read reaches table 2 only when nothing within distance 2 has a
+// clean segment 0 or 1; a guide that can still match has exactly one mismatch in segment 0 and one in segment 1, so it
+// agrees with the read on one HALF of each of those segments.  Per table-2 bucket one 64-byte line holds four
+// 128-bit sets — the (hashed) values the bucket's guides show in the halves 0a, 0b, 1a, 1b; a read whose own values
+// miss (0a and 0b) or (1a and 1b) has no candidate in the bucket and need not fetch its slabs at all.
+BC_HD static inline uint32_t flt_hash7(uint32_t v) { return (v * 0x9E3779B1u) >> 25; }
 struct SlabParams {
     int nseg;
     SlabTable t[MAX_SEG];
     const uint32_t* nbr_slot;  // [G] list number, NBR_NONE or NBR_OVER (NULL = no lists)
     const uint4* nbr;          // [lists][NBR_CAP]
+    const uint32_t* flt;       // [table-2 buckets][16] filter lines, NULL = none
+    uint32_t f_pos[4], f_len[4];  // first base / length of the halves 0a, 0b, 1a, 1b
 };
 
 // Tuning / experiment knobs, read from the environment ONCE when a library is created (never per launch).
 // Defaults are the measured best; the knob-coverage tests check that none of them changes a result.
 struct Knobs {
-    int lane = 1;         // BC_LANE=0: quad kernels (k_match_fused) instead of the wave kernel
+    int lane = 1;         // BC_LANE=0: quad kernels (k_match_fused) instead of the wave kernels
+    int wave_list = 1;    // BC_WAVE_LIST=0: k_match_wave (lane-per-read batches) instead of k_match_wq (quad work list)
     int phase2_sm = 1;    // BC_PHASE2_SM=0: quad kernels without the state machine
     int single_slab = 0;  // BC_SINGLE_SLAB=1: the one-kernel slab form (k_match_slab) for every d
     int slab_lpr = 4;     // BC_SLAB_LPR=8: eight lanes per read in k_match_slab
+    int diag = 0;         // BC_DIAG: bit mask that switches stages of k_match_wq off (timing experiments; results are wrong)
     int tally = 0;        // BC_TALLY: 0 auto, 1 global atomics, 2 k_hist sweeps, 3 range-partitioned records
     int phase_prof = 0;   // BC_PHASE_PROF=1: per-stage cycle sums of the wave kernel on stderr
     int host_pin = 1;     // BC_HOST_PIN=0: bc_match_host does not pin the caller's buffers

@@ -1022,14 +1022,19 @@ __device__ __forceinline__ bool resolve_ties(const SlabParams& sp, uint32_t rlo,
     nb = 1u;
     if (slot == NBR_NONE) return true;
     if (slot == NBR_OVER) return false;
+    // the whole list (NBR_CAP x 16 B = one 128-byte line) is requested before any entry is looked at: one memory
+    // round trip, not one per entry (unused slots are zero: e.w == 0)
+    uint4 e[NBR_CAP];
+#pragma unroll
+    for (int i = 0; i < NBR_CAP; ++i) e[i] = sp.nbr[(size_t)slot * NBR_CAP + i];
     bool ok = true;
     uint32_t best = idx;
+#pragma unroll
     for (int i = 0; i < NBR_CAP; ++i) {
-        const uint4 e = sp.nbr[(size_t)slot * NBR_CAP + i];
-        if (e.w == 0u) break;
-        const uint32_t d = __popc((rlo ^ e.x) | (rhi ^ e.y));
-        if (d == d1) { ++nb; best = min(best, e.z); }
-        if (d < d1) ok = false;  // cannot happen (every closer guide has been seen); never trust it silently
+        const uint32_t d = __popc((rlo ^ e[i].x) | (rhi ^ e[i].y));
+        const bool used = e[i].w != 0u;
+        if (used && d == d1) { ++nb; best = min(best, e[i].z); }
+        if (used && d < d1) ok = false;  // cannot happen (every closer guide has been seen); never trust it silently
     }
     idx = best;
     return ok;
@@ -1318,6 +1323,404 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             for (int j = 0; j < 4; ++j)
                 if (p0 + j >= tn) idx[j] = BC_IDX_SKIP;
             part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_key), q_off);
+        }
+    }
+    phase_mark(3);
+    if (PROF && threadIdx.x == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_phase_cycles[i], t_acc[i]);
+        atomicAdd(&g_phase_cycles[7], 1ull);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2+K3, wave form with a quad work list (k_match_wq; default for d = 1, 2 since round 2).
+// Same tables, same phase 1 and the same decision rules as k_match_wave; what changed is everything that only a
+// FEW reads of a tile need.  k_match_wave ran those as lane-per-read batches — the overflow slabs of tables 0/1
+// (16 % of the listed reads each), the second, mostly empty batch of listed reads (one tile in five), table 2's
+// 128-byte slabs and their chains for 14 % of the reads — and every such batch costs a full wave's instructions
+// however few lanes have work (phase 2a + 2b: 64 % of the kernel's cycles for 23 % of the reads).  Here they become
+// ITEMS {listed read, table, slab} on a stack in LDS that the wave drains sixteen at a time, one DPP quad per item:
+// lane s fetches quarter s of the slab (one L1 access), scans its two entries, a two-step DPP minimum gives the
+// quad the slab's best key, lane 0 folds it into the read's running minimum with an LDS atomic, and a link in the
+// slab's last slot becomes a new item.  Full-width work stays full width: table 0 for all 256 reads (phase 1) and
+// table 1's primary slab for the first 64 listed reads.
+//   phase 1   table 0, every read; reads that are not settled are listed, their table-0 overflow link -> item
+//   phase 2   table 1 primary slab: first 64 listed reads as one batch (links -> items), further ones as items
+//   drain     tables 0/1 items; then the decision per listed read (hit / ties from neighbour lists / exact path /
+//             needs table 2), exactly as k_match_wave
+//   phase 3   table 2: candidates -> items (128/256-byte slabs: NQ2 pieces per lane), drain, decide
+//   phase 4   exact path for crowded neighbourhoods, coalesced result stores, tally records
+// ---------------------------------------------------------------------------
+constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 64 drains first when fewer are free
+
+template <int NSEG, int NQ2, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wq(const SlabParams* __restrict__ spp,
+                                                   const uint64_t* __restrict__ reads,
+                                                   const uint8_t* __restrict__ flags, uint64_t n, int k,
+                                                   uint64_t kmask, int max_mm_, MatchOut o_arg) {
+    static_assert(NSEG == 2 || NSEG == 3, "wave kernel: d = 1 or 2");
+    (void)o_arg;  // read from the kernel-argument segment in the last phase, see there
+    __shared__ uint64_t q_read[WAVE_T];                                 // listed read; later its result
+    __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];     // its best key so far (LDS atomic min)
+    __shared__ uint32_t wl[WL_CAP];                                     // items: list entry | table << 8 | slab << 10
+    __shared__ uint16_t l_t2[WAVE_T];     // list entries that need table 2
+    __shared__ uint16_t l_slow[WAVE_T];   // list entries that need the exact path
+    const SlabParams& sp = *spp;
+    const uint32_t max_mm = (uint32_t)max_mm_ & 0xFFu;
+    const uint32_t diag = (uint32_t)max_mm_ >> 8;  // BC_DIAG: timing experiments only (results are wrong with any bit set)
+    const uint64_t tile0 = (uint64_t)blockIdx.x * WAVE_T;
+    const uint32_t tn = (uint32_t)min((uint64_t)WAVE_T, n - tile0);
+    const SlabTable& T0 = sp.t[0];
+    const SlabTable& T1 = sp.t[1];
+    const SlabTable& T2 = sp.t[NSEG - 1];
+    const char* const b0 = reinterpret_cast<const char*>(T0.slabs);
+    const char* const b1 = reinterpret_cast<const char*>(T1.slabs);
+    const char* const b2 = reinterpret_cast<const char*>(T2.slabs);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
+    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
+    const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u, sh2 = T2.log2S + 3u;
+    const uint32_t empty0 = T0.empty << 6, empty1 = T1.empty << 6, empty2 = T2.empty << sh2;  // what idle lanes fetch
+    const int s = (int)(lane & 3u);
+    const uint32_t none4[4] = {0u, 0u, 0u, 0u};
+    unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull, t_acc[4] = {0ull, 0ull, 0ull, 0ull};
+    auto phase_mark = [&](int ph) {
+        if (PROF) {
+            const unsigned long long t = (unsigned long long)clock64();
+            t_acc[ph] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    auto rank_of = [&](unsigned long long m) {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
+    auto put = [&](uint32_t qi, uint32_t idx, uint32_t dist, uint32_t nb) {
+        q_read[qi] = (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)(nb > 255u ? 255u : nb) << 40);
+    };
+    uint32_t qn = 0, t2n = 0, sn = 0, wn = 0;  // wave-uniform list lengths
+
+    auto push_items = [&](bool has, uint32_t item) {
+        const unsigned long long m = __ballot(has);
+        if (has) wl[wn + rank_of(m)] = item;
+        wn += (uint32_t)__popcll(m);
+    };
+
+    // sixteen items per step, one quad each; tables 0 and 1 (64-byte slabs)
+    auto drain01 = [&]() {
+        while (wn) {
+            wave_lds_sync();
+            const uint32_t take = min(wn, 16u);
+            wn -= take;
+            const uint32_t q = lane >> 2;
+            const bool act = q < take;
+            const uint32_t item = act ? wl[wn + q] : 0u;
+            const uint32_t qi = item & 255u, slab = item >> 10;
+            const bool t1 = (item & 0x100u) != 0u;
+            const uint64_t r = q_read[qi];
+            const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+            // slab_rest with the table picked per lane
+            const uint32_t st = t1 ? T1.start : T0.start, sh = t1 ? T1.start + T1.slen : T0.start + T0.slen;
+            const uint32_t hf = t1 ? half1 : half0, hm = t1 ? hm1 : hm0;
+            const uint32_t below = (1u << st) - 1u;
+            const uint32_t rest = ((rlo & below) | ((rlo >> sh) << st)) | (((rhi & below) | ((rhi >> sh) << st)) << hf);
+            const char* base = t1 ? b1 : b0;
+            const uint32_t off = act ? (slab << 6) : empty0;
+            const uint4 w = load16(base, off + (uint32_t)s * 16u);
+            const uint32_t x0 = rest ^ w.x, x1 = rest ^ w.z;
+            const uint32_t d0 = __popc((x0 & hm) | (x0 >> hf)), d1 = __popc((x1 & hm) | (x1 >> hf));
+            uint32_t m = min((d0 << 24) | w.y, (d1 << 24) | w.w);
+            m = min(m, quad_perm<0xB1>(m));
+            m = min(m, quad_perm<0x4E>(m));
+            const uint32_t lnk = quad_bcast<3>(w.z);  // the slab's last slot: link or empty (0)
+            const bool lead = act && s == 0;
+            if (lead) atomicMin(&q_key[qi], m);
+            push_items(lead && lnk != 0u, (item & 0x3FFu) | (lnk << 10));
+        }
+        wave_lds_sync();
+    };
+
+    // table 2: NQ2 pieces per lane (128- or 256-byte slabs)
+    auto drain2 = [&]() {
+        while (wn) {
+            wave_lds_sync();
+            const uint32_t take = min(wn, 16u);
+            wn -= take;
+            const uint32_t q = lane >> 2;
+            const bool act = q < take;
+            const uint32_t item = act ? wl[wn + q] : 0u;
+            const uint32_t qi = item & 255u, slab = item >> 10;
+            const uint64_t r = q_read[qi];
+            const uint32_t rest = slab_rest(T2, (uint32_t)r, (uint32_t)(r >> 32));
+            const uint32_t off = act ? (slab << sh2) : empty2;
+            uint4 w[NQ2];
+#pragma unroll
+            for (int h = 0; h < NQ2; ++h) w[h] = load16(b2, off + (uint32_t)(s + 4 * h) * 16u);
+            uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+            for (int h = 0; h < NQ2; ++h) {
+                const uint32_t x0 = rest ^ w[h].x, x1 = rest ^ w[h].z;
+                const uint32_t d0 = __popc((x0 & hm2) | (x0 >> half2)), d1 = __popc((x1 & hm2) | (x1 >> half2));
+                m = min(m, min((d0 << 24) | w[h].y, (d1 << 24) | w[h].w));
+            }
+            m = min(m, quad_perm<0xB1>(m));
+            m = min(m, quad_perm<0x4E>(m));
+            const uint32_t lnk = quad_bcast<3>(w[NQ2 - 1].z);
+            const bool lead = act && s == 0;
+            if (lead) atomicMin(&q_key[qi], m);
+            push_items(lead && lnk != 0u, (item & 0x3FFu) | (lnk << 10));
+        }
+        wave_lds_sync();
+    };
+
+    // hit / tie / exact-path decision for the lane's read once every guide that can matter has been seen
+    auto decide = [&](bool mine, bool final_miss, uint32_t qi, uint32_t kmin, uint32_t rlo, uint32_t rhi) {
+        const uint32_t d = kmin >> 24;
+        const bool inrange = mine && d <= max_mm;
+        uint32_t ridx = kmin & SLAB_GIDX_MASK, rnb = 1u;
+        bool slow = false;
+        if (inrange && !key_unique(kmin, max_mm) && !(diag & 4u)) slow = !sp.nbr_slot || !resolve_ties(sp, rlo, rhi, d, ridx, rnb);
+        if (inrange && !slow) put(qi, ridx, d, rnb);
+        if (mine && !inrange && final_miss) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+        const unsigned long long m = __ballot(slow);
+        if (slow) l_slow[sn + rank_of(m)] = (uint16_t)qi;
+        sn += (uint32_t)__popcll(m);
+        return inrange;
+    };
+
+    // ---- phase 1: table 0, primary slab, every read (exact hits and isolated near hits are final)
+    const uint32_t p0 = lane * 4u;
+    const bool full = p0 + 3 < tn;
+    int32_t idx[4];
+    uint32_t at[4];     // list entry of the lane's reads that were listed
+    uint32_t dist4 = 0; // distances of the reads settled in phase 1, one byte each
+    {
+        uint64_t r[4] = {0, 0, 0, 0};
+        if (full) {
+            load_reads4(reads + tile0 + p0, r);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) r[j] = reads[tile0 + p0 + j];
+        }
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ok[j] = p0 + j < tn && !read_skipped(r[j], flags, tile0 + p0 + j, k);
+            r[j] &= kmask;
+        }
+        // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
+        auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << 6) : 0u; };
+        auto finish = [&](int j, const uint4 (&w)[4][1]) {
+            uint32_t l[4], key = 0xFFFFFFFFu;
+            visit_scan<1>(w, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key, l);
+            const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
+            const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner's overflow link
+            const uint32_t d = key >> 24;
+            const bool fin = ok[j] && d <= max_mm && key_unique(key, max_mm);
+            idx[j] = !ok[j] ? BC_IDX_SKIP : fin ? (int32_t)(key & SLAB_GIDX_MASK) : BC_IDX_MISS;
+            dist4 |= (fin ? d : 0u) << (8 * j);
+            const bool push = ok[j] && !fin;
+            const unsigned long long m = __ballot(push);
+            at[j] = push ? qn + rank_of(m) : 0xFFFFFFFFu;
+            if (push) {
+                q_read[at[j]] = r[j];
+                q_key[at[j]] = key;
+            }
+            qn += (uint32_t)__popcll(m);
+            push_items(push && lnk != 0u, at[j] | (lnk << 10));  // table 0 item
+        };
+        uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
+        visit_issue<1, false>(b0, off0(0), none4, s, wa);
+        visit_issue<1, false>(b0, off0(1), none4, s, wb);
+        finish(0, wa);
+        visit_issue<1, false>(b0, off0(2), none4, s, wa);
+        finish(1, wb);
+        visit_issue<1, false>(b0, off0(3), none4, s, wb);
+        finish(2, wa);
+        finish(3, wb);  // at most 256 table-0 items: WL_CAP holds them
+    }
+    wave_lds_sync();
+    phase_mark(0);
+
+    // ---- phase 2: table 1's primary slab — the first 64 listed reads as one full-width batch, the rest as items
+    if (qn && !(diag & 2u)) {
+        if (wn > WL_CAP - 64) drain01();
+        const uint32_t qi = lane;
+        const bool mine = qi < qn;
+        uint32_t kmin = 0xFFFFFFFFu, rest1 = 0, off1 = empty1;
+        if (mine) {
+            const uint64_t r = q_read[qi];
+            const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+            kmin = q_key[qi];
+            rest1 = slab_rest(T1, rlo, rhi);
+            off1 = seed_value(rlo, rhi, T1.start, T1.slen) << 6;
+        }
+        uint4 wa[4][1];
+        uint32_t l1[4];
+        visit_issue<1, false>(b1, off1, none4, s, wa);
+        visit_scan<1>(wa, rest1, half1, hm1, s, kmin, l1);
+        const uint32_t t0 = quad_bcast<3>(l1[0]), t1 = quad_bcast<3>(l1[1]), t2 = quad_bcast<3>(l1[2]), t3 = quad_bcast<3>(l1[3]);
+        const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;
+        if (mine) q_key[qi] = kmin;
+        push_items(mine && lnk != 0u, qi | 0x100u | (lnk << 10));
+        for (uint32_t qb = 64; qb < qn; qb += 64) {
+            if (wn > WL_CAP - 64) drain01();
+            const uint32_t qj = qb + lane;
+            const bool mj = qj < qn;
+            uint32_t sv = 0;
+            if (mj) {
+                const uint64_t r = q_read[qj];
+                sv = seed_value((uint32_t)r, (uint32_t)(r >> 32), T1.start, T1.slen);
+            }
+            push_items(mj, qj | 0x100u | (sv << 10));
+        }
+    }
+    if (!(diag & 2u)) drain01();
+    wn = 0;
+    // seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1 (NSEG = 3) /
+    // within max_mm (NSEG = 2); unseen guides are at distance >= 2
+    for (uint32_t qb = 0; qb < qn; qb += 64) {
+        const uint32_t qi = qb + lane;
+        const bool mine = qi < qn;
+        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu;
+        if (mine) {
+            const uint64_t r = q_read[qi];
+            rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
+            kmin = q_key[qi];
+        }
+        const bool inrange = decide(mine, NSEG != 3, qi, kmin, rlo, rhi);
+        if (NSEG == 3) {
+            const bool t2 = mine && !inrange;
+            const unsigned long long m = __ballot(t2);
+            if (t2) l_t2[t2n + rank_of(m)] = (uint16_t)qi;
+            t2n += (uint32_t)__popcll(m);
+        }
+    }
+    wave_lds_sync();
+    phase_mark(1);
+
+    // ---- phase 3: table 2 for the reads with nothing in range yet: their primary slabs as items, drained by quads
+    if (NSEG == 3 && !(diag & 1u)) {
+        // the bucket's filter line first (one request): most reads that get here match nothing and leave at once
+        const uint32_t* const flt = (diag & 8u) ? nullptr : sp.flt;
+        uint32_t t2s = 0;  // candidates that pass the filter, compacted at the front of l_t2
+        for (uint32_t tb = 0; tb < t2n; tb += 64) {
+            if (wn > WL_CAP - 64) drain2();
+            const uint32_t ti = tb + lane;
+            const bool mine = ti < t2n;
+            uint32_t qi = 0, sv = 0;
+            bool pass = mine;
+            if (mine) {
+                qi = l_t2[ti];
+                const uint64_t r = q_read[qi];
+                const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+                sv = seed_value(rlo, rhi, T2.start, T2.slen);
+                if (flt) {
+                    const uint32_t* line = flt + (size_t)sv * 16u;
+                    uint32_t hit[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const uint32_t bit = flt_hash7(seed_value(rlo, rhi, sp.f_pos[h], sp.f_len[h]));
+                        hit[h] = (line[h * 4 + (bit >> 5)] >> (bit & 31u)) & 1u;
+                    }
+                    pass = ((hit[0] | hit[1]) & (hit[2] | hit[3])) != 0u;
+                    if (!pass) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+                }
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) l_t2[t2s + rank_of(m)] = (uint16_t)qi;  // slots at or before this lane's own, already read
+            t2s += (uint32_t)__popcll(m);
+            push_items(pass, qi | 0x200u | (sv << 10));
+        }
+        t2n = t2s;
+        drain2();
+        // every guide within max_mm of these reads has segments 0 and 1 dirty, hence a clean segment 2: all seen
+        for (uint32_t tb = 0; tb < t2n; tb += 64) {
+            const uint32_t ti = tb + lane;
+            const bool mine = ti < t2n;
+            uint32_t qi = 0, rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu;
+            if (mine) {
+                qi = l_t2[ti];
+                const uint64_t r = q_read[qi];
+                rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
+                kmin = q_key[qi];
+            }
+            decide(mine, true, qi, kmin, rlo, rhi);
+        }
+        wave_lds_sync();
+    }
+    phase_mark(2);
+
+    // ---- phase 4a: exact evaluation by DPP quads (guides with more than NBR_CAP close neighbours only)
+    if (sn) {
+        const int last_lane = (int)(lane | 3u);
+        for (uint32_t si = lane >> 2; si < sn; si += 16) {
+            const uint32_t qi = l_slow[si];
+            const uint64_t r = q_read[qi];
+            uint32_t key, nb;
+            slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), (int)max_mm, s, last_lane, key, nb);
+            if (s == 0) {
+                if ((key >> 24) <= max_mm) put(qi, key & SLAB_GIDX_MASK, key >> 24, nb);
+                else put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+            }
+        }
+        wave_lds_sync();
+    }
+
+    // ---- phase 4b: every lane collects its four reads' results; full-width coalesced stores, nothing is patched
+    {
+        // The output descriptor (22 dwords) is needed from here on only.  Left to itself the compiler loads it at
+        // kernel entry and keeps it in SGPRs through every phase, spilling table descriptors around it (v_writelane /
+        // v_readlane count against the VALU issue this kernel is bound by): fetch it from the kernel-argument
+        // segment now, through a pointer the optimiser cannot see through.
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const MatchOut __attribute__((address_space(4)))* karg_out_t;
+        const char __attribute__((address_space(4)))* ka =
+            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const MatchOut o = *(karg_out_t)(ka + offsetof(WaveKargs, o));
+#else
+        const MatchOut o = o_arg;  // host pass of the single-source compile: never executed
+#endif
+        uint32_t dist[4], nb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dist[j] = idx[j] >= 0 ? ((dist4 >> (8 * j)) & 0xFFu) : (uint32_t)BC_DIST_NONE;
+            nb[j] = idx[j] >= 0 ? 1u : 0u;
+            if (at[j] != 0xFFFFFFFFu) {
+                const uint64_t e = q_read[at[j]];
+                idx[j] = (int32_t)(uint32_t)e; dist[j] = (uint32_t)(e >> 32) & 0xFFu; nb[j] = (uint32_t)(e >> 40) & 0xFFu;
+            }
+        }
+        if (full) {
+            // non-temporal: nothing in this kernel touches these lines again, the tables should keep the L2 (3 % measured)
+            const u32x4 t = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2], (uint32_t)idx[3]};
+            __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(o.best_idx + tile0) + (p0 >> 2));
+            if (o.best_dist) {
+                __builtin_nontemporal_store(dist[0] | (dist[1] << 8) | (dist[2] << 16) | (dist[3] << 24),
+                                            reinterpret_cast<uint32_t*>(o.best_dist + tile0) + (p0 >> 2));
+            }
+            if (o.n_best) {
+                __builtin_nontemporal_store(nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24),
+                                            reinterpret_cast<uint32_t*>(o.n_best + tile0) + (p0 >> 2));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < tn) {
+                    o.best_idx[tile0 + p0 + j] = idx[j];
+                    if (o.best_dist) o.best_dist[tile0 + p0 + j] = (uint8_t)dist[j];
+                    if (o.n_best) o.n_best[tile0 + p0 + j] = (uint8_t)nb[j];
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
+        if (o.part.rec) {
+            // the lists are dead (every lane has its results in registers): q_key becomes the record staging area
+            // (256 dwords), the item stack the range counters
+            wave_lds_sync();
+            part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_key), wl);
         }
     }
     phase_mark(3);
@@ -1713,6 +2116,36 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     if (s == cs.nseg - 1) {  // descriptor block for the kernel (read through scalar loads)
         sl.nbr_slot = lib->h_nn.empty() ? nullptr : lib->d_nbr_slot;
         sl.nbr = lib->h_nn.empty() ? nullptr : lib->d_nbr;
+        sl.flt = nullptr;
+        if (cs.nseg == 3 && env_int("BC_T2_FILTER", 1)) {  // table-2 filter (see SlabParams)
+            const int k = lib->k;
+            int seg_len[3], seg_pos[3], at = 0;
+            for (int t = 0; t < 3; ++t) { seg_len[t] = k / 3 + (t < k % 3 ? 1 : 0); seg_pos[t] = at; at += seg_len[t]; }
+            for (int t = 0; t < 2; ++t) {
+                const int la = (seg_len[t] + 1) / 2;
+                sl.f_pos[2 * t] = (uint32_t)seg_pos[t]; sl.f_len[2 * t] = (uint32_t)la;
+                sl.f_pos[2 * t + 1] = (uint32_t)(seg_pos[t] + la); sl.f_len[2 * t + 1] = (uint32_t)(seg_len[t] - la);
+            }
+            bool usable = true;
+            for (int h = 0; h < 4; ++h) usable = usable && sl.f_len[h] >= 1 && sl.f_len[h] <= 16;
+            if (usable) {
+                std::vector<uint32_t> flt((size_t)nb * 16, 0u);
+                const uint32_t m2 = (1u << slen) - 1u;
+                for (uint32_t g = 0; g < lib->G; ++g) {
+                    const uint32_t lo = (uint32_t)lib->h_guides[g], hi = (uint32_t)(lib->h_guides[g] >> 32);
+                    const uint32_t bucket = ((lo >> start) & m2) | (((hi >> start) & m2) << slen);
+                    for (int h = 0; h < 4; ++h) {
+                        const uint32_t mh = (1u << sl.f_len[h]) - 1u;
+                        const uint32_t v = ((lo >> sl.f_pos[h]) & mh) | (((hi >> sl.f_pos[h]) & mh) << sl.f_len[h]);
+                        const uint32_t bit = flt_hash7(v);
+                        flt[(size_t)bucket * 16 + (size_t)h * 4 + (bit >> 5)] |= 1u << (bit & 31u);
+                    }
+                }
+                uint32_t* d_flt;
+                if ((rc = dev_upload(lib, flt, &d_flt)) != BC_OK) return rc;
+                sl.flt = d_flt;
+            }
+        }
         std::vector<SlabParams> one(1, sl);
         SlabParams* d_sp;
         if ((rc = dev_upload(lib, one, &d_sp)) != BC_OK) return rc;
@@ -2066,8 +2499,14 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     const int nq2 = nseg == 3 ? (1 << (hp.t[2].log2S - 3)) : 1;
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_)                                                                         \
-    hipLaunchKernelGGL((k_match_wave<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n,   \
-                       lib->k, lib->kmask, max_mm, o)
+    do {                                                                                                           \
+        if (lib->knobs.wave_list)                                                                                  \
+            hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
+                               lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o);                                                    \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_match_wave<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
+                               lib->k, lib->kmask, max_mm, o);                                                     \
+    } while (0)
 #define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false); } while (0)
                     if (nseg == 2) BC_WAVE_P(2, 1);
                     else if (nq2 == 1) BC_WAVE_P(3, 1);
@@ -2075,7 +2514,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     else BC_WAVE_P(3, 4);
 #undef BC_WAVE_P
 #undef BC_WAVE_LAUNCH
-                    note_kernel(lib, "k_match_wave");
+                    note_kernel(lib, lib->knobs.wave_list ? "k_match_wq" : "k_match_wave");
                     BC_HIP(hipGetLastError());
                     if (o.part.rec) { *part_done = true; *tail_begin = n; }
                     if (prof) {
@@ -2329,6 +2768,8 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->device = device; lib->G = n_guides; lib->k = k; lib->kmask = km;
     // experiment knobs: the environment is read here, once per library, never per launch
     lib->knobs.lane = env_int("BC_LANE", 1);
+    lib->knobs.wave_list = env_int("BC_WAVE_LIST", 1);
+    lib->knobs.diag = env_int("BC_DIAG", 0);
     lib->knobs.phase2_sm = env_int("BC_PHASE2_SM", 1);
     lib->knobs.single_slab = env_int("BC_SINGLE_SLAB", 0);
     lib->knobs.slab_lpr = env_int("BC_SLAB_LPR", 4);

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 tag=$1; shift
 rm -rf gpurun_out/kt_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$tag -- python3 bench.py --no-cpu --steps 5 --warmup 2 "$@" > gpurun_out/kt_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$tag -- python3 bench.py --no-cpu --no-secondary --steps 5 --warmup 2 "$@" > gpurun_out/kt_$tag.log 2>&1
 python3 - <<PY
 import csv,glob
 for f in glob.glob("gpurun_out/kt_$tag/*/*kernel_stats.csv"):

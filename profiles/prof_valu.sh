@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pv; mkdir -p gpurun_out/pv
 for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   p=$(echo $pass | cut -c1-14 | tr ' ' '_')
-  timeout -k 10 200 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pv/pmc_$p -- python3 bench.py --no-cpu --steps 2 --warmup 1 "$@" > gpurun_out/pv/$p.log 2>&1 || echo "$p failed"
+  timeout -k 10 200 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pv/pmc_$p -- python3 bench.py --no-cpu --no-secondary --steps 2 --warmup 1 "$@" > gpurun_out/pv/$p.log 2>&1 || echo "$p failed"
 done
 python3 profiles/summarize.py gpurun_out/pv k_match > gpurun_out/pv/summary.json
 python3 - <<PY
