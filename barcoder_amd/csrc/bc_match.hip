@@ -1364,7 +1364,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];     // its best key so far (LDS atomic min)
     __shared__ uint32_t wl[WL_CAP];                                     // items: list entry | table << 8 | slab << 10
     __shared__ uint16_t l_t2[WAVE_T];     // list entries that need table 2
-    __shared__ uint16_t l_slow[WAVE_T];   // list entries that need the exact path
+    __shared__ uint16_t l_slow[WAVE_T];   // list entries whose best guide may tie with a neighbour; then (compacted in
+                                          // place, behind the position being read) those that need the exact path
+    uint16_t* const l_tie = l_slow;
     const SlabParams& sp = *spp;
     const uint32_t max_mm = (uint32_t)max_mm_ & 0xFFu;
     const uint32_t diag = (uint32_t)max_mm_ >> 8;  // BC_DIAG: timing experiments only (results are wrong with any bit set)
@@ -1397,7 +1399,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     auto put = [&](uint32_t qi, uint32_t idx, uint32_t dist, uint32_t nb) {
         q_read[qi] = (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)(nb > 255u ? 255u : nb) << 40);
     };
-    uint32_t qn = 0, t2n = 0, sn = 0, wn = 0;  // wave-uniform list lengths
+    uint32_t qn = 0, t2n = 0, sn = 0, wn = 0, tien = 0;  // wave-uniform list lengths
 
     auto push_items = [&](bool has, uint32_t item) {
         const unsigned long long m = __ballot(has);
@@ -1472,18 +1474,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         wave_lds_sync();
     };
 
-    // hit / tie / exact-path decision for the lane's read once every guide that can matter has been seen
-    auto decide = [&](bool mine, bool final_miss, uint32_t qi, uint32_t kmin, uint32_t rlo, uint32_t rhi) {
+    // hit / tie / miss decision for the lane's read once every guide that can matter has been seen.  A best guide
+    // whose isolation flag does not rule out a second guide at the same distance goes on the tie list (resolved by
+    // quads from the guide's neighbour list after all decisions: one pass per tile instead of one per decision batch)
+    auto decide = [&](bool mine, bool final_miss, uint32_t qi, uint32_t kmin) {
         const uint32_t d = kmin >> 24;
         const bool inrange = mine && d <= max_mm;
-        uint32_t ridx = kmin & SLAB_GIDX_MASK, rnb = 1u;
-        bool slow = false;
-        if (inrange && !key_unique(kmin, max_mm) && !(diag & 4u)) slow = !sp.nbr_slot || !resolve_ties(sp, rlo, rhi, d, ridx, rnb);
-        if (inrange && !slow) put(qi, ridx, d, rnb);
+        const bool tie = inrange && !key_unique(kmin, max_mm) && !(diag & 4u);
+        if (inrange && !tie) put(qi, kmin & SLAB_GIDX_MASK, d, 1u);
         if (mine && !inrange && final_miss) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-        const unsigned long long m = __ballot(slow);
-        if (slow) l_slow[sn + rank_of(m)] = (uint16_t)qi;
-        sn += (uint32_t)__popcll(m);
+        const unsigned long long m = __ballot(tie);
+        if (tie) l_tie[tien + rank_of(m)] = (uint16_t)qi;
+        tien += (uint32_t)__popcll(m);
         return inrange;
     };
 
@@ -1578,8 +1580,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (!(diag & 2u)) drain01();
     wn = 0;
     // seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1 (NSEG = 3) /
-    // within max_mm (NSEG = 2); unseen guides are at distance >= 2
+    // within max_mm (NSEG = 2); unseen guides are at distance >= 2.  A read with nothing in range is a candidate
+    // for table 2: its bucket's filter line first (one request) — most such reads match nothing and leave here
+    const uint32_t* const flt = (NSEG == 3 && !(diag & 8u)) ? sp.flt : nullptr;
     for (uint32_t qb = 0; qb < qn; qb += 64) {
+        if (NSEG == 3 && wn > WL_CAP - 64) drain2();
         const uint32_t qi = qb + lane;
         const bool mine = qi < qn;
         uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu;
@@ -1588,67 +1593,77 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
             kmin = q_key[qi];
         }
-        const bool inrange = decide(mine, NSEG != 3, qi, kmin, rlo, rhi);
+        const bool inrange = decide(mine, NSEG != 3, qi, kmin);
         if (NSEG == 3) {
-            const bool t2 = mine && !inrange;
-            const unsigned long long m = __ballot(t2);
-            if (t2) l_t2[t2n + rank_of(m)] = (uint16_t)qi;
+            bool pass = mine && !inrange && !(diag & 1u);
+            const uint32_t sv = seed_value(rlo, rhi, T2.start, T2.slen);
+            if (pass && flt) {
+                const uint32_t* line = flt + (size_t)sv * 16u;
+                uint32_t hit[4];
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+                    const uint32_t bit = flt_hash7(seed_value(rlo, rhi, sp.f_pos[hh], sp.f_len[hh]));
+                    hit[hh] = (line[hh * 4 + (bit >> 5)] >> (bit & 31u)) & 1u;
+                }
+                pass = ((hit[0] | hit[1]) & (hit[2] | hit[3])) != 0u;
+            }
+            if (mine && !inrange && !pass) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+            const unsigned long long m = __ballot(pass);
+            if (pass) l_t2[t2n + rank_of(m)] = (uint16_t)qi;
             t2n += (uint32_t)__popcll(m);
+            push_items(pass, qi | 0x200u | (sv << 10));
         }
     }
     wave_lds_sync();
     phase_mark(1);
 
-    // ---- phase 3: table 2 for the reads with nothing in range yet: their primary slabs as items, drained by quads
-    if (NSEG == 3 && !(diag & 1u)) {
-        // the bucket's filter line first (one request): most reads that get here match nothing and leave at once
-        const uint32_t* const flt = (diag & 8u) ? nullptr : sp.flt;
-        uint32_t t2s = 0;  // candidates that pass the filter, compacted at the front of l_t2
-        for (uint32_t tb = 0; tb < t2n; tb += 64) {
-            if (wn > WL_CAP - 64) drain2();
-            const uint32_t ti = tb + lane;
-            const bool mine = ti < t2n;
-            uint32_t qi = 0, sv = 0;
-            bool pass = mine;
-            if (mine) {
-                qi = l_t2[ti];
-                const uint64_t r = q_read[qi];
-                const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
-                sv = seed_value(rlo, rhi, T2.start, T2.slen);
-                if (flt) {
-                    const uint32_t* line = flt + (size_t)sv * 16u;
-                    uint32_t hit[4];
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const uint32_t bit = flt_hash7(seed_value(rlo, rhi, sp.f_pos[h], sp.f_len[h]));
-                        hit[h] = (line[h * 4 + (bit >> 5)] >> (bit & 31u)) & 1u;
-                    }
-                    pass = ((hit[0] | hit[1]) & (hit[2] | hit[3])) != 0u;
-                    if (!pass) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-                }
-            }
-            const unsigned long long m = __ballot(pass);
-            if (pass) l_t2[t2s + rank_of(m)] = (uint16_t)qi;  // slots at or before this lane's own, already read
-            t2s += (uint32_t)__popcll(m);
-            push_items(pass, qi | 0x200u | (sv << 10));
-        }
-        t2n = t2s;
+    // ---- phase 3: table 2 items, then the decisions for the candidates
+    if (NSEG == 3 && t2n) {
         drain2();
         // every guide within max_mm of these reads has segments 0 and 1 dirty, hence a clean segment 2: all seen
         for (uint32_t tb = 0; tb < t2n; tb += 64) {
             const uint32_t ti = tb + lane;
             const bool mine = ti < t2n;
-            uint32_t qi = 0, rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu;
+            uint32_t qi = 0, kmin = 0xFFFFFFFFu;
             if (mine) {
                 qi = l_t2[ti];
-                const uint64_t r = q_read[qi];
-                rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
                 kmin = q_key[qi];
             }
-            decide(mine, true, qi, kmin, rlo, rhi);
+            decide(mine, true, qi, kmin);
         }
         wave_lds_sync();
     }
+    // ---- ties: one quad per listed read whose best guide has neighbours within reach.  The guide's list (at most
+    // NBR_CAP entries, one 128-byte line) is fetched two entries per lane; every guide that ties with it is in there
+    for (uint32_t tb = 0; tb < tien; tb += 16) {
+        const uint32_t ti = tb + (lane >> 2);
+        const bool act = ti < tien;
+        const uint32_t qi = act ? l_tie[ti] : 0u;
+        const uint64_t r = q_read[qi];
+        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+        const uint32_t kmin = q_key[qi];
+        const uint32_t d1 = kmin >> 24, g0 = kmin & SLAB_GIDX_MASK;
+        uint32_t slot = NBR_NONE;
+        if (act && sp.nbr_slot) slot = sp.nbr_slot[g0];
+        const bool listed = slot < NBR_OVER;
+        uint32_t cnt = 0, best = g0;
+        if (listed) {
+            const uint4 e0 = sp.nbr[(size_t)slot * NBR_CAP + s], e1 = sp.nbr[(size_t)slot * NBR_CAP + s + 4];
+            const bool t0 = e0.w != 0u && (uint32_t)__popc((rlo ^ e0.x) | (rhi ^ e0.y)) == d1;
+            const bool t1 = e1.w != 0u && (uint32_t)__popc((rlo ^ e1.x) | (rhi ^ e1.y)) == d1;
+            cnt = (t0 ? 1u : 0u) + (t1 ? 1u : 0u);
+            best = min(t0 ? e0.z : g0, t1 ? e1.z : g0);
+        }
+        cnt += quad_perm<0xB1>(cnt); cnt += quad_perm<0x4E>(cnt);
+        best = min(best, quad_perm<0xB1>(best)); best = min(best, quad_perm<0x4E>(best));
+        // without lists (or with more neighbours than a list holds) the exact path decides
+        const bool slow = act && (!sp.nbr_slot || slot == NBR_OVER);
+        if (act && !slow && s == 0) put(qi, best, d1, 1u + cnt);
+        const unsigned long long m = __ballot(slow && s == 0);
+        if (slow && s == 0) l_slow[sn + rank_of(m)] = (uint16_t)qi;
+        sn += (uint32_t)__popcll(m);
+    }
+    wave_lds_sync();
     phase_mark(2);
 
     // ---- phase 4a: exact evaluation by DPP quads (guides with more than NBR_CAP close neighbours only)
