@@ -93,8 +93,7 @@ struct SlabParams {
 // Tuning / experiment knobs, read from the environment ONCE when a library is created (never per launch).
 // Defaults are the measured best; the knob-coverage tests check that none of them changes a result.
 struct Knobs {
-    int lane = 1;         // BC_LANE=0: quad kernels (k_match_fused) instead of the wave kernels
-    int wave_list = 1;    // BC_WAVE_LIST=0: k_match_wave (lane-per-read batches) instead of k_match_wq (quad work list)
+    int lane = 1;         // BC_LANE=0: quad kernels (k_match_fused) instead of the wave kernel (k_match_wq)
     int phase2_sm = 1;    // BC_PHASE2_SM=0: quad kernels without the state machine
     int single_slab = 0;  // BC_SINGLE_SLAB=1: the one-kernel slab form (k_match_slab) for every d
     int slab_lpr = 4;     // BC_SLAB_LPR=8: eight lanes per read in k_match_slab

@@ -7,19 +7,25 @@
 //
 // Algorithms over the same inputs / outputs (bc_match_dev selects):
 //   k_match_hash   : d = 0.  One open-addressing probe (two-slot buckets, one 16-byte
-//                    load) per read into a table that lives in L2 / Infinity Cache.
-//   k_match_fused  : d = 1..3, the default.  Per 2048-read tile: exact stage through the
-//                    hash table, reads without an exact hit queued in LDS, seed stage
-//                    (pigeonhole slab index, DPP quad per read, staged table rounds).
-//   k_match_slab / k_match_slabq : the same slab index as one kernel / as the second
-//                    kernel of a two-launch pipeline (tuning and fallback variants).
-//   k_match_seed   : CSR form of the seed index, lane = read (k > 28, huge libraries).
-//   k_match_all    : every (query, guide, dist) within d: the Bowtie -a -v N bypass.
-//   k_match_brute  : any d.  Guide table tiled through LDS, lane = read, all pairs
-//                    XOR + popcount.  VALU-bound; the in-GPU cross-check.
-//   k_hist         : per-guide counts + first-seen from best_idx, LDS-privatised.
-// Measured bound of the lookup kernels: ~0.3-0.4 vector-L1 (TCP) accesses per clock
-// per CU, i.e. the number of divergent table visits per read, not HBM or L2.
+//                    load) per read into a 4 MiB table that lives in L2.
+//   k_match_wq     : d = 1, 2, the default.  Pigeonhole slab index, no hash table (table 0 is
+//                    the exact stage); a wave owns 256 reads, quad-cooperative slab loads for
+//                    the full-width stages, a quad work list for the sparse ones, a filter line
+//                    in front of table 2.
+//   k_match_fused  : previous generation (hash stage + LDS queue + DPP quad per queued read):
+//                    d = 3, buckets above 16 guides (libraries above ~2.6e5 20-mers), BC_LANE=0.
+//   k_match_slab   : the slab index as one simple kernel (small / unaligned inputs, d = 0 via seed).
+//   k_match_seed   : CSR form of the seed index, lane = read (k - seed > 16 bases, huge libraries).
+//   k_match_all    : every (query, guide, dist) within d, optionally gated by a PAM bitmap:
+//                    the Bowtie -a -v N bypass of targets.find_hits.
+//   k_match_brute  : any d.  Guide tile in LDS, lane = read, all pairs XOR + popcount.
+//                    VALU-bound; the in-GPU cross-check.
+//   k_hist_part + k_first_refine : per-guide counts / first-seen from the range-partitioned
+//                    records the matchers write while a tile's results are on chip;
+//   k_hist         : the same from best_idx, one sweep per guide range (other kernels, few ranges).
+// Bounds (measured): the lookup kernels sit on the L2's random-request rate
+// under a concurrent stream (~1.1 requests per read is the floor: 0.67 ms per 1e8 reads) and on
+// VALU issue (86 %) at the same time; the tally kernels are HBM streams.
 #include <dlfcn.h>
 #include <math.h>
 #include <stddef.h>
@@ -907,45 +913,22 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
 }
 
 // ---------------------------------------------------------------------------
-// K2+K3 wave form (default for d = 1, 2).  History of the bound, measured with
-// profiles/prof_insts.sh, profiles/prof_valu.sh and profiles/gather_bench.hip:
-//   quad state machine (k_match_fused): 11.6 VALU wave-instructions per read =
-//     88 % of the issue slots, and 7.4 MB of tables against a 4 MB L2 (41 % L2
-//     misses, Infinity-Fabric bound at the same time): 2.33 ms per 1e8 reads;
-//   one lane per read, slabs fetched as 4 x 16 B by the lane: VALU 47 %, but
-//     four vector-L1 accesses per slab and ~25 dependent memory round trips per
-//     workgroup tile held together by barriers: 1.95 ms.
-// This kernel (1.22 ms; 2.1 L2 requests per read at 170 G requests/s — the stream +
-// gather microbenchmark reaches 142-184 G/s with a table this size — and VALU 90 %):
-//   * no hash table: a guide equal to the read sits in the read's seed-0 bucket, so
-//     table 0 doubles as the exact-match table; 3.7 MB of slabs, 93 % L2 hits;
-//   * a wave works alone (64-thread workgroups) on 256 consecutive reads and keeps
-//     its own LDS lists; nothing ever waits on a workgroup barrier;
-//   * reads are owned by lanes, slabs are fetched QUAD-COOPERATIVELY: for the four
-//     reads owned by the lanes of a quad, load j brings read j's slab with lane s
-//     taking quarter s — one L1 access per slab; lane s scans its quarter for all
-//     four reads (rest of read j by DPP broadcast; xor, shift, and-or, popcount,
-//     shift-or, min per entry) and a transposed DPP min-reduction hands every
-//     owner its minimum; overflow links are followed straight from lane 3 (a read
-//     without one is pointed at its table's all-empty slab: no branches, no masks);
-//   * stages run on compacted lists: reads without an exact hit (table 1 + overflow
-//     slabs, then the decision), then the ones that still need table 2;
-//   * n_best = 1 is proven by the best guide's isolation flags; otherwise the
-//     owning lane counts ties from the guide's neighbour list; the quad exact
-//     path (slab_slow) is left for guides with more than NBR_CAP close neighbours;
-//   * results are staged in the list entries and leave as full-width coalesced
-//     stores by the lane that owns the read: nothing is patched afterwards.
-// Tried and dropped (slower): persistent waves draining the lists
-// across tiles (fewer VALU, worse memory behaviour), skipping the loads nobody
-// needs (fewer L1 accesses, 13 % more VALU: 6 % slower now that VALU is the wall),
-// direct scattered result stores over placeholders (0.5 ms of partial-line writes).
+// Building blocks of the wave matcher (k_match_wq below).  A wave works alone (64-thread workgroups, no barriers)
+// on 256 consecutive reads that its lanes own, four each; slabs are fetched QUAD-COOPERATIVELY: for the four reads
+// owned by the lanes of a quad, load j brings read j's 64-byte slab with lane s taking quarter s — one L1 access
+// per slab; lane s scans its quarter for all four reads (rest of read j by DPP broadcast; xor, shift, and-or,
+// popcount, shift-or, min per entry) and a transposed DPP min-reduction hands every owner its minimum.  There is
+// no hash table: a guide equal to the read sits in the read's seed-0 bucket, so table 0 doubles as the exact-match
+// table.  n_best = 1 is proven by the best guide's isolation flags; otherwise ties are counted from the guide's
+// neighbour list; the quad exact path (slab_slow) is left for guides with more than NBR_CAP close neighbours.
+// Results are staged in the list entries and leave as full-width coalesced stores by the lane that owns the read.
 // ---------------------------------------------------------------------------
 constexpr int WAVE_T = 256;  // reads per wave (4 per lane)
-// layout of k_match_wave's kernel-argument segment (natural alignment, declaration order)
+// layout of k_match_wq's kernel-argument segment (natural alignment, declaration order)
 struct WaveKargs {
     const void* spp; const void* reads; const void* flags; uint64_t n; int k; uint64_t kmask; int max_mm; MatchOut o;
 };
-static_assert(offsetof(WaveKargs, o) == 56, "k_match_wave kernel-argument layout");
+static_assert(offsetof(WaveKargs, o) == 56, "k_match_wq kernel-argument layout");
 
 // is the best candidate provably the only guide at its distance?
 __device__ __forceinline__ bool key_unique(uint32_t key, uint32_t max_mm) {
@@ -1047,309 +1030,30 @@ __device__ unsigned long long g_phase_cycles[8];  // BC_PHASE_PROF=1: summed cyc
 // for every outstanding global load and store
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int NSEG, int NQ2, bool PROF>
-// 6 waves per SIMD (78 VGPRs): measured 1.36 ms against 1.43 ms at the compiler's own choice (85 VGPRs, 5 waves)
-// and 1.53 ms when forced to 7 (72 VGPRs with spills)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wave(const SlabParams* __restrict__ spp,
-                                                   const uint64_t* __restrict__ reads,
-                                                   const uint8_t* __restrict__ flags, uint64_t n, int k,
-                                                   uint64_t kmask, int max_mm_, MatchOut o_arg) {
-    static_assert(NSEG == 2 || NSEG == 3, "wave kernel: d = 1 or 2");
-    (void)o_arg;  // read from the kernel-argument segment in phase 3, see there
-    // list of reads without an exact hit: read, best key so far, table 0's overflow slab (byte offset), position
-    __shared__ uint64_t q_read[WAVE_T];
-    __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];
-    __shared__ uint32_t q_off[WAVE_T];
-    __shared__ uint16_t l_t2[WAVE_T];     // list entries that need table 2
-    __shared__ uint16_t l_slow[WAVE_T];   // list entries that need the exact path
-    const SlabParams& sp = *spp;
-    const uint32_t max_mm = (uint32_t)max_mm_;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * WAVE_T;
-    const uint32_t tn = (uint32_t)min((uint64_t)WAVE_T, n - tile0);
-    const SlabTable& T0 = sp.t[0];
-    const SlabTable& T1 = sp.t[1];
-    const SlabTable& T2 = sp.t[NSEG - 1];
-    const char* const b0 = reinterpret_cast<const char*>(T0.slabs);
-    const char* const b1 = reinterpret_cast<const char*>(T1.slabs);
-    const char* const b2 = reinterpret_cast<const char*>(T2.slabs);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
-    const uint32_t empty0 = T0.empty << 6, empty1 = T1.empty << 6, empty2 = T2.empty << (T2.log2S + 3u);  // what idle lanes fetch
-    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
-    const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u, sh2 = T2.log2S + 3u;
-    const int s = (int)(lane & 3u);
-    const uint32_t none4[4] = {0u, 0u, 0u, 0u};
-    unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull, t_acc[4] = {0ull, 0ull, 0ull, 0ull};
-    auto phase_mark = [&](int ph) {
-        if (PROF) {
-            const unsigned long long t = (unsigned long long)clock64();
-            t_acc[ph] += t - t_prev;
-            t_prev = t;
-        }
-    };
-    auto rank_of = [&](unsigned long long m) {
-        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    };
-    // a listed read's result replaces the read in its list entry (index | dist << 32 | n_best << 40); the lane that
-    // owns the read in phase 1 collects it at the end: every result leaves in full-width coalesced stores
-    auto put = [&](uint32_t qi, uint32_t idx, uint32_t dist, uint32_t nb) {
-        q_read[qi] = (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)(nb > 255u ? 255u : nb) << 40);
-    };
-    uint32_t qn = 0, t2n = 0, sn = 0;  // wave-uniform list lengths
-
-    // hit / tie / exact-path decision for the lane's read once every guide that can matter has been seen
-    auto decide = [&](bool mine, bool final_miss, uint32_t qi, uint32_t kmin, uint32_t rlo, uint32_t rhi) {
-        const uint32_t d = kmin >> 24;
-        const bool inrange = mine && d <= max_mm;
-        uint32_t ridx = kmin & SLAB_GIDX_MASK, rnb = 1u;
-        bool slow = false;
-        if (inrange && !key_unique(kmin, max_mm)) slow = !sp.nbr_slot || !resolve_ties(sp, rlo, rhi, d, ridx, rnb);
-        if (inrange && !slow) put(qi, ridx, d, rnb);
-        if (mine && !inrange && final_miss) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-        const unsigned long long m = __ballot(slow);
-        if (slow) l_slow[sn + rank_of(m)] = (uint16_t)qi;
-        sn += (uint32_t)__popcll(m);
-        return inrange;
-    };
-
-    // ---- phase 1: table 0, primary slab, every read (exact hits and isolated near hits are final)
-    const uint32_t p0 = lane * 4u;
-    const bool full = p0 + 3 < tn;
-    int32_t idx[4];
-    uint32_t at[4];     // list entry of the lane's reads that were listed
-    uint32_t dist4 = 0; // distances of the reads settled in phase 1, one byte each
-    {
-        uint64_t r[4] = {0, 0, 0, 0};
-        if (full) {
-            load_reads4(reads + tile0 + p0, r);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (p0 + j < tn) r[j] = reads[tile0 + p0 + j];
-        }
-        bool ok[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ok[j] = p0 + j < tn && !read_skipped(r[j], flags, tile0 + p0 + j, k);
-            r[j] &= kmask;
-        }
-        // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
-        auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << 6) : 0u; };
-        auto finish = [&](int j, const uint4 (&w)[4][1]) {
-            uint32_t l[4], key = 0xFFFFFFFFu;
-            visit_scan<1>(w, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key, l);
-            const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
-            const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner needs its link for the list
-            // final already: the guide itself (d = 0), or a guide within max_mm whose isolation flag rules out any
-            // other guide that close to the read (nn > 2d: a second guide within d of the read would be within 2d of
-            // this one) — whatever the other tables and the overflow slabs hold
-            const uint32_t d = key >> 24;
-            const bool fin = ok[j] && d <= max_mm && key_unique(key, max_mm);
-            idx[j] = !ok[j] ? BC_IDX_SKIP : fin ? (int32_t)(key & SLAB_GIDX_MASK) : BC_IDX_MISS;
-            dist4 |= (fin ? d : 0u) << (8 * j);
-            const bool push = ok[j] && !fin;
-            const unsigned long long m = __ballot(push);
-            at[j] = push ? qn + rank_of(m) : 0xFFFFFFFFu;
-            if (push) {
-                q_read[at[j]] = r[j];
-                q_key[at[j]] = key;
-                q_off[at[j]] = lnk ? (lnk << 6) : empty0;
-            }
-            qn += (uint32_t)__popcll(m);
-        };
-        uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
-        visit_issue<1, false>(b0, off0(0), none4, s, wa);
-        visit_issue<1, false>(b0, off0(1), none4, s, wb);
-        finish(0, wa);
-        visit_issue<1, false>(b0, off0(2), none4, s, wa);
-        finish(1, wb);
-        visit_issue<1, false>(b0, off0(3), none4, s, wb);
-        finish(2, wa);
-        finish(3, wb);
-    }
-    wave_lds_sync();
-    phase_mark(0);
-
-    // ---- phase 2a: table 1 + overflow slabs of tables 0 and 1, 64 listed reads at a time, then the decision
-    for (uint32_t qb = 0; qb < qn; qb += 64) {
-        const uint32_t qi = qb + lane;
-        const bool mine = qi < qn;
-        uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu, rest0 = 0, rest1 = 0, off0 = empty0, off1 = empty1;
-        if (mine) {
-            const uint64_t r = q_read[qi];
-            rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
-            kmin = q_key[qi]; off0 = q_off[qi];
-            rest0 = slab_rest(T0, rlo, rhi);
-            rest1 = slab_rest(T1, rlo, rhi);
-            off1 = seed_value(rlo, rhi, T1.start, T1.slen) << 6;
-        }
-        uint4 wa[4][1], wb[4][1];
-        uint32_t l0[4] = {0u, 0u, 0u, 0u}, l1[4];
-        bool any0 = __ballot(off0 != empty0) != 0ull;
-        visit_issue<1, false>(b1, off1, none4, s, wa);
-        if (any0) visit_issue<1, false>(b0, off0, none4, s, wb);
-        visit_scan<1>(wa, rest1, half1, hm1, s, kmin, l1);
-        if (any0) visit_scan<1>(wb, rest0, half0, hm0, s, kmin, l0);
-        for (;;) {  // further overflow slabs, straight from lane 3 (one table at a time: registers)
-            any0 = __ballot(s == 3 && (l0[0] | l0[1] | l0[2] | l0[3]) != 0u) != 0ull;
-            const bool any1 = __ballot(s == 3 && (l1[0] | l1[1] | l1[2] | l1[3]) != 0u) != 0ull;
-            if (!any0 && !any1) break;
-            if (any0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) l0[j] = l0[j] ? (l0[j] << 6) : empty0;
-                visit_issue<1, true>(b0, 0u, l0, s, wa);
-                visit_scan<1>(wa, rest0, half0, hm0, s, kmin, l0);
-            }
-            if (any1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) l1[j] = l1[j] ? (l1[j] << 6) : empty1;
-                visit_issue<1, true>(b1, 0u, l1, s, wa);
-                visit_scan<1>(wa, rest1, half1, hm1, s, kmin, l1);
-            }
-        }
-        // seen so far: every guide with a clean segment 0 or 1, i.e. every guide within distance 1 (NSEG = 3) /
-        // within max_mm (NSEG = 2); unseen guides are at distance >= 2
-        const bool inrange = decide(mine, NSEG != 3, qi, kmin, rlo, rhi);
-        if (NSEG == 3) {
-            const bool t2 = mine && !inrange;
-            const unsigned long long m = __ballot(t2);
-            if (t2) l_t2[t2n + rank_of(m)] = (uint16_t)qi;
-            t2n += (uint32_t)__popcll(m);
-        }
-    }
-    wave_lds_sync();
-    phase_mark(1);
-
-    // ---- phase 2b: table 2 for the reads with nothing in range yet (compacted: full waves again)
-    if constexpr (NSEG == 3) {
-        for (uint32_t tb = 0; tb < t2n; tb += 64) {
-            const uint32_t ti = tb + lane;
-            const bool mine = ti < t2n;
-            uint32_t qi = 0, rlo = 0, rhi = 0, rest = 0, off = empty2, kmin = 0xFFFFFFFFu;
-            if (mine) {
-                qi = l_t2[ti];
-                const uint64_t r = q_read[qi];
-                rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
-                rest = slab_rest(T2, rlo, rhi);
-                off = seed_value(rlo, rhi, T2.start, T2.slen) << sh2;
-            }
-            uint4 w[4][NQ2];
-            uint32_t l[4];
-            visit_issue<NQ2, false>(b2, off, none4, s, w);
-            visit_scan<NQ2>(w, rest, half2, hm2, s, kmin, l);
-            while (__ballot(s == 3 && (l[0] | l[1] | l[2] | l[3]) != 0u) != 0ull) {  // overflow slabs, from lane 3
-#pragma unroll
-                for (int j = 0; j < 4; ++j) l[j] = l[j] ? (l[j] << sh2) : empty2;
-                visit_issue<NQ2, true>(b2, 0u, l, s, w);
-                visit_scan<NQ2>(w, rest, half2, hm2, s, kmin, l);
-            }
-            // every guide within max_mm of these reads has segments 0 and 1 dirty, hence a clean segment 2: all seen
-            decide(mine, true, qi, kmin, rlo, rhi);
-        }
-        wave_lds_sync();
-    }
-    phase_mark(2);
-
-    // ---- phase 2c: exact evaluation by DPP quads (guides with more than NBR_CAP close neighbours only)
-    if (sn) {
-        const int last_lane = (int)(lane | 3u);
-        for (uint32_t si = lane >> 2; si < sn; si += 16) {
-            const uint32_t qi = l_slow[si];
-            const uint64_t r = q_read[qi];
-            uint32_t key, nb;
-            slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), max_mm_, s, last_lane, key, nb);
-            if (s == 0) {
-                if ((key >> 24) <= max_mm) put(qi, key & SLAB_GIDX_MASK, key >> 24, nb);
-                else put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-            }
-        }
-        wave_lds_sync();
-    }
-
-    // ---- phase 3: every lane collects its four reads' results; full-width coalesced stores, nothing is patched
-    {
-        // The output descriptor (22 dwords) is needed from here on only.  Left to itself the compiler loads it at
-        // kernel entry and keeps it in SGPRs through every phase, spilling table descriptors around it (v_writelane /
-        // v_readlane count against the VALU issue this kernel is bound by): fetch it from the kernel-argument
-        // segment now, through a pointer the optimiser cannot see through.
-#if defined(__HIP_DEVICE_COMPILE__)
-        typedef const MatchOut __attribute__((address_space(4)))* karg_out_t;
-        const char __attribute__((address_space(4)))* ka =
-            (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        const MatchOut o = *(karg_out_t)(ka + offsetof(WaveKargs, o));
-#else
-        const MatchOut o = o_arg;  // host pass of the single-source compile: never executed
-#endif
-        uint32_t dist[4], nb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dist[j] = idx[j] >= 0 ? ((dist4 >> (8 * j)) & 0xFFu) : (uint32_t)BC_DIST_NONE;
-            nb[j] = idx[j] >= 0 ? 1u : 0u;
-            if (at[j] != 0xFFFFFFFFu) {
-                const uint64_t e = q_read[at[j]];
-                idx[j] = (int32_t)(uint32_t)e; dist[j] = (uint32_t)(e >> 32) & 0xFFu; nb[j] = (uint32_t)(e >> 40) & 0xFFu;
-            }
-        }
-        if (full) {
-            // non-temporal: nothing in this kernel touches these lines again, the tables should keep the L2 (3 % measured)
-            const u32x4 t = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2], (uint32_t)idx[3]};
-            __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(o.best_idx + tile0) + (p0 >> 2));
-            if (o.best_dist) {
-                __builtin_nontemporal_store(dist[0] | (dist[1] << 8) | (dist[2] << 16) | (dist[3] << 24),
-                                            reinterpret_cast<uint32_t*>(o.best_dist + tile0) + (p0 >> 2));
-            }
-            if (o.n_best) {
-                __builtin_nontemporal_store(nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24),
-                                            reinterpret_cast<uint32_t*>(o.n_best + tile0) + (p0 >> 2));
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (p0 + j < tn) {
-                    o.best_idx[tile0 + p0 + j] = idx[j];
-                    if (o.best_dist) o.best_dist[tile0 + p0 + j] = (uint8_t)dist[j];
-                    if (o.n_best) o.n_best[tile0 + p0 + j] = (uint8_t)nb[j];
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
-        if (o.part.rec) {
-            // the lists are dead (every lane has its results in registers; the stores above come after the waits on
-            // those LDS reads): q_key becomes the record staging area (256 dwords), q_off the range counters
-            wave_lds_sync();
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (p0 + j >= tn) idx[j] = BC_IDX_SKIP;
-            part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_key), q_off);
-        }
-    }
-    phase_mark(3);
-    if (PROF && threadIdx.x == 0) {
-        for (int i = 0; i < 4; ++i) atomicAdd(&g_phase_cycles[i], t_acc[i]);
-        atomicAdd(&g_phase_cycles[7], 1ull);
-    }
-}
-
 // ---------------------------------------------------------------------------
-// K2+K3, wave form with a quad work list (k_match_wq; default for d = 1, 2 since round 2).
-// Same tables, same phase 1 and the same decision rules as k_match_wave; what changed is everything that only a
-// FEW reads of a tile need.  k_match_wave ran those as lane-per-read batches — the overflow slabs of tables 0/1
-// (16 % of the listed reads each), the second, mostly empty batch of listed reads (one tile in five), table 2's
-// 128-byte slabs and their chains for 14 % of the reads — and every such batch costs a full wave's instructions
-// however few lanes have work (phase 2a + 2b: 64 % of the kernel's cycles for 23 % of the reads).  Here they become
-// ITEMS {listed read, table, slab} on a stack in LDS that the wave drains sixteen at a time, one DPP quad per item:
-// lane s fetches quarter s of the slab (one L1 access), scans its two entries, a two-step DPP minimum gives the
-// quad the slab's best key, lane 0 folds it into the read's running minimum with an LDS atomic, and a link in the
-// slab's last slot becomes a new item.  Full-width work stays full width: table 0 for all 256 reads (phase 1) and
-// table 1's primary slab for the first 64 listed reads.
+// K2+K3, the wave matcher (k_match_wq; default for d = 1, 2).
+// Full-width work stays full width — table 0 for all 256 reads (phase 1), table 1's primary slab for the first 64
+// listed reads, the decision pass — but everything that only a FEW reads of a tile need is NOT run as lane-per-read
+// batches (round 1's k_match_wave did: overflow slabs of tables 0/1, a second, mostly empty batch of listed reads,
+// table 2's 128-byte slabs and their chains — 64 % of that kernel's cycles for 23 % of the reads, because a batch
+// costs a full wave's instructions however few lanes have work).  Such work becomes ITEMS {listed read, table, slab}
+// on a stack in LDS that the wave drains sixteen at a time, one DPP quad per item: lane s fetches quarter s of the
+// slab (one L1 access), scans its two entries, a two-step DPP minimum gives the quad the slab's best key, lane 0
+// folds it into the read's running minimum with an LDS atomic, and a link in the slab's last slot becomes a new item.
+// Ties are resolved the same way (one quad per read, the best guide's neighbour list two entries per lane).  A read
+// reaches table 2 only when no guide within reach has a clean segment 0 or 1; the bucket's filter line
+// (SlabParams::flt) then turns away most of the reads that match nothing with one request instead of a slab chain.
 //   phase 1   table 0, every read; reads that are not settled are listed, their table-0 overflow link -> item
-//   phase 2   table 1 primary slab: first 64 listed reads as one batch (links -> items), further ones as items
-//   drain     tables 0/1 items; then the decision per listed read (hit / ties from neighbour lists / exact path /
-//             needs table 2), exactly as k_match_wave
-//   phase 3   table 2: candidates -> items (128/256-byte slabs: NQ2 pieces per lane), drain, decide
-//   phase 4   exact path for crowded neighbourhoods, coalesced result stores, tally records
+//   phase 2   table 1 primary slab: first 64 listed reads as one batch (links -> items), further ones as items;
+//             drain; decision per listed read: hit / tie list / candidate for table 2 -> filter -> item
+//   phase 3   table 2 items drained (128/256-byte slabs: NQ2 pieces per lane), decisions for the candidates;
+//             ties by quads; exact path (slab_slow) for guides with more than NBR_CAP close neighbours
+//   phase 4   coalesced result stores, tally records
+// Measured (1e8 reads, 1e5 guides, d <= 2): 1.14-1.17 ms against 1.27-1.29 ms for k_match_wave on the same boxes;
+// VALU 1420 wave-instructions per tile (was 1650), L2 requests 1.92 per read (was 2.07), 54 VGPRs.
+// Tried and dropped this round: two tiles per wave sharing one pass of the later phases (the full-width passes
+// scale with the listed reads, only partially filled item rounds amortise: -3 % VALU, and the bigger lists cost
+// occupancy: 1.27 ms); forcing 8 waves per SIMD (5 KiB of LDS, 1.17 ms: occupancy is not what limits it).
 // ---------------------------------------------------------------------------
 constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 64 drains first when fewer are free
 
@@ -2074,7 +1778,7 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     const double mu = (double)lib->G / nb;
     int log2S = (mu <= 7.0) ? 3 : 4;
     // tables 0 and 1 of the d = 1, 2 indexes keep 64-byte slabs up to ~16 guides per bucket: that is the geometry
-    // k_match_wave is built for (one quad-cooperative load per slab; fuller buckets chain).  Measured, 1e8 reads,
+    // k_match_wq is built for (one quad-cooperative load per slab; fuller buckets chain).  Measured, 1e8 reads,
     // d <= 2: G = 2e4 77 vs 57 G reads/s (quad kernels), 2e5 27 vs 23; at 1e6 (61 per bucket) the quad kernels win.
     if ((cs.nseg == 2 || cs.nseg == 3) && s < 2 && mu <= 16.0) log2S = 3;
     log2S = std::max(log2S, env_int("BC_SLAB_MIN_LOG2S", 3));
@@ -2514,14 +2218,8 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     const int nq2 = nseg == 3 ? (1 << (hp.t[2].log2S - 3)) : 1;
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_)                                                                         \
-    do {                                                                                                           \
-        if (lib->knobs.wave_list)                                                                                  \
-            hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
-                               lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o);                                                    \
-        else                                                                                                       \
-            hipLaunchKernelGGL((k_match_wave<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
-                               lib->k, lib->kmask, max_mm, o);                                                     \
-    } while (0)
+    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n,     \
+                       lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o)
 #define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false); } while (0)
                     if (nseg == 2) BC_WAVE_P(2, 1);
                     else if (nq2 == 1) BC_WAVE_P(3, 1);
@@ -2529,7 +2227,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     else BC_WAVE_P(3, 4);
 #undef BC_WAVE_P
 #undef BC_WAVE_LAUNCH
-                    note_kernel(lib, lib->knobs.wave_list ? "k_match_wq" : "k_match_wave");
+                    note_kernel(lib, "k_match_wq");
                     BC_HIP(hipGetLastError());
                     if (o.part.rec) { *part_done = true; *tail_begin = n; }
                     if (prof) {
@@ -2783,7 +2481,6 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->device = device; lib->G = n_guides; lib->k = k; lib->kmask = km;
     // experiment knobs: the environment is read here, once per library, never per launch
     lib->knobs.lane = env_int("BC_LANE", 1);
-    lib->knobs.wave_list = env_int("BC_WAVE_LIST", 1);
     lib->knobs.diag = env_int("BC_DIAG", 0);
     lib->knobs.phase2_sm = env_int("BC_PHASE2_SM", 1);
     lib->knobs.single_slab = env_int("BC_SINGLE_SLAB", 0);

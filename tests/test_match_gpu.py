@@ -42,7 +42,7 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
                                  {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4", "BC_SINGLE_SLAB": "1"},
                                  {"BC_SLAB_LOG2S": "3,3,3,3"}, {"BC_SLAB_LOG2S": "5,5,5,5"}, {"BC_SLAB_LOG2S": "4,3,5,4"},
                                  {"BC_SINGLE_SLAB": "1"}, {"BC_LANE": "0"}, {"BC_LANE": "0", "BC_PHASE2_SM": "0"},
-                                 {"BC_WAVE_LIST": "0"}, {"BC_T2_FILTER": "0"},
+                                 {"BC_T2_FILTER": "0"},
                                  {"BC_HASH_SLOTS_PCT": "120"}, {"BC_HASH_SLOTS_PCT": "3000"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
     """Tally by global atomics vs LDS histogram vs records, wave vs quad vs single
@@ -94,7 +94,7 @@ def _mutate(rng, codes, nsub):
 @pytest.mark.parametrize("slab", ["3,3,3", "3,3,4", "3,3,5"])
 @pytest.mark.parametrize("cluster", [0, 3, 12])
 def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, monkeypatch):
-    """The default d = 1, 2 kernel (k_match_wave) on every table-2 slab size, with libraries from isolated guides
+    """The default d = 1, 2 kernel (k_match_wq) on every table-2 slab size, with libraries from isolated guides
     to tight clusters: isolation flags, tie counting from neighbour lists (cluster = 3: lists of <= 8), the quad
     exact path (cluster = 12: more than 8 close neighbours), overflow chains, skip flags, a ragged last tile —
     against the oracle and against the quad kernels (BC_LANE=0)."""
@@ -125,17 +125,12 @@ def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, monkeypatch):
     dl = DeviceLibrary(lib, k, gpu_device)
     monkeypatch.setenv("BC_LANE", "0")  # knobs are read at creation: a second library for the quad kernels
     dq = DeviceLibrary(lib, k, gpu_device)
-    monkeypatch.setenv("BC_LANE", "1")
-    monkeypatch.setenv("BC_WAVE_LIST", "0")  # and a third for the previous wave kernel (lane-per-read batches)
-    dw = DeviceLibrary(lib, k, gpu_device)
     for d in (1, 2):
         ref = oracle.best_hit(lib_s, reads_s, d, skip=flags, base=3)
         _check(GpuMatcher(dl).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
         assert dl.last_kernel == "k_match_wq"
         _check(GpuMatcher(dq).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
         assert dq.last_kernel == "k_match_fused"
-        _check(GpuMatcher(dw).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
-        assert dw.last_kernel == "k_match_wave"
     if cluster:
         assert (ref["n_best"] > 1).sum() > 50
 
