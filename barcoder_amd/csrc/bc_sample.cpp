@@ -79,6 +79,28 @@ int next_chunk(bc_reader* r, uint64_t want, Chunk& c) {
     return BC_OK;
 }
 
+// rolling 2-bit value of the k-mer window at position i of a read (positions visited in ascending order)
+struct Roll {
+    int k;
+    uint64_t v = 0, mask;
+    size_t next = 0;   // first character not yet shifted in
+    int run = 0;       // ACGT characters in a row up to `next`
+    explicit Roll(int k_) : k(k_), mask(k_ >= 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull)) {}
+    static uint32_t hash(uint64_t v) { return (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 40); }  // 24 bits
+    // can the window [i, i + k) be a library entry?  (pure ACGT and its hash bit is set)
+    bool at(std::string_view s, size_t i, const std::vector<uint64_t>& bits) {
+        const size_t end = i + (size_t)k;
+        for (; next < end; ++next) {
+            const int c = base_code((unsigned char)s[next]);
+            if (c < 4) { v = ((v << 2) | (uint64_t)c) & mask; ++run; }
+            else { v = (v << 2) & mask; run = 0; }
+        }
+        if (run < k) return false;
+        const uint32_t h = hash(v);
+        return (bits[h >> 6] >> (h & 63)) & 1ull;
+    }
+};
+
 std::string revcomp_str(std::string_view s) {
     std::string o(s.size(), 'N');
     for (size_t i = 0; i < s.size(); ++i) {
@@ -117,6 +139,23 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     }
     for (uint32_t g = 0; g < G; ++g) { fwd.insert(fwd_store[g]); rev.insert(rev_store[g]); }
     const uint64_t n_lib = fwd.size();  // len(barcodes) of the SET (heuristicount.py:174-176)
+    // Pre-filter for the k-mer sweep (most windows of a read are no barcode): 2^24 bits set at a hash of the packed
+    // value of every library entry and reverse complement.  Only when every entry is pure upper-case ACGT and fits a
+    // 64-bit packing; otherwise the sweep asks the sets for every window, as the reference does.
+    bool prefilter = k <= 32;
+    for (uint32_t g = 0; g < G && prefilter; ++g)
+        for (int j = 0; j < k; ++j) prefilter = prefilter && base_code((unsigned char)fwd_store[g][j]) < 4;
+    std::vector<uint64_t> pf_bits;
+    if (prefilter) {
+        pf_bits.assign((1u << 24) / 64, 0);
+        for (uint32_t g = 0; g < G; ++g)
+            for (const std::string* sp : {&fwd_store[g], &rev_store[g]}) {
+                uint64_t v = 0;
+                for (int j = 0; j < k; ++j) v = (v << 2) | (uint64_t)base_code((unsigned char)(*sp)[j]);
+                const uint32_t h = Roll::hash(v);
+                pf_bits[h >> 6] |= 1ull << (h & 63);
+            }
+    }
     bc_reader *r1 = nullptr, *r2 = nullptr;
     int rc = bc_reader_open(file1, &r1);
     if (rc != BC_OK) return rc;
@@ -153,10 +192,14 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
             seen_reads.emplace(read1);
             if (paired) seen_reads.emplace(have2 ? std::string(read2) : std::string("\x01None"));
             if ((int64_t)read1.size() < k) continue;
+            Roll roll1(k), roll2(k);
             for (size_t i = 0; i + k <= read1.size(); ++i) {
                 const std::string_view kmer = read1.substr(i, k);
-                if (c_barcodes.count(kmer)) continue;
-                for (int lib = 0; lib < 2; ++lib)
+                // pre-filter: a window that cannot be a library entry (or its reverse complement) takes none of the
+                // set look-ups below — they would all miss (c_barcodes only ever holds k-mers found in a set)
+                const bool maybe1 = !prefilter || roll1.at(read1, i, pf_bits);
+                if (maybe1 && c_barcodes.count(kmer)) continue;
+                if (maybe1) for (int lib = 0; lib < 2; ++lib)
                     if ((lib == 0 ? fwd : rev).count(kmer)) {
                         div[0]++; c_barcodes.insert(kmer); observed.emplace(kmer);
                         c_or[0].push_back(lib); c_off[0].push_back((int64_t)i);
@@ -165,6 +208,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                     }
                 if (paired && have2) {
                     const std::string_view kmer2 = i < read2.size() ? read2.substr(i, k) : std::string_view();
+                    if (prefilter && (kmer2.size() != (size_t)k || !roll2.at(read2, i, pf_bits))) continue;  // same argument
                     if (c_barcodes.count(kmer2)) continue;
                     for (int lib = 0; lib < 2; ++lib)
                         if (kmer2.size() == (size_t)k && (lib == 0 ? fwd : rev).count(kmer2)) {
