@@ -66,6 +66,7 @@ struct SlabTable {
     uint32_t start, slen, half;   // seed position / length; half = k - slen
     uint32_t log2S;               // entries per slab (incl. the link entry)
     uint32_t empty;               // index of an all-empty slab appended after the overflow slabs
+    uint32_t wide;                // 1: 16-byte entries {rest lo plane, giw, rest hi plane, 0} (k - seed > 16 bases)
     uint32_t dmask[MAX_SEG];      // dmask[t]: seed t's bases in rest coordinates (t < this table)
 };
 // Neighbour lists: for a guide with another guide within NBR_RADIUS substitutions, the (at most NBR_CAP) guides
@@ -134,6 +135,7 @@ struct bc_lib {
     bc::SeedParams seed[bc::MAX_SEG];
     bc::SlabParams slab[bc::MAX_SEG] = {};
     bool slab_ok[bc::MAX_SEG] = {false, false, false, false};
+    bool slab_wide[bc::MAX_SEG] = {false, false, false, false};  // wide entries: only k_match_wq reads them
     const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
     bc::Knobs knobs;
     std::deque<bc::TallyWs> ws;    // tally workspaces by stream (deque: pointers stay valid as it grows)

@@ -955,6 +955,35 @@ __device__ __forceinline__ uint4 load16(const char* base, uint32_t off) {
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+// Two entry formats share the slab layout.  NARROW (k - seed <= 16 bases): 8-byte entries {rest, giw}, both planes of
+// the rest packed into one dword (hi plane << half); a 16-byte piece holds two.  WIDE (longer rests, k up to 32):
+// 16-byte entries {rest lo plane, giw, rest hi plane, 0}; a piece holds one.  In both the last slot of a slab is
+// link-or-empty and its first word is the next slab (0 = none).
+struct RestW { uint32_t lo, hi; };  // narrow: lo = the packed rest, hi unused
+template <bool WIDE>
+__device__ __forceinline__ RestW rest_of(uint32_t start, uint32_t sh, uint32_t half, uint32_t rlo, uint32_t rhi) {
+    const uint32_t below = (1u << start) - 1u;
+    if constexpr (WIDE) {
+        const uint32_t up_lo = sh >= 32u ? 0u : (rlo >> sh), up_hi = sh >= 32u ? 0u : (rhi >> sh);
+        return RestW{(rlo & below) | (up_lo << start), (rhi & below) | (up_hi << start)};
+    } else {
+        return RestW{((rlo & below) | ((rlo >> sh) << start)) | (((rhi & below) | ((rhi >> sh) << start)) << half), 0u};
+    }
+}
+// best key (distance << 24 | giw) among the entries of one 16-byte piece
+template <bool WIDE>
+__device__ __forceinline__ uint32_t piece_min(const uint4& w, uint32_t rl, uint32_t rh, uint32_t half, uint32_t hmask) {
+    if constexpr (WIDE) {
+        return ((uint32_t)__popc((rl ^ w.x) | (rh ^ w.z)) << 24) | w.y;
+    } else {
+        const uint32_t x0 = rl ^ w.x, x1 = rl ^ w.z;
+        const uint32_t d0 = __popc((x0 & hmask) | (x0 >> half)), d1 = __popc((x1 & hmask) | (x1 >> half));
+        return min((d0 << 24) | w.y, (d1 << 24) | w.w);
+    }
+}
+template <bool WIDE>
+__device__ __forceinline__ uint32_t link_word(const uint4& last_piece) { return WIDE ? last_piece.x : last_piece.z; }
+
 // request the slabs of the quad's four reads, NQ quarters per lane and read (1: 64-byte slabs, 2: 128, 4: 256).
 // off = byte offset of the slab wanted by the read this lane owns (FROM3: by read j, held in lane 3 as off4[j]).
 // A read that wants nothing is pointed at its table's all-empty slab: skipping the load instead (exec-masked
@@ -974,23 +1003,18 @@ __device__ __forceinline__ void visit_issue(const char* base, uint32_t off, cons
 
 // scan them: kmin = min(kmin, best key of the read this lane owns); l[j] = last slot's first word of read j's
 // slab as seen by this lane — in lane 3 that is the overflow link (0 = none: the slot is link-or-empty)
-template <int NQ>
-__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], uint32_t rest, uint32_t half, uint32_t hmask, int s,
+template <int NQ, bool WIDE = false>
+__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], RestW rest, uint32_t half, uint32_t hmask, int s,
                                            uint32_t& kmin, uint32_t (&l)[4]) {
     uint32_t a[4];
     auto one = [&](auto jt) {
         constexpr int j = decltype(jt)::value;
-        const uint32_t rj = quad_bcast<j>(rest);
+        const uint32_t rl = quad_bcast<j>(rest.lo), rh = WIDE ? quad_bcast<j>(rest.hi) : 0u;
         uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-        for (int h = 0; h < NQ; ++h) {
-            const uint32_t x0 = rj ^ w[j][h].x, x1 = rj ^ w[j][h].z;
-            const uint32_t d0 = __popc((x0 & hmask) | (x0 >> half));
-            const uint32_t d1 = __popc((x1 & hmask) | (x1 >> half));
-            m = min(m, min((d0 << 24) | w[j][h].y, (d1 << 24) | w[j][h].w));
-        }
+        for (int h = 0; h < NQ; ++h) m = min(m, piece_min<WIDE>(w[j][h], rl, rh, half, hmask));
         a[j] = m;
-        l[j] = w[j][NQ - 1].z;
+        l[j] = link_word<WIDE>(w[j][NQ - 1]);
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
@@ -1030,6 +1054,51 @@ __device__ unsigned long long g_phase_cycles[8];  // BC_PHASE_PROF=1: summed cyc
 // for every outstanding global load and store
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// exact evaluation of one read by one DPP quad over every table of a WIDE index (chains followed, candidates met
+// through an earlier seed skipped, counts per distance): the definition of the result, for the rare read whose
+// best guide has more close neighbours than a neighbour list holds
+template <int NSEG>
+__device__ __forceinline__ void slab_slow_wide(const SlabParams& sp, uint32_t rlo, uint32_t rhi, uint32_t max_mm, int s,
+                                               uint32_t& key_out, uint32_t& nb_out) {
+    uint32_t key = 0xFFFFFFFFu, cur = max_mm;
+    uint64_t cnt = 0;  // candidates per distance, 16-bit fields
+    for (int t = 0; t < NSEG; ++t) {
+        const SlabTable& T = sp.t[t];
+        const RestW rest = rest_of<true>(T.start, T.start + T.slen, T.half, rlo, rhi);
+        const char* base = reinterpret_cast<const char*>(T.slabs);
+        const uint32_t bytes_log2 = T.log2S + 4u, pieces = 1u << (T.log2S - 2u);  // 16-byte entries, pieces per lane
+        uint32_t slab = seed_value(rlo, rhi, T.start, T.slen);
+        while (slab != 0xFFFFFFFFu) {
+            uint32_t next = 0;
+            for (uint32_t h = 0; h < pieces; ++h) {
+                const uint4 w = load16(base, (slab << bytes_log2) + (uint32_t)(s + 4 * h) * 16u);
+                const uint32_t mm = (rest.lo ^ w.x) | (rest.hi ^ w.z);
+                const uint32_t d = __popc(mm);
+                bool ok = d <= cur && w.y < SLAB_LINK;
+                for (int u = 0; u < t; ++u) ok = ok && (mm & T.dmask[u]) != 0u;  // not met through an earlier seed
+                if (ok) {
+                    key = min(key, (d << 24) | (w.y & SLAB_GIDX_MASK));
+                    cur = d;
+                    cnt += 1ull << (16 * d);
+                }
+                if (h == pieces - 1u) next = w.x;
+            }
+            next = quad_bcast<3>(next);  // lane 3's last piece is the slab's link-or-empty slot
+            slab = next ? next : 0xFFFFFFFFu;
+        }
+        cur = min(cur, quad_perm<0xB1>(cur));
+        cur = min(cur, quad_perm<0x4E>(cur));
+    }
+    key = min(key, quad_perm<0xB1>(key));
+    key = min(key, quad_perm<0x4E>(key));
+    const uint32_t md = key >> 24;
+    uint32_t mine = md <= 3u ? (uint32_t)((cnt >> (16 * (md & 3u))) & 0xFFFFu) : 0u;
+    mine += quad_perm<0xB1>(mine);
+    mine += quad_perm<0x4E>(mine);
+    key_out = key;
+    nb_out = mine;
+}
+
 // ---------------------------------------------------------------------------
 // K2+K3, the wave matcher (k_match_wq; default for d = 1, 2).
 // Full-width work stays full width — table 0 for all 256 reads (phase 1), table 1's primary slab for the first 64
@@ -1057,12 +1126,14 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // ---------------------------------------------------------------------------
 constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 64 drains first when fewer are free
 
-template <int NSEG, int NQ2, bool PROF>
+template <int NSEG, int NQ2, bool PROF, bool WIDE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wq(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,
                                                    const uint8_t* __restrict__ flags, uint64_t n, int k,
                                                    uint64_t kmask, int max_mm_, MatchOut o_arg) {
     static_assert(NSEG == 2 || NSEG == 3, "wave kernel: d = 1 or 2");
+    constexpr int NQ01 = WIDE ? 2 : 1;           // 16-byte pieces per lane of a table-0/1 slab (8 entries: 64 / 128 bytes)
+    constexpr uint32_t S01 = WIDE ? 7u : 6u;     // log2 of that slab's bytes
     (void)o_arg;  // read from the kernel-argument segment in the last phase, see there
     __shared__ uint64_t q_read[WAVE_T];                                 // listed read; later its result
     __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];     // its best key so far (LDS atomic min)
@@ -1084,9 +1155,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     const char* const b2 = reinterpret_cast<const char*>(T2.slabs);
     const uint32_t lane = threadIdx.x;
     const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
-    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;
-    const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u, sh2 = T2.log2S + 3u;
-    const uint32_t empty0 = T0.empty << 6, empty1 = T1.empty << 6, empty2 = T2.empty << sh2;  // what idle lanes fetch
+    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;  // (the masks are not used by the wide format)
+    const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u, sh2 = T2.log2S + (WIDE ? 4u : 3u);
+    const uint32_t empty0 = T0.empty << S01, empty1 = T1.empty << S01, empty2 = T2.empty << sh2;  // what idle lanes fetch
     const int s = (int)(lane & 3u);
     const uint32_t none4[4] = {0u, 0u, 0u, 0u};
     unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull, t_acc[4] = {0ull, 0ull, 0ull, 0ull};
@@ -1124,20 +1195,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const bool t1 = (item & 0x100u) != 0u;
             const uint64_t r = q_read[qi];
             const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
-            // slab_rest with the table picked per lane
+            // the rest of the read with the table picked per lane
             const uint32_t st = t1 ? T1.start : T0.start, sh = t1 ? T1.start + T1.slen : T0.start + T0.slen;
             const uint32_t hf = t1 ? half1 : half0, hm = t1 ? hm1 : hm0;
-            const uint32_t below = (1u << st) - 1u;
-            const uint32_t rest = ((rlo & below) | ((rlo >> sh) << st)) | (((rhi & below) | ((rhi >> sh) << st)) << hf);
+            const RestW rest = rest_of<WIDE>(st, sh, hf, rlo, rhi);
             const char* base = t1 ? b1 : b0;
-            const uint32_t off = act ? (slab << 6) : empty0;
-            const uint4 w = load16(base, off + (uint32_t)s * 16u);
-            const uint32_t x0 = rest ^ w.x, x1 = rest ^ w.z;
-            const uint32_t d0 = __popc((x0 & hm) | (x0 >> hf)), d1 = __popc((x1 & hm) | (x1 >> hf));
-            uint32_t m = min((d0 << 24) | w.y, (d1 << 24) | w.w);
+            const uint32_t off = act ? (slab << S01) : empty0;
+            uint4 w[NQ01];
+#pragma unroll
+            for (int h = 0; h < NQ01; ++h) w[h] = load16(base, off + (uint32_t)(s + 4 * h) * 16u);
+            uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+            for (int h = 0; h < NQ01; ++h) m = min(m, piece_min<WIDE>(w[h], rest.lo, rest.hi, hf, hm));
             m = min(m, quad_perm<0xB1>(m));
             m = min(m, quad_perm<0x4E>(m));
-            const uint32_t lnk = quad_bcast<3>(w.z);  // the slab's last slot: link or empty (0)
+            const uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ01 - 1]));  // the slab's last slot: link or empty (0)
             const bool lead = act && s == 0;
             if (lead) atomicMin(&q_key[qi], m);
             push_items(lead && lnk != 0u, (item & 0x3FFu) | (lnk << 10));
@@ -1156,21 +1228,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const uint32_t item = act ? wl[wn + q] : 0u;
             const uint32_t qi = item & 255u, slab = item >> 10;
             const uint64_t r = q_read[qi];
-            const uint32_t rest = slab_rest(T2, (uint32_t)r, (uint32_t)(r >> 32));
+            const RestW rest = rest_of<WIDE>(T2.start, T2.start + T2.slen, half2, (uint32_t)r, (uint32_t)(r >> 32));
             const uint32_t off = act ? (slab << sh2) : empty2;
             uint4 w[NQ2];
 #pragma unroll
             for (int h = 0; h < NQ2; ++h) w[h] = load16(b2, off + (uint32_t)(s + 4 * h) * 16u);
             uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-            for (int h = 0; h < NQ2; ++h) {
-                const uint32_t x0 = rest ^ w[h].x, x1 = rest ^ w[h].z;
-                const uint32_t d0 = __popc((x0 & hm2) | (x0 >> half2)), d1 = __popc((x1 & hm2) | (x1 >> half2));
-                m = min(m, min((d0 << 24) | w[h].y, (d1 << 24) | w[h].w));
-            }
+            for (int h = 0; h < NQ2; ++h) m = min(m, piece_min<WIDE>(w[h], rest.lo, rest.hi, half2, hm2));
             m = min(m, quad_perm<0xB1>(m));
             m = min(m, quad_perm<0x4E>(m));
-            const uint32_t lnk = quad_bcast<3>(w[NQ2 - 1].z);
+            const uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ2 - 1]));
             const bool lead = act && s == 0;
             if (lead) atomicMin(&q_key[qi], m);
             push_items(lead && lnk != 0u, (item & 0x3FFu) | (lnk << 10));
@@ -1215,10 +1283,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             r[j] &= kmask;
         }
         // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
-        auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << 6) : 0u; };
-        auto finish = [&](int j, const uint4 (&w)[4][1]) {
+        auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << S01) : 0u; };
+        auto finish = [&](int j, const uint4 (&w)[4][NQ01]) {
             uint32_t l[4], key = 0xFFFFFFFFu;
-            visit_scan<1>(w, slab_rest(T0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), half0, hm0, s, key, l);
+            visit_scan<NQ01, WIDE>(w, rest_of<WIDE>(T0.start, T0.start + T0.slen, half0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)),
+                                   half0, hm0, s, key, l);
             const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
             const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner's overflow link
             const uint32_t d = key >> 24;
@@ -1235,15 +1304,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             qn += (uint32_t)__popcll(m);
             push_items(push && lnk != 0u, at[j] | (lnk << 10));  // table 0 item
         };
-        uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
-        visit_issue<1, false>(b0, off0(0), none4, s, wa);
-        visit_issue<1, false>(b0, off0(1), none4, s, wb);
-        finish(0, wa);
-        visit_issue<1, false>(b0, off0(2), none4, s, wa);
-        finish(1, wb);
-        visit_issue<1, false>(b0, off0(3), none4, s, wb);
-        finish(2, wa);
-        finish(3, wb);  // at most 256 table-0 items: WL_CAP holds them
+        if constexpr (!WIDE) {
+            uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
+            visit_issue<1, false>(b0, off0(0), none4, s, wa);
+            visit_issue<1, false>(b0, off0(1), none4, s, wb);
+            finish(0, wa);
+            visit_issue<1, false>(b0, off0(2), none4, s, wa);
+            finish(1, wb);
+            visit_issue<1, false>(b0, off0(3), none4, s, wb);
+            finish(2, wa);
+            finish(3, wb);  // at most 256 table-0 items: WL_CAP holds them
+        } else {
+            uint4 wa[4][2];  // 128-byte slabs: one round in flight (two would take 64 registers)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                visit_issue<2, false>(b0, off0(j), none4, s, wa);
+                finish(j, wa);
+            }
+        }
     }
     wave_lds_sync();
     phase_mark(0);
@@ -1253,18 +1331,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         if (wn > WL_CAP - 64) drain01();
         const uint32_t qi = lane;
         const bool mine = qi < qn;
-        uint32_t kmin = 0xFFFFFFFFu, rest1 = 0, off1 = empty1;
+        uint32_t kmin = 0xFFFFFFFFu, off1 = empty1;
+        RestW rest1{0u, 0u};
         if (mine) {
             const uint64_t r = q_read[qi];
             const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
             kmin = q_key[qi];
-            rest1 = slab_rest(T1, rlo, rhi);
-            off1 = seed_value(rlo, rhi, T1.start, T1.slen) << 6;
+            rest1 = rest_of<WIDE>(T1.start, T1.start + T1.slen, half1, rlo, rhi);
+            off1 = seed_value(rlo, rhi, T1.start, T1.slen) << S01;
         }
-        uint4 wa[4][1];
+        uint4 wa[4][NQ01];
         uint32_t l1[4];
-        visit_issue<1, false>(b1, off1, none4, s, wa);
-        visit_scan<1>(wa, rest1, half1, hm1, s, kmin, l1);
+        visit_issue<NQ01, false>(b1, off1, none4, s, wa);
+        visit_scan<NQ01, WIDE>(wa, rest1, half1, hm1, s, kmin, l1);
         const uint32_t t0 = quad_bcast<3>(l1[0]), t1 = quad_bcast<3>(l1[1]), t2 = quad_bcast<3>(l1[2]), t3 = quad_bcast<3>(l1[3]);
         const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;
         if (mine) q_key[qi] = kmin;
@@ -1377,7 +1456,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const uint32_t qi = l_slow[si];
             const uint64_t r = q_read[qi];
             uint32_t key, nb;
-            slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), (int)max_mm, s, last_lane, key, nb);
+            if constexpr (WIDE) slab_slow_wide<NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), max_mm, s, key, nb);
+            else slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), (int)max_mm, s, last_lane, key, nb);
             if (s == 0) {
                 if ((key >> 24) <= max_mm) put(qi, key & SLAB_GIDX_MASK, key >> 24, nb);
                 else put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
@@ -1769,15 +1849,23 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     SlabParams& sl = lib->slab[d];
     if (s == 0) { sl.nseg = cs.nseg; lib->slab_ok[d] = true; }
     const int start = cs.start[s], slen = cs.slen[s], half = lib->k - slen;
-    if (2 * half > 32 || lib->G >= (1u << SLAB_GIDX_BITS)) { lib->slab_ok[d] = false; return BC_OK; }  // rest: one dword (two planes of `half` bits); index: 22 bits + 2 flags
+    // rest in one dword (two planes of `half` bits: narrow entries) or in two (wide entries, k up to 32); index: 22 bits + 2 flags.
+    // All tables of an index use one format: the widest rest decides.
+    if (lib->G >= (1u << SLAB_GIDX_BITS)) { lib->slab_ok[d] = false; return BC_OK; }
+    if (s == 0) {
+        bool wide = false;
+        for (int t = 0; t < cs.nseg; ++t) wide = wide || 2 * (lib->k - cs.slen[t]) > 32;
+        lib->slab_wide[d] = wide;
+    }
+    const bool wide = lib->slab_wide[d];
     if (!lib->slab_ok[d]) return BC_OK;
     const uint32_t nb = 1u << (2 * slen);
-    // slab size: 64-byte slabs (7 entries + link) while the mean bucket fits, else 128-byte slabs and
+    // slab size: 8 entries (7 + link: 64 bytes narrow, 128 wide) while the mean bucket fits, else 16 and
     // chaining.  Measured on MI355X (G=1e5, k=20, d<=2): sizes (8,8,16) 3.04 ms per 1e8 reads vs
     // (16,16,32) 3.13 ms — short chained slabs beat long ones (smaller tables, fewer bytes per visit).
     const double mu = (double)lib->G / nb;
     int log2S = (mu <= 7.0) ? 3 : 4;
-    // tables 0 and 1 of the d = 1, 2 indexes keep 64-byte slabs up to ~16 guides per bucket: that is the geometry
+    // tables 0 and 1 of the d = 1, 2 indexes keep 8-entry slabs up to ~16 guides per bucket: that is the geometry
     // k_match_wq is built for (one quad-cooperative load per slab; fuller buckets chain).  Measured, 1e8 reads,
     // d <= 2: G = 2e4 77 vs 57 G reads/s (quad kernels), 2e5 27 vs 23; at 1e6 (61 per bucket) the quad kernels win.
     if ((cs.nseg == 2 || cs.nseg == 3) && s < 2 && mu <= 16.0) log2S = 3;
@@ -1788,25 +1876,43 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
         int nv = sscanf(spec, "%d,%d,%d,%d", &vals[0], &vals[1], &vals[2], &vals[3]);
         if (s < nv && vals[s] >= 3 && vals[s] <= SLAB_MAX_LOG2S) log2S = vals[s];
     }
+    if (wide) log2S = std::min(log2S, 4);  // 16-byte entries: at most 256-byte slabs (four pieces per lane)
     const uint32_t S = 1u << log2S;
-    std::vector<uint2> slabs((size_t)nb << log2S, make_uint2(0u, SLAB_EMPTY));
+    const uint32_t W = wide ? 2u : 1u;  // uint2 words per entry
+    // entries as uint2 words: narrow {rest, giw}; wide {rest lo, giw}{rest hi, 0}
+    std::vector<uint2> slabs(((size_t)nb << log2S) * W, make_uint2(0u, SLAB_EMPTY));
+    if (wide)
+        for (size_t e = 0; e < ((size_t)nb << log2S); ++e) slabs[e * 2 + 1] = make_uint2(0u, 0u);
     const uint32_t below = (1u << start) - 1u;
     const int sh = start + slen;
-    auto rest_of = [&](uint64_t g) {
-        uint32_t lo = (uint32_t)g, hi = (uint32_t)(g >> 32);
-        uint32_t lo_r = (lo & below) | ((sh >= 32 ? 0u : (lo >> sh)) << start);
-        uint32_t hi_r = (hi & below) | ((sh >= 32 ? 0u : (hi >> sh)) << start);
-        return lo_r | (half >= 32 ? 0u : (hi_r << half));
+    auto put_entry = [&](size_t slot, uint64_t g, uint32_t giw, bool link, uint32_t next) {
+        const uint32_t lo = (uint32_t)g, hi = (uint32_t)(g >> 32);
+        const uint32_t lo_r = (lo & below) | ((sh >= 32 ? 0u : (lo >> sh)) << start);
+        const uint32_t hi_r = (hi & below) | ((sh >= 32 ? 0u : (hi >> sh)) << start);
+        if (link) {
+            slabs[slot * W] = make_uint2(next, SLAB_LINK);
+            if (wide) slabs[slot * W + 1] = make_uint2(0u, 0u);
+        } else if (wide) {
+            slabs[slot * 2] = make_uint2(lo_r, giw);
+            slabs[slot * 2 + 1] = make_uint2(hi_r, 0u);
+        } else {
+            slabs[slot] = make_uint2(lo_r | (half >= 32 ? 0u : (hi_r << half)), giw);
+        }
+    };
+    auto append_slab = [&]() {
+        const size_t idx = slabs.size() / W >> log2S;
+        slabs.resize(slabs.size() + (size_t)S * W, make_uint2(0u, SLAB_EMPTY));
+        if (wide)
+            for (uint32_t e = 0; e < S; ++e) slabs[(idx << log2S) * 2 + (size_t)e * 2 + 1] = make_uint2(0u, 0u);
+        return idx;
     };
     for (uint32_t b = 0; b < nb; ++b) {
         size_t cur = b;
         uint32_t pos = 0;
         for (uint32_t j = off[b]; j < off[b + 1]; ++j) {
             if (pos == S - 1) {  // chain an overflow slab
-                size_t nxt = slabs.size() >> log2S;
-                if (nxt >= 0xFFFFFFFEull) { set_error("slab index overflow"); return BC_EINVAL; }
-                slabs.resize(slabs.size() + S, make_uint2(0u, SLAB_EMPTY));
-                slabs[(cur << log2S) + S - 1] = make_uint2((uint32_t)nxt, SLAB_LINK);
+                const size_t nxt = append_slab();
+                put_entry((cur << log2S) + S - 1, 0, 0, true, (uint32_t)nxt);
                 cur = nxt;
                 pos = 0;
             }
@@ -1817,17 +1923,17 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
                 if (nn > 2 * d) fl |= SLAB_F_ISO;
                 if (nn > 2 * (d - 1)) fl |= SLAB_F_ISO1;
             }
-            slabs[(cur << log2S) + pos++] = make_uint2(rest_of(keys[j]), gidx[j] | fl);
+            put_entry((cur << log2S) + pos++, keys[j], gidx[j] | fl, false, 0);
         }
     }
-    const uint32_t empty_slab = (uint32_t)(slabs.size() >> log2S);
-    slabs.resize(slabs.size() + S, make_uint2(0u, SLAB_EMPTY));
+    const uint32_t empty_slab = (uint32_t)append_slab();
     if ((slabs.size() * sizeof(uint2)) >> 32) { lib->slab_ok[d] = false; return BC_OK; }  // 32-bit byte offsets
     uint2* d_slabs;
     int rc = dev_upload(lib, slabs, &d_slabs);
     if (rc != BC_OK) return rc;
     SlabTable& T = sl.t[s];
     T.empty = empty_slab;
+    T.wide = wide ? 1u : 0u;
     T.slabs = d_slabs; T.start = (uint32_t)start; T.slen = (uint32_t)slen; T.half = (uint32_t)half;
     T.log2S = (uint32_t)log2S;
     for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
@@ -2198,33 +2304,44 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
             set_error("bc_match: the seed index supports 0 <= max_mismatch <= %d", MAX_SEG - 1);
             return BC_EINVAL;
         }
-        if (algo == BC_ALGO_SEED && lib->slab_ok[max_mm]) {
+        // the slab form serves k_match_wq (narrow and wide entries) and, narrow only, the quad / single slab kernels
+        const SlabParams& hp = lib->slab[max_mm];
+        const int nseg = hp.nseg;
+        const bool wide = lib->slab_wide[max_mm];
+        const bool vec_ok = aligned16(d_reads) && aligned16(o.best_idx) && n >= 4 &&
+                            (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
+                            (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
+        bool wave_ok = algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && max_mm >= 1 && vec_ok && !lib->knobs.single_slab &&
+                       lib->knobs.lane && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 && hp.t[1].log2S == 3 &&
+                       !lib->h_nn.empty();
+        for (int t = 0; t < nseg && wave_ok; ++t) wave_ok = hp.t[t].empty < (1u << 22);  // slab numbers travel in 22-bit item fields
+        if (wave_ok && nseg == 3 && wide && hp.t[2].log2S > 4) wave_ok = false;
+        if (algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && (!wide || wave_ok)) {
             uint32_t minS = 1u << SLAB_MAX_LOG2S;
-            for (int s = 0; s < lib->slab[max_mm].nseg; ++s) minS = std::min(minS, 1u << lib->slab[max_mm].t[s].log2S);
+            for (int s = 0; s < nseg; ++s) minS = std::min(minS, 1u << hp.t[s].log2S);
             const SlabParams* dp = lib->d_slab[max_mm];
             const bool l8 = (lib->knobs.slab_lpr == 8 && minS >= 16);
-            const int nseg = lib->slab[max_mm].nseg;
-            const bool vec_ok = aligned16(d_reads) && aligned16(o.best_idx) && n >= 4 &&
-                                (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
-                                (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
             if (max_mm >= 1 && vec_ok && !lib->knobs.single_slab) {
-                const SlabParams& hp = lib->slab[max_mm];
                 // default: the wave kernel (lane-owned reads, quad-cooperative loads, no hash table);
                 // BC_LANE=0 selects the quad kernels
-                const bool wave_ok = lib->knobs.lane && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 &&
-                                     hp.t[1].log2S == 3 && !lib->h_nn.empty();
                 if (wave_ok) {
                     const bool prof = lib->knobs.phase_prof != 0;  // tuning aid: per-stage cycle sums on stderr
-                    const int nq2 = nseg == 3 ? (1 << (hp.t[2].log2S - 3)) : 1;
+                    const int nq2 = nseg == 3 ? ((wide ? 2 : 1) << (hp.t[2].log2S - 3)) : 1;  // 16-byte pieces per lane
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
-#define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_)                                                                         \
-    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n,     \
+#define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_)                                                                  \
+    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o)
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false); } while (0)
-                    if (nseg == 2) BC_WAVE_P(2, 1);
-                    else if (nq2 == 1) BC_WAVE_P(3, 1);
-                    else if (nq2 == 2) BC_WAVE_P(3, 2);
-                    else BC_WAVE_P(3, 4);
+#define BC_WAVE_P(NSEG_, NQ2_, WIDE_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, WIDE_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, WIDE_); } while (0)
+                    if (!wide) {
+                        if (nseg == 2) BC_WAVE_P(2, 1, false);
+                        else if (nq2 == 1) BC_WAVE_P(3, 1, false);
+                        else if (nq2 == 2) BC_WAVE_P(3, 2, false);
+                        else BC_WAVE_P(3, 4, false);
+                    } else {
+                        if (nseg == 2) BC_WAVE_P(2, 2, true);
+                        else if (nq2 == 2) BC_WAVE_P(3, 2, true);
+                        else BC_WAVE_P(3, 4, true);
+                    }
 #undef BC_WAVE_P
 #undef BC_WAVE_LAUNCH
                     note_kernel(lib, "k_match_wq");
@@ -2235,7 +2352,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                         BC_HIP(hipStreamSynchronize(st));
                         BC_HIP(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_phase_cycles), sizeof(c)));
                         BC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
-                        fprintf(stderr, "match stages (cycles/wave): 1 %.0f  2a %.0f  2b %.0f  2c+3 %.0f  waves %llu\n",
+                        fprintf(stderr, "match stages (cycles/wave): 1 %.0f  2 %.0f  3 %.0f  4 %.0f  waves %llu\n",
                                 (double)c[0] / c[7], (double)c[1] / c[7], (double)c[2] / c[7], (double)c[3] / c[7], c[7]);
                     }
                     return BC_OK;

@@ -36,6 +36,11 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
     ref = oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads & E.kmer_mask(k), k), max_mm, skip=flags, base=5)
     _check(res, ref)
     assert (res.best_idx >= 0).sum() > n // 2
+    if algo == "seed":  # which kernel took it: the wave matcher for d = 1, 2 at every k (wide entries for k = 32)
+        wide = k == 32
+        want = {0: "k_match_seed" if wide else "k_match_slab", 1: "k_match_wq", 2: "k_match_wq",
+                3: "k_match_seed" if wide else "k_match_fused"}[max_mm]
+        assert dl.last_kernel == want, (k, max_mm, dl.last_kernel)
 
 
 @pytest.mark.parametrize("env", [{"BC_TALLY": "1"}, {"BC_TALLY": "2"}, {"BC_TALLY": "3"},
@@ -91,14 +96,16 @@ def _mutate(rng, codes, nsub):
     return out
 
 
+@pytest.mark.parametrize("k", [20, 32])
 @pytest.mark.parametrize("slab", ["3,3,3", "3,3,4", "3,3,5"])
 @pytest.mark.parametrize("cluster", [0, 3, 12])
-def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, monkeypatch):
+def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, k, monkeypatch):
     """The default d = 1, 2 kernel (k_match_wq) on every table-2 slab size, with libraries from isolated guides
     to tight clusters: isolation flags, tie counting from neighbour lists (cluster = 3: lists of <= 8), the quad
     exact path (cluster = 12: more than 8 close neighbours), overflow chains, skip flags, a ragged last tile —
-    against the oracle and against the quad kernels (BC_LANE=0)."""
-    k, n = 20, 10007
+    against the oracle and against the quad kernels (BC_LANE=0).  k = 32: the wide entry format (two-dword rests,
+    128-byte slabs for tables 0/1, the quad exact path slab_slow_wide); BC_LANE=0 then leaves only the CSR kernel."""
+    n = 10007
     rng = np.random.default_rng(17 + cluster)
     if cluster:
         centres = rng.integers(0, 4, size=(400, k))
@@ -130,12 +137,13 @@ def test_wave_kernel_paths(gpu_device, oracle, slab, cluster, monkeypatch):
         _check(GpuMatcher(dl).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
         assert dl.last_kernel == "k_match_wq"
         _check(GpuMatcher(dq).match(reads, flags, max_mismatch=d, algo="seed", first_index=3), ref)
-        assert dq.last_kernel == "k_match_fused"
+        assert dq.last_kernel == ("k_match_fused" if k == 20 else "k_match_seed")
     if cluster:
         assert (ref["n_best"] > 1).sum() > 50
 
 
-@pytest.mark.parametrize("k,G", [(12, 5000), (16, 20000), (18, 60000), (20, 20000), (20, 150000), (22, 60000)])
+@pytest.mark.parametrize("k,G", [(12, 5000), (16, 20000), (18, 60000), (20, 20000), (20, 150000), (22, 60000),
+                                 (24, 60000), (28, 30000), (32, 9503), (32, 100000)])
 def test_wave_kernel_geometries_at_scale(gpu_device, oracle, k, G):
     """Default d = 1, 2 path over k-mer lengths and library sizes (different seed / rest widths, bucket loads from
     1 to 16 per slab, neighbour densities from none to dense), 300 k reads each, every per-read output against the
@@ -156,6 +164,9 @@ def test_wave_kernel_geometries_at_scale(gpu_device, oracle, k, G):
         res = GpuMatcher(dl).match(reads, None, max_mismatch=d, algo="seed", first_index=0)
         ref = oracle.best_hit_arrays(la, ra, d, indexed=True)
         _check(res, ref)
+        # short k-mers have short segments: their seeds stop at the segment's length and the buckets outgrow the wave
+        # kernel's 8-entry slabs (more than 16 guides per bucket) -> quad kernels; everything else: the wave matcher
+        assert dl.last_kernel == ("k_match_fused" if (k, d) in ((12, 1), (12, 2), (16, 2)) else "k_match_wq"), (k, d, dl.last_kernel)
 
 
 def test_tally_hot_guides(gpu_device):
