@@ -209,12 +209,14 @@ def secondary_workloads(torch, dev, local, stream, lib_packed, matcher, n, steps
 
 
 def main():
+    global K
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=float, default=1e8, help="reads per GPU")
     ap.add_argument("--guides", type=int, default=G)
+    ap.add_argument("--k", type=int, default=K, help="k-mer length (default 20: BASELINE configs[2]; 32 = the shipped CN-32 geometry)")
     ap.add_argument("--algo", default="seed", choices=["seed", "seed_csr", "brute", "hash", "auto"])
     ap.add_argument("--max-mismatch", type=int, default=MAX_MM)
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = ~15 s worth)")
@@ -228,6 +230,7 @@ def main():
         launcher = _dist_module_without_package()
         raise SystemExit(launcher.launch_workers([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
+    K = args.k
     from barcoder_amd import dist as D
     with D.stdout_to_stderr():  # stdout carries the one JSON line and nothing else (gloo prints to fd 1)
         line = run(args)
@@ -330,8 +333,8 @@ def run(args):
             "dtype": "u64", "data": "synthetic",
             "value_median": world * n / (med_ms * 1e-3) / 1e6,
             "ms_per_step_median": med_ms,
-            "config": {"workload": f"20-mer <={args.max_mismatch}-mismatch best hit, {Gn}-guide library, "
-                                   f"{n} reads per GPU (BASELINE configs[2])",
+            "config": {"workload": f"{K}-mer <={args.max_mismatch}-mismatch best hit, {Gn}-guide library, "
+                                   f"{n} reads per GPU" + (" (BASELINE configs[2])" if (K, args.max_mismatch, Gn) == (20, 2, 100_000) else ""),
                        "algo": args.algo, "reads_per_gpu": n, "guides": Gn, "k": K,
                        "max_mismatch": args.max_mismatch, "matched_fraction": matched / n,
                        "job_matched_reads": total_hits,
@@ -340,9 +343,7 @@ def run(args):
                                       + (f" ({backend})" if backend else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": {"seed": "k_match_wave (table 0 = exact stage, tables 1-2 on compacted lists)",
-                                    "seed_csr": "k_match_seed", "brute": "k_match_brute", "hash": "k_match_hash",
-                                    "auto": "k_match_wave"}[args.algo],
+                         "kernel": dl.last_kernel,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_read": ALGO_BYTES,
                          "frac_of_measured_copy_peak": achieved / 6290.0,
                          "pass_ms": pass_ms, "pass": "matcher + tally (per-guide counts and first-seen)",

@@ -4,12 +4,13 @@ profiles/traffic.json (read by bench.py for roofline.traffic).
 
 Corrections (MI355X_MICROARCH.md, section HBM): on gfx950 FETCH_SIZE reports half
 the bytes of a 16-byte-per-lane coalesced streaming read, WRITE_SIZE is exact.
-k_hist (and the stand-alone k_match_hash) stream their input with 16-byte-per-lane
-loads, so their FETCH_SIZE is doubled (calibration on known byte counts: k_match_hash
-raw 436 MB for an 800 MB read array, k_hist raw 1.0 GB for 5 x 400 MB).
-k_match_wave / k_match_fused / k_match_slabq mix the 16-byte-per-lane read stream
-(8 B per read, counted at half: + 4 B per read added back) with table pieces served
-from L2 / Infinity Cache (FETCH_SIZE counts Infinity-Cache hits as fetches).
+k_hist / k_hist_part (and the stand-alone k_match_hash) stream their input with
+16-byte-per-lane loads, so their FETCH_SIZE is doubled (calibration on known byte
+counts: k_match_hash raw 436 MB for an 800 MB read array, k_hist raw 1.0 GB for
+5 x 400 MB).  k_match_wq / k_match_fused mix the 16-byte-per-lane read stream (8 B
+per read, counted at half: + 4 B per read added back) with table pieces served from
+L2 / Infinity Cache (FETCH_SIZE counts Infinity-Cache hits as fetches).
+k_first_refine reads 4-byte words (uncalibrated width: taken as counted).
 usage: python profiles/collect_traffic.py profiles/r01_rocprof_summary.json reads algo max_mm
 """
 import json, sys
@@ -17,12 +18,15 @@ src, reads, algo, mm = sys.argv[1], int(float(sys.argv[2])), sys.argv[3], int(sy
 d = json.load(open(src))["pmc"]
 rows, total = {}, 0.0
 for name, e in d.items():
-    if not name.startswith(("k_match", "k_hist")):
+    if not name.startswith(("k_match", "k_hist", "k_first_refine")):
         continue
     f = e.get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0) * 1024
-    w = e.get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0) * 1024
+    # the matcher runs with and without the tally in one bench invocation (kernel-only timing launches write no
+    # records): the launches of a counting pass are the larger ones
+    ws = e.get("WRITE_SIZE", {})
+    w = ws.get("max_per_dispatch", ws.get("mean_per_dispatch", 0.0)) * 1024
     corr = 2.0 if name.startswith(("k_match_hash", "k_hist")) else 1.0
-    add = 4.0 * reads if name.startswith(("k_match_wave", "k_match_fused", "k_match_slabq")) else 0.0
+    add = 4.0 * reads if name.startswith(("k_match_wq", "k_match_wave", "k_match_fused")) else 0.0
     rows[name] = {"fetch_raw_bytes": f, "fetch_correction": corr, "fetch_added_bytes": add, "write_bytes": w,
                   "hbm_bytes": f * corr + add + w}
     total += f * corr + add + w

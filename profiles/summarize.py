@@ -26,5 +26,5 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         for name, cs in acc.items():
             e = out["pmc"].setdefault(name, {"meta": meta[name]})
             for c, v in cs.items():
-                e[c] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
+                e[c] = {"mean_per_dispatch": sum(v) / len(v), "max_per_dispatch": max(v), "dispatches": len(v)}
 print(json.dumps(out, indent=1))

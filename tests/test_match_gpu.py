@@ -166,7 +166,7 @@ def test_wave_kernel_geometries_at_scale(gpu_device, oracle, k, G):
         _check(res, ref)
         # short k-mers have short segments: their seeds stop at the segment's length and the buckets outgrow the wave
         # kernel's 8-entry slabs (more than 16 guides per bucket) -> quad kernels; everything else: the wave matcher
-        assert dl.last_kernel == ("k_match_fused" if (k, d) in ((12, 1), (12, 2), (16, 2)) else "k_match_wq"), (k, d, dl.last_kernel)
+        assert dl.last_kernel == ("k_match_fused" if (k, d) in ((12, 2), (16, 2)) else "k_match_wq"), (k, d, dl.last_kernel)
 
 
 def test_tally_hot_guides(gpu_device):
