@@ -22,7 +22,8 @@ except Exception:  # torch is plumbing only; the C ABI works without it
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbarcoder_hip.so")
+# BC_NATIVE_SO: another build of the same library (the host-sanitizer build of tests/README: build/libbarcoder_hip_asan.so)
+SO_PATH = os.environ.get("BC_NATIVE_SO") or os.path.join(_HERE, "libbarcoder_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 BC_OK, BC_EINVAL, BC_ENOMEM, BC_EHIP, BC_ENODEV, BC_ECAP = 0, -1, -2, -3, -4, -5
