@@ -118,3 +118,45 @@ def test_against_indexed_oracle_at_scale(full_run, oracle):
             np.testing.assert_array_equal(bi[a:a + m_].cpu().numpy(), ref["best_idx"])
             np.testing.assert_array_equal(bd[a:a + m_].cpu().numpy(), ref["best_dist"])
             np.testing.assert_array_equal(nb[a:a + m_].cpu().numpy(), ref["n_best"])
+
+
+def test_config4_shards_on_one_gpu(gpu_device):
+    """BASELINE configs[4] is 1e9 reads in 8 contiguous shards of 1.25e8, counts all-reduced.  With one GPU the eight
+    shards run one after the other on it (same seeded stream, `first_index_base` = the shard's global offset, counts and
+    first-seen accumulating in place of the all-reduce): the job-wide vectors must equal what the shards imply — counts
+    sum to the matched reads, every shard's matched fraction is the stream's 90 %, first-seen keys lie in the shard that
+    first shows the guide and are the global minimum, and re-running shard 0 alone reproduces its contribution."""
+    import torch
+    from barcoder_amd import DeviceLibrary, GpuMatcher, synth as S
+    dev = torch.device("cuda", gpu_device)
+    n_shard, shards = 125_000_000, 8
+    lib = S.library(G, K)
+    m = GpuMatcher(DeviceLibrary(lib, K, gpu_device))
+    reads = torch.empty(n_shard, dtype=torch.int64, device=dev)
+    bi = torch.empty(n_shard, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(G, dtype=torch.int32, device=dev)
+    fs = torch.full((G,), -1, dtype=torch.int64, device=dev)
+    matched, cnt0, fs_min_seen = 0, None, None
+    for r in range(shards):
+        base = r * n_shard
+        m.synth_reads_dev(5, base, n_shard, 1, reads.data_ptr())
+        m.match_dev(reads.data_ptr(), n_shard, bi.data_ptr(), max_mismatch=2, algo="seed", d_counts=cnt.data_ptr(),
+                    d_first_seen=fs.data_ptr(), first_index=base)
+        torch.cuda.synchronize()
+        hit = int((bi >= 0).sum())
+        assert abs(hit / n_shard - 0.90) < 2e-3
+        matched += hit
+        if r == 0:
+            cnt0 = cnt.clone()
+            assert int((fs >= 0).sum()) == int((cnt0 > 0).sum())       # every seen guide has a key ...
+            assert int(fs.max()) < n_shard                              # ... inside shard 0
+            # first-seen of a few guides against a direct scan of best_idx
+            for g in (0, 1, 77, G - 1):
+                pos = torch.nonzero(bi == g)
+                assert int(fs[g]) == int(pos[0]) if pos.numel() else int(fs[g]) == -1
+            fs_min_seen = fs.clone()
+    assert int(cnt.to(torch.int64).sum()) == matched
+    assert bool((cnt >= cnt0).all()) and int(cnt.min()) > 0
+    # keys only ever decrease, and with 1.25e8 reads over 1e5 guides every guide shows up in shard 0 already
+    assert bool((fs == fs_min_seen).all())
+    assert m.lib.last_kernel == "k_match_wq"
