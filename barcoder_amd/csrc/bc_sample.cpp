@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -49,6 +50,30 @@ struct OrderedCounter {
         return v;
     }
     bool empty() const { return items.empty(); }
+};
+
+// set of strings whose storage is a chunked arena: membership test and insertion hash the characters once and
+// allocate nothing for a string that is already present (std::unordered_set<std::string>::emplace builds a node —
+// a heap allocation — before it looks)
+struct StrSet {
+    std::unordered_set<std::string_view> set;
+    std::vector<std::unique_ptr<char[]>> blocks;
+    size_t used = 0, cap = 0;
+    explicit StrSet(size_t expect = 0) { if (expect) set.reserve(expect); }
+    bool insert(std::string_view v) {  // true when new
+        if (set.find(v) != set.end()) return false;
+        if (used + v.size() > cap) {
+            cap = std::max<size_t>(1u << 22, v.size());
+            blocks.emplace_back(new char[cap]);
+            used = 0;
+        }
+        char* at = blocks.back().get() + used;
+        memcpy(at, v.data(), v.size());
+        used += v.size();
+        set.emplace(at, v.size());
+        return true;
+    }
+    size_t size() const { return set.size(); }
 };
 
 struct Chunk {
@@ -165,7 +190,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     OrderedCounter<int> orients[2];      // 0 = "forward", 1 = "reverse"
     OrderedCounter<int64_t> offsets[2];
     std::vector<std::string> valid_store[2];
-    std::unordered_set<std::string> valid[2], seen_reads, observed;
+    StrSet valid[2], seen_reads(6 * (size_t)n_lib), observed(2 * (size_t)n_lib);
     uint64_t all_novel = 0;
     bool satisfied = false;
     uint64_t n_chunks = 0;
@@ -179,6 +204,8 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         std::vector<int> c_or[2];
         std::vector<int64_t> c_off[2];
         std::unordered_set<std::string_view> c_barcodes, c_reads;
+        c_barcodes.reserve((size_t)n_lib);
+        c_reads.reserve((size_t)n_lib);
         // zip(read1_chunk, read2_chunk if read2_chunk else [None]*len): an EMPTY mate chunk means "None" mates
         const bool have2 = paired && c2.n > 0;
         const uint64_t nz = have2 ? std::min(c1.n, c2.n) : c1.n;
@@ -189,8 +216,8 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
             last1_truthy = !read1.empty();
             last2_truthy = have2 && !read2.empty();
             if (c_reads.count(read1) || (last2_truthy && c_reads.count(read2))) continue;
-            seen_reads.emplace(read1);
-            if (paired) seen_reads.emplace(have2 ? std::string(read2) : std::string("\x01None"));
+            seen_reads.insert(read1);
+            if (paired) seen_reads.insert(have2 ? read2 : std::string_view("\x01None"));
             if ((int64_t)read1.size() < k) continue;
             Roll roll1(k), roll2(k);
             for (size_t i = 0; i + k <= read1.size(); ++i) {
@@ -201,9 +228,9 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 if (maybe1 && c_barcodes.count(kmer)) continue;
                 if (maybe1) for (int lib = 0; lib < 2; ++lib)
                     if ((lib == 0 ? fwd : rev).count(kmer)) {
-                        div[0]++; c_barcodes.insert(kmer); observed.emplace(kmer);
+                        div[0]++; c_barcodes.insert(kmer); observed.insert(kmer);
                         c_or[0].push_back(lib); c_off[0].push_back((int64_t)i);
-                        if (valid[0].emplace(read1).second) valid_store[0].emplace_back(read1);
+                        if (valid[0].insert(read1)) valid_store[0].emplace_back(read1);
                         c_reads.insert(read1);
                     }
                 if (paired && have2) {
@@ -212,9 +239,9 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                     if (c_barcodes.count(kmer2)) continue;
                     for (int lib = 0; lib < 2; ++lib)
                         if (kmer2.size() == (size_t)k && (lib == 0 ? fwd : rev).count(kmer2)) {
-                            div[1]++; c_barcodes.insert(kmer2); observed.emplace(kmer);  // sic: the first mate's k-mer
+                            div[1]++; c_barcodes.insert(kmer2); observed.insert(kmer);  // sic: the first mate's k-mer
                             c_or[1].push_back(lib); c_off[1].push_back((int64_t)i);
-                            if (valid[1].emplace(read2).second) valid_store[1].emplace_back(read2);
+                            if (valid[1].insert(read2)) valid_store[1].emplace_back(read2);
                             c_reads.insert(read2);
                         }
                 }
