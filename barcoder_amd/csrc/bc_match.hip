@@ -415,14 +415,17 @@ __device__ __forceinline__ void slab_slow_wide(const SlabParams& sp, uint32_t rl
 // ---------------------------------------------------------------------------
 constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 64 drains first when fewer are free
 
-template <int NSEG, int NQ2, bool PROF, bool WIDE>
+template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wq(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,
                                                    const uint8_t* __restrict__ flags, uint64_t n, int k,
                                                    uint64_t kmask, int max_mm_, MatchOut o_arg) {
     static_assert(NSEG == 2 || NSEG == 3, "wave kernel: d = 1 or 2");
-    constexpr int NQ01 = WIDE ? 2 : 1;           // 16-byte pieces per lane of a table-0/1 slab (8 entries: 64 / 128 bytes)
-    constexpr uint32_t S01 = WIDE ? 7u : 6u;     // log2 of that slab's bytes
+    // NQ01: 16-byte pieces per lane of a table-0/1 slab — 1: 64-byte slabs (8 narrow entries); 2: 128-byte slabs
+    // (16 narrow entries for buckets above 16 guides, or 8 wide entries)
+    static_assert(NQ01 == 1 || NQ01 == 2, "table 0/1 slabs are 64 or 128 bytes");
+    static_assert(!WIDE || NQ01 == 2, "wide entries: 8-entry slabs of 128 bytes");
+    constexpr uint32_t S01 = NQ01 == 2 ? 7u : 6u;     // log2 of that slab's bytes
     (void)o_arg;  // read from the kernel-argument segment in the last phase, see there
     __shared__ uint64_t q_read[WAVE_T];                                 // listed read; later its result
     __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];     // its best key so far (LDS atomic min)
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             qn += (uint32_t)__popcll(m);
             push_items(push && lnk != 0u, at[j] | (lnk << 10));  // table 0 item
         };
-        if constexpr (!WIDE) {
+        if constexpr (NQ01 == 1) {
             uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
             visit_issue<1, false>(b0, off0(0), none4, s, wa);
             visit_issue<1, false>(b0, off0(1), none4, s, wb);
@@ -1446,7 +1449,9 @@ int launch_hist(bc_lib* lib, const MatchOut& o, uint64_t n, hipStream_t st) {
 // ranges: as few as the LDS allows (HIST_R guides each), equal sizes; range(g) = umulhi(g, magic) must be exact
 bool part_geometry(uint32_t G, PartOut& P) {
     const uint32_t nr = (G + HIST_R - 1) / HIST_R;
-    if (nr < 3 || nr > (uint32_t)PART_MAX_NR) return false;  // one or two ranges: sweeping best_idx costs no more
+    // one or two ranges: sweeping best_idx costs no more.  Above eight the lines are mostly empty (256 reads over nr
+    // ranges) and writing + reading them costs what the sweeps cost (measured, 25 ranges: 1.13 vs 1.07 ms per 1e8 reads)
+    if (nr < 3 || nr > (uint32_t)PART_MAX_NR) return false;
     const uint32_t R = (G + nr - 1) / nr;
     const uint32_t magic = (uint32_t)((0x100000000ull + R - 1) / R);
     for (uint32_t g = 0; g < G; ++g)
@@ -1513,7 +1518,11 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     // records (k_hist_part) when the kernel that runs can write them, else by sweeping best_idx once per range (k_hist)
     const int tally_mode = lib->knobs.tally;  // 0 auto, 1 atomics, 2 k_hist, 3 records when possible
     const bool want_tally = o_in.counts || o_in.first_seen;
-    const bool use_lds = want_tally && aligned16(o_in.best_idx) && (tally_mode >= 2 || (tally_mode == 0 && n >= 4ull * lib->G));
+    // libraries of more than 36 ranges (7.4e5 guides): one sweep of best_idx per range (0.05 ms each per 1e8 reads) costs
+    // more than device-scope atomics on counters that spread (1.6 - 2.2 ms per 1e8 reads at 5e5 - 3e6 guides)
+    const bool sweeps_pay = (lib->G + HIST_R - 1) / HIST_R <= 36u;
+    const bool use_lds = want_tally && aligned16(o_in.best_idx) &&
+                         (tally_mode >= 2 || (tally_mode == 0 && n >= 4ull * lib->G && sweeps_pay));
     const uint64_t CH = 1ull << 31;  // reads per launch: 32-bit tile numbers and offsets stay far from wrapping
     for (uint64_t a = 0; a < n; a += CH) {
         const uint64_t m = std::min(CH, n - a);
@@ -1600,33 +1609,43 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
         const bool vec_ok = aligned16(d_reads) && aligned16(o.best_idx) && n >= 4 &&
                             (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
                             (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
+        // table-0/1 slabs of 64 bytes (8 narrow entries) or 128 bytes (16 narrow entries: buckets above 16 guides; or
+        // 8 wide entries): one or two 16-byte pieces per lane
+        const int nq01 = (int)(((wide ? 16u : 8u) << hp.t[0].log2S) / 64u);
         bool wave_ok = algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && max_mm >= 1 && vec_ok && !lib->knobs.single_slab &&
-                       lib->knobs.lane && (nseg == 2 || nseg == 3) && hp.t[0].log2S == 3 && hp.t[1].log2S == 3 &&
-                       !lib->h_nn.empty();
+                       lib->knobs.lane && (nseg == 2 || nseg == 3) && hp.t[0].log2S == hp.t[1].log2S &&
+                       (nq01 == 1 || nq01 == 2) && !lib->h_nn.empty();
         for (int t = 0; t < nseg && wave_ok; ++t) wave_ok = hp.t[t].empty < (1u << 22);  // slab numbers travel in 22-bit item fields
-        if (wave_ok && nseg == 3 && wide && hp.t[2].log2S > 4) wave_ok = false;
+        // narrow 128-byte slabs: measured against the quad kernels, 1e8 reads, d <= 2: 5e5 20-mers (30 per bucket) 14.7 vs
+        // 13.1 G reads/s, 1e6 (61 per bucket) 6.1 vs 7.1, 2e4 12-mers (rest of 8 bases: ties everywhere) 9.6 vs 11.0
+        if (wave_ok && !wide && nq01 == 2 && (lib->k < 16 || (double)lib->G / (double)(1u << (2 * hp.t[0].slen)) > 40.0)) wave_ok = false;
+        const int nq2 = nseg == 3 ? (int)(((wide ? 16u : 8u) << hp.t[2].log2S) / 64u) : nq01;  // pieces per lane, table 2
+        if (wave_ok && nseg == 3 && (nq2 > 4 || (nq01 == 2 && nq2 < 2))) wave_ok = false;
         if (algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && (!wide || wave_ok)) {
             const SlabParams* dp = lib->d_slab[max_mm];
             if (max_mm >= 1 && vec_ok && !lib->knobs.single_slab) {
                 // default: the wave kernel (lane-owned reads, quad-cooperative loads, no hash table);
                 // BC_LANE=0 selects the quad kernels
                 if (wave_ok) {
-                    const bool prof = lib->knobs.phase_prof != 0;  // tuning aid: per-stage cycle sums on stderr
-                    const int nq2 = nseg == 3 ? ((wide ? 2 : 1) << (hp.t[2].log2S - 3)) : 1;  // 16-byte pieces per lane
+                    const bool prof = lib->knobs.phase_prof != 0 && !wide && nq01 == 1;  // tuning aid: per-stage cycle sums on stderr
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
-#define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_)                                                                  \
-    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
+#define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
+    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o)
-#define BC_WAVE_P(NSEG_, NQ2_, WIDE_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, WIDE_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, WIDE_); } while (0)
-                    if (!wide) {
-                        if (nseg == 2) BC_WAVE_P(2, 1, false);
-                        else if (nq2 == 1) BC_WAVE_P(3, 1, false);
-                        else if (nq2 == 2) BC_WAVE_P(3, 2, false);
-                        else BC_WAVE_P(3, 4, false);
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+                    if (!wide && nq01 == 1) {
+                        if (nseg == 2) BC_WAVE_P(2, 1);
+                        else if (nq2 == 1) BC_WAVE_P(3, 1);
+                        else if (nq2 == 2) BC_WAVE_P(3, 2);
+                        else BC_WAVE_P(3, 4);
+                    } else if (!wide) {
+                        if (nseg == 2) BC_WAVE_LAUNCH(2, 2, false, false, 2);
+                        else if (nq2 == 2) BC_WAVE_LAUNCH(3, 2, false, false, 2);
+                        else BC_WAVE_LAUNCH(3, 4, false, false, 2);
                     } else {
-                        if (nseg == 2) BC_WAVE_P(2, 2, true);
-                        else if (nq2 == 2) BC_WAVE_P(3, 2, true);
-                        else BC_WAVE_P(3, 4, true);
+                        if (nseg == 2) BC_WAVE_LAUNCH(2, 2, false, true, 2);
+                        else if (nq2 == 2) BC_WAVE_LAUNCH(3, 2, false, true, 2);
+                        else BC_WAVE_LAUNCH(3, 4, false, true, 2);
                     }
 #undef BC_WAVE_P
 #undef BC_WAVE_LAUNCH
