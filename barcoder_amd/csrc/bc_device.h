@@ -63,7 +63,8 @@ constexpr uint32_t SLAB_F_ISO1 = 1u << 22;
 constexpr uint32_t SLAB_F_ISO = 1u << 23;
 struct SlabTable {
     const uint2* slabs;
-    uint32_t start, slen, half;   // seed position / length; half = k - slen
+    uint32_t start, slen, half;   // seed position / length; half = bit distance of the rest's two planes inside an
+                                  // 8-byte entry's first word (always 16) / k - slen for 16-byte entries
     uint32_t log2S;               // entries per slab (incl. the link entry)
     uint32_t empty;               // index of an all-empty slab appended after the overflow slabs
     uint32_t wide;                // 1: 16-byte entries {rest lo plane, giw, rest hi plane, 0} (k - seed > 16 bases)

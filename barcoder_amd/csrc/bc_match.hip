@@ -256,8 +256,21 @@ __device__ __forceinline__ RestW rest_of(uint32_t start, uint32_t sh, uint32_t h
         const uint32_t up_lo = sh >= 32u ? 0u : (rlo >> sh), up_hi = sh >= 32u ? 0u : (rhi >> sh);
         return RestW{(rlo & below) | (up_lo << start), (rhi & below) | (up_hi << start)};
     } else {
-        return RestW{((rlo & below) | ((rlo >> sh) << start)) | (((rhi & below) | ((rhi >> sh) << start)) << half), 0u};
+        (void)half;  // narrow entries keep the high plane in the upper 16 bits, whatever the rest's length
+        return RestW{((rlo & below) | ((rlo >> sh) << start)) | (((rhi & below) | ((rhi >> sh) << start)) << 16), 0u};
     }
+}
+// mismatching bases of a narrow rest: x = read ^ entry, low plane in bits 0-15, high plane in bits 16-31 (unused
+// bits are zero on both sides).  The two planes are or-ed by sub-dword operand selection: one instruction instead
+// of shift + and-or (the scan is a quarter of this VALU-bound kernel's instructions)
+__device__ __forceinline__ uint32_t planes_dist(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m;
+    asm("v_or_b32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(m) : "v"(x));
+    return (uint32_t)__popc(m);
+#else
+    return (uint32_t)__builtin_popcount((x | (x >> 16)) & 0xFFFFu);
+#endif
 }
 // best key (distance << 24 | giw) among the entries of one 16-byte piece
 template <bool WIDE>
@@ -265,9 +278,8 @@ __device__ __forceinline__ uint32_t piece_min(const uint4& w, uint32_t rl, uint3
     if constexpr (WIDE) {
         return ((uint32_t)__popc((rl ^ w.x) | (rh ^ w.z)) << 24) | w.y;
     } else {
-        const uint32_t x0 = rl ^ w.x, x1 = rl ^ w.z;
-        const uint32_t d0 = __popc((x0 & hmask) | (x0 >> half)), d1 = __popc((x1 & hmask) | (x1 >> half));
-        return min((d0 << 24) | w.y, (d1 << 24) | w.w);
+        (void)half; (void)hmask;
+        return min((planes_dist(rl ^ w.x) << 24) | w.y, (planes_dist(rl ^ w.z) << 24) | w.w);
     }
 }
 template <bool WIDE>
@@ -430,9 +442,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     __shared__ uint64_t q_read[WAVE_T];                                 // listed read; later its result
     __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];     // its best key so far (LDS atomic min)
     __shared__ uint32_t wl[WL_CAP];                                     // items: list entry | table << 8 | slab << 10
-    __shared__ uint16_t l_t2[WAVE_T];     // list entries that need table 2
-    __shared__ uint16_t l_slow[WAVE_T];   // list entries whose best guide may tie with a neighbour; then (compacted in
-                                          // place, behind the position being read) those that need the exact path
+    // q_aux: until the listed reads' decisions, the table-0 overflow link of each listed read (its item is pushed only
+    // if table 1's primary slab does not settle the read); from then on two 16-bit lists
+    __shared__ __attribute__((aligned(16))) uint32_t q_aux[WAVE_T];
+    uint32_t* const q_lnk = q_aux;
+    uint16_t* const l_t2 = reinterpret_cast<uint16_t*>(q_aux);  // list entries that need table 2
+    uint16_t* const l_slow = l_t2 + WAVE_T;  // list entries whose best guide may tie with a neighbour; then (compacted in
+                                             // place, behind the position being read) those that need the exact path
     uint16_t* const l_tie = l_slow;
     const SlabParams& sp = *spp;
     const uint32_t max_mm = (uint32_t)max_mm_ & 0xFFu;
@@ -468,6 +484,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     };
     uint32_t qn = 0, t2n = 0, sn = 0, wn = 0, tien = 0;  // wave-uniform list lengths
 
+    // a best key in range whose guide has no neighbour that close is final whatever has not been visited yet: any
+    // other guide h lies further than 2e from it, hence further than e from the read (key_unique, triangle inequality)
+    auto settled = [&](uint32_t key) { return (key >> 24) <= max_mm && key_unique(key, max_mm); };
     auto push_items = [&](bool has, uint32_t item) {
         const unsigned long long m = __ballot(has);
         if (has) wl[wn + rank_of(m)] = item;
@@ -503,8 +522,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             m = min(m, quad_perm<0x4E>(m));
             const uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ01 - 1]));  // the slab's last slot: link or empty (0)
             const bool lead = act && s == 0;
-            if (lead) atomicMin(&q_key[qi], m);
-            push_items(lead && lnk != 0u, (item & 0x3FFu) | (lnk << 10));
+            uint32_t now = 0xFFFFFFFFu;
+            if (lead) now = min(m, atomicMin(&q_key[qi], m));
+            push_items(lead && lnk != 0u && !settled(now), (item & 0x3FFu) | (lnk << 10));  // a settled read's chain ends here
         }
         wave_lds_sync();
     };
@@ -532,8 +552,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             m = min(m, quad_perm<0x4E>(m));
             const uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ2 - 1]));
             const bool lead = act && s == 0;
-            if (lead) atomicMin(&q_key[qi], m);
-            push_items(lead && lnk != 0u, (item & 0x3FFu) | (lnk << 10));
+            uint32_t now = 0xFFFFFFFFu;
+            if (lead) now = min(m, atomicMin(&q_key[qi], m));
+            push_items(lead && lnk != 0u && !settled(now), (item & 0x3FFu) | (lnk << 10));
         }
         wave_lds_sync();
     };
@@ -592,9 +613,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             if (push) {
                 q_read[at[j]] = r[j];
                 q_key[at[j]] = key;
+                q_lnk[at[j]] = lnk;  // table 0's overflow slab: visited only if table 1 does not settle the read
             }
             qn += (uint32_t)__popcll(m);
-            push_items(push && lnk != 0u, at[j] | (lnk << 10));  // table 0 item
         };
         if constexpr (NQ01 == 1) {
             uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
@@ -605,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             finish(1, wb);
             visit_issue<1, false>(b0, off0(3), none4, s, wb);
             finish(2, wa);
-            finish(3, wb);  // at most 256 table-0 items: WL_CAP holds them
+            finish(3, wb);
         } else {
             uint4 wa[4][2];  // 128-byte slabs: one round in flight (two would take 64 registers)
 #pragma unroll
@@ -620,7 +641,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
 
     // ---- phase 2: table 1's primary slab — the first 64 listed reads as one full-width batch, the rest as items
     if (qn && !(diag & 2u)) {
-        if (wn > WL_CAP - 64) drain01();
         const uint32_t qi = lane;
         const bool mine = qi < qn;
         uint32_t kmin = 0xFFFFFFFFu, off1 = empty1;
@@ -638,18 +658,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         visit_scan<NQ01, WIDE>(wa, rest1, half1, hm1, s, kmin, l1);
         const uint32_t t0 = quad_bcast<3>(l1[0]), t1 = quad_bcast<3>(l1[1]), t2 = quad_bcast<3>(l1[2]), t3 = quad_bcast<3>(l1[3]);
         const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;
-        if (mine) q_key[qi] = kmin;
-        push_items(mine && lnk != 0u, qi | 0x100u | (lnk << 10));
+        // a read that table 1's primary slab settles (a third of the listed ones) needs neither overflow slab
+        const bool more = mine && !settled(kmin);
+        uint32_t lnk0 = 0;
+        if (mine) {
+            q_key[qi] = kmin;
+            lnk0 = q_lnk[qi];
+        }
+        push_items(more && lnk0 != 0u, qi | (lnk0 << 10));
+        push_items(more && lnk != 0u, qi | 0x100u | (lnk << 10));
         for (uint32_t qb = 64; qb < qn; qb += 64) {
-            if (wn > WL_CAP - 64) drain01();
+            if (wn > WL_CAP - 128) drain01();
             const uint32_t qj = qb + lane;
             const bool mj = qj < qn;
-            uint32_t sv = 0;
+            uint32_t sv = 0, lj = 0;
             if (mj) {
                 const uint64_t r = q_read[qj];
                 sv = seed_value((uint32_t)r, (uint32_t)(r >> 32), T1.start, T1.slen);
+                lj = q_lnk[qj];
             }
             push_items(mj, qj | 0x100u | (sv << 10));
+            push_items(mj && lj != 0u, qj | (lj << 10));
         }
     }
     if (!(diag & 2u)) drain01();
@@ -1157,10 +1186,12 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     // (16,16,32) 3.13 ms — short chained slabs beat long ones (smaller tables, fewer bytes per visit).
     const double mu = (double)lib->G / nb;
     int log2S = (mu <= 7.0) ? 3 : 4;
-    // tables 0 and 1 of the d = 1, 2 indexes keep 8-entry slabs up to ~16 guides per bucket: that is the geometry
-    // k_match_wq is built for (one quad-cooperative load per slab; fuller buckets chain).  Measured, 1e8 reads,
-    // d <= 2: G = 2e4 77 vs 57 G reads/s (quad kernels), 2e5 27 vs 23; at 1e6 (61 per bucket) the quad kernels win.
-    if ((cs.nseg == 2 || cs.nseg == 3) && s < 2 && mu <= 16.0) log2S = 3;
+    // 8-byte entries of 16+ base k-mers: 128-byte slabs from 7 guides per bucket on, in every table (k_match_wq takes two
+    // pieces per lane then).  Measured, 1e8 reads, d <= 2, G = 1.2e5 / 1.4e5 / 1.6e5 / 2e5: 64-byte slabs with chains
+    // 1.38 / 1.56 / 1.81 / 2.35 ms, 128-byte slabs 1.39 / 1.43 / 1.49 / 1.65 ms (at 1e5, 6.1 per bucket: 1.14 / 1.35).
+    // Shorter k-mers and 16-byte entries keep 8-entry slabs for tables 0 and 1 up to 16 guides per bucket: the quad
+    // kernels (12-mers) and the wide wave kernel are built for that geometry.
+    if ((cs.nseg == 2 || cs.nseg == 3) && s < 2 && mu <= 16.0 && (wide || lib->k < 16)) log2S = 3;
     log2S = std::max(log2S, env_int("BC_SLAB_MIN_LOG2S", 3));
     log2S = std::min(std::min(SLAB_MAX_LOG2S, env_int("BC_SLAB_MAX_LOG2S", SLAB_MAX_LOG2S)), log2S);
     if (const char* spec = getenv("BC_SLAB_LOG2S")) {  // tuning aid: explicit per-table sizes "a,b,c"
@@ -1188,7 +1219,7 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
             slabs[slot * 2] = make_uint2(lo_r, giw);
             slabs[slot * 2 + 1] = make_uint2(hi_r, 0u);
         } else {
-            slabs[slot] = make_uint2(lo_r | (half >= 32 ? 0u : (hi_r << half)), giw);
+            slabs[slot] = make_uint2(lo_r | (hi_r << 16), giw);  // narrow: half <= 16 bases per plane
         }
     };
     auto append_slab = [&]() {
@@ -1226,7 +1257,7 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     SlabTable& T = sl.t[s];
     T.empty = empty_slab;
     T.wide = wide ? 1u : 0u;
-    T.slabs = d_slabs; T.start = (uint32_t)start; T.slen = (uint32_t)slen; T.half = (uint32_t)half;
+    T.slabs = d_slabs; T.start = (uint32_t)start; T.slen = (uint32_t)slen; T.half = wide ? (uint32_t)half : 16u;
     T.log2S = (uint32_t)log2S;
     for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
         T.dmask[t] = (t < s) ? (((1u << cs.slen[t]) - 1u) << cs.start[t]) : 0u;
