@@ -90,6 +90,7 @@ SIGNATURES = {
     "bc_dev_set": (C.c_int, [C.c_int]),
     "bc_dev_alloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
     "bc_dev_free": (C.c_int, [vp]),
+    "bc_tally_export_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_int, vp]),
     "bc_dev_memset": (C.c_int, [vp, C.c_int, C.c_size_t, vp]),
     "bc_dev_h2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "bc_dev_d2h": (C.c_int, [vp, vp, C.c_size_t, vp]),

@@ -1856,6 +1856,24 @@ __global__ void k_widen_counts(const uint32_t* __restrict__ c32, uint64_t* __res
     if (g < G) c64[g] = c32[g];
 }
 
+// tallies of one pass in the form a job-wide reduction wants (64-bit sums; first-seen with the identity of a SIGNED
+// 64-bit minimum for "unseen"), optionally leaving the accumulators reset for the next pass: one launch instead of
+// five framework kernels between two passes
+__global__ void k_tally_export(uint32_t* __restrict__ c32, uint64_t* __restrict__ fs, int64_t* __restrict__ c64,
+                               int64_t* __restrict__ fmin, uint32_t G, int reset) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    if (c32) {
+        if (c64) c64[g] = (int64_t)c32[g];
+        if (reset) c32[g] = 0u;
+    }
+    if (fs) {
+        const uint64_t f = fs[g];
+        if (fmin) fmin[g] = f == 0xFFFFFFFFFFFFFFFFull ? INT64_MAX : (int64_t)f;
+        if (reset) fs[g] = 0xFFFFFFFFFFFFFFFFull;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1947,6 +1965,20 @@ int bc_match_dev(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     BC_HIP(hipSetDevice(lib->device));
     MatchOut o{d_best_idx, d_best_dist, d_n_best, d_counts, d_first_seen, first_index_base, PartOut{}};
     return launch_match(lib, d_reads, d_flags, n, max_mismatch, algo, o, (hipStream_t)stream);
+}
+
+
+int bc_tally_export_dev(uint32_t* d_counts, uint64_t* d_first_seen, int64_t* d_counts64, int64_t* d_first_min,
+                        uint32_t n_guides, int reset, void* stream) {
+    if (n_guides == 0) return BC_OK;
+    if ((d_counts64 && !d_counts) || (d_first_min && !d_first_seen)) {
+        set_error("bc_tally_export_dev: an output without its accumulator");
+        return BC_EINVAL;
+    }
+    hipLaunchKernelGGL(k_tally_export, dim3((n_guides + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_counts,
+                       d_first_seen, d_counts64, d_first_min, n_guides, reset);
+    BC_HIP(hipGetLastError());
+    return BC_OK;
 }
 
 int bc_match_time_dev(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,

@@ -63,6 +63,13 @@ class GpuMatcher:
                                       N.ALGOS[algo], d_best_idx, d_best_dist or None, d_n_best or None,
                                       d_counts or None, d_first_seen or None, int(first_index), stream or None))
 
+    def tally_export_dev(self, d_counts: int, d_first_seen: int, d_counts64: int, d_first_min: int,
+                         reset: bool = False, stream: int = 0):
+        """counts -> int64 sums, first_seen -> int64 with INT64_MAX for unseen (what the job-wide SUM / MIN
+        all-reduce takes); reset leaves the accumulators empty for the next pass (bc_tally_export_dev)."""
+        N.check(N.load().bc_tally_export_dev(d_counts or None, d_first_seen or None, d_counts64 or None,
+                                             d_first_min or None, self.lib.size, int(bool(reset)), stream or None))
+
     def time_dev(self, d_reads: int, n: int, d_best_idx: int, max_mismatch: int, algo: str, iters: int,
                  d_best_dist: int = 0, d_n_best: int = 0, d_counts: int = 0, d_first_seen: int = 0,
                  stream: int = 0) -> float:

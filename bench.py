@@ -266,22 +266,21 @@ def run(args):
     counts32 = torch.zeros(Gn, dtype=torch.int32, device=dev)
     counts64 = torch.zeros(Gn, dtype=torch.int64, device=dev)
     first_seen = torch.full((Gn,), -1, dtype=torch.int64, device=dev)  # 0xFFFF.. = unseen
+    first_min = torch.empty(Gn, dtype=torch.int64, device=dev)
     first = rank * n  # global index of this rank's first read (weak scaling: n per GPU)
     m.synth_reads_dev(seed, first, n, args.mixture, reads.data_ptr(), stream)
     torch.cuda.synchronize()
-    i64max = torch.iinfo(torch.int64).max
 
     def match_shard(a, b):
         """This rank's shard [a, b) of the job's world*n reads (resident since before the timed region)."""
         assert (a, b) == (first, first + n)
-        counts32.zero_()
-        first_seen.fill_(-1)
         m.match_dev(reads.data_ptr(), n, best_idx.data_ptr(), max_mismatch=args.max_mismatch, algo=args.algo,
                     d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), d_counts=counts32.data_ptr(),
                     d_first_seen=first_seen.data_ptr(), first_index=first, stream=stream)
-        counts64.copy_(counts32)
-        first_seen.masked_fill_(first_seen < 0, i64max)  # unseen: the identity of MIN over int64
-        return counts64, first_seen
+        # one launch: 64-bit sums, unseen -> the identity of MIN over int64, accumulators reset for the next pass
+        m.tally_export_dev(counts32.data_ptr(), first_seen.data_ptr(), counts64.data_ptr(), first_min.data_ptr(),
+                           reset=True, stream=stream)
+        return counts64, first_min
 
     def step():
         return D.count_sharded(world * n, match_shard, Gn, rank, world, device=dev)

@@ -337,6 +337,14 @@ int bc_windows_dev(const uint64_t *d_bases, const uint32_t *d_invalid, uint64_t 
 int bc_score_mismatch_dev(const uint64_t *d_orig, const uint64_t *d_var, uint64_t n, int k,
                           const double *d_weights, double *d_out, uint8_t *d_none, void *stream);
 
+/* Tallies of a pass in the form the job-wide merge wants (heuristicount.py:726-737 merges per-worker Counters; here
+ * the per-GPU vectors are all-reduced: SUM of 64-bit counts, MIN of first-seen read indices).  counts64[g] =
+ * counts[g]; first_min[g] = first_seen[g], with INT64_MAX for "unseen" (the identity of a signed 64-bit MIN, which
+ * is what torch.distributed reduces).  reset != 0 leaves counts = 0 and first_seen = UINT64_MAX for the next pass.
+ * Any of the four pointers may be NULL (an output needs its accumulator). */
+int bc_tally_export_dev(uint32_t *d_counts, uint64_t *d_first_seen, int64_t *d_counts64, int64_t *d_first_min,
+                        uint32_t n_guides, int reset, void *stream);
+
 /* ---- synthetic workloads (bench / tests) -----------
  * Counter-based splitmix64 streams, identical to barcoder_amd/synth.py.
  * mixture: 0 = exact (90 % library reads, 10 % random),

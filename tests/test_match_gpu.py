@@ -374,3 +374,34 @@ def test_large_library_and_misaligned_device_pointers(gpu_device):
         np.testing.assert_array_equal(bi[1:].cpu().numpy(), ref.best_idx)
         np.testing.assert_array_equal(bd[1:].cpu().numpy(), ref.best_dist)
         np.testing.assert_array_equal(nb[1:].cpu().numpy(), ref.n_best)
+
+
+def test_tally_export_and_reset(gpu_device):
+    """bc_tally_export_dev: 64-bit sums, INT64_MAX for guides never seen, accumulators reset for the next pass."""
+    import torch
+    k, G, n = 20, 5000, 200_000
+    lib = S.library(G, k)
+    reads = S.reads(lib, k, 3, 0, n, 1)
+    dl = DeviceLibrary(lib[:G - 7], k, gpu_device)  # the last 7 guides are absent: their reads match nothing
+    m = GpuMatcher(dl)
+    want = m.match(reads, None, max_mismatch=1, algo="seed", first_index=11)
+    dev = torch.device("cuda", gpu_device)
+    Gd = G - 7
+    d_reads = torch.from_numpy(reads.view(np.int64)).to(dev)
+    bi = torch.empty(n, dtype=torch.int32, device=dev)
+    c32 = torch.zeros(Gd, dtype=torch.int32, device=dev)
+    fs = torch.full((Gd,), -1, dtype=torch.int64, device=dev)
+    c64 = torch.empty(Gd, dtype=torch.int64, device=dev)
+    fmin = torch.empty(Gd, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(2):  # the second pass starts from the reset accumulators
+        m.match_dev(d_reads.data_ptr(), n, bi.data_ptr(), max_mismatch=1, algo="seed", d_counts=c32.data_ptr(),
+                    d_first_seen=fs.data_ptr(), first_index=11, stream=st)
+        m.tally_export_dev(c32.data_ptr(), fs.data_ptr(), c64.data_ptr(), fmin.data_ptr(), reset=True, stream=st)
+        torch.cuda.synchronize(dev)
+        np.testing.assert_array_equal(c64.cpu().numpy(), want.counts.astype(np.int64))
+        f = fmin.cpu().numpy()
+        seen = want.counts > 0
+        np.testing.assert_array_equal(f[seen], want.first_seen[seen].astype(np.int64))
+        assert (f[~seen] == np.iinfo(np.int64).max).all()
+        assert int(c32.sum().item()) == 0 and bool((fs == -1).all().item())
