@@ -92,6 +92,20 @@ struct SlabParams {
     uint32_t f_pos[4], f_len[4];  // first base / length of the halves 0a, 0b, 1a, 1b
 };
 
+// Pair index of the 3-mismatch matcher (bc_match_pairs.hip): the k-mer in five pieces, one table per pair (a < b) of
+// pieces, keyed on piece a's first a_len bases and piece b's first b_len bases; slabs of 7 entries {rest, guide} +
+// link, rest = the other k - a_len - b_len bases (low plane in bits 0-15, high plane in bits 16-31).
+struct PairTable {
+    const uint2* slabs;           // bucket = slab number; overflow slabs behind the primaries
+    uint32_t a_start, a_len, b_start, b_len;   // key fields, in bases
+    uint32_t must_clean;          // rest positions of what is left of pieces a and b: a counted guide is clean there
+    uint32_t other[3], n_other;   // rest positions of each piece c < b, c != a: a counted guide is dirty in every one
+};
+struct PairParams {
+    int ntab;
+    PairTable t[10];
+};
+
 // Tuning / experiment knobs, read from the environment ONCE when a library is created (never per launch).
 // Defaults are the measured best; the knob-coverage tests check that none of them changes a result.
 struct Knobs {
@@ -103,6 +117,8 @@ struct Knobs {
     int tally = 0;        // BC_TALLY: 0 auto, 1 global atomics, 2 k_hist sweeps, 3 range-partitioned records
     int phase_prof = 0;   // BC_PHASE_PROF=1: per-stage cycle sums of the wave kernel on stderr
     int host_pin = 1;     // BC_HOST_PIN=0: bc_match_host does not pin the caller's buffers
+    int cascade = 1;      // BC_CASCADE=0: d = 3 by the four-segment index over every read (round 1's path); 2: the pair
+                          // index over every read (no d <= 2 pass first); 1: cascade
 };
 
 // scratch of the record tally (k_hist_part), one per stream that launches on a library
@@ -113,6 +129,14 @@ struct TallyWs {
     uint32_t* ovf_count = nullptr; // self-resetting (k_first_refine)
     uint32_t* first_tile = nullptr;  // [G], 0xFFFFFFFF between launches
     uint64_t tiles_cap = 0;
+    // d = 3 cascade: the reads the d <= 2 pass left without a hit, compacted, and their results before the scatter
+    uint64_t casc_cap = 0;
+    uint32_t* c_idx = nullptr;     // [casc_cap] position of the read in the launch
+    uint64_t* c_reads = nullptr;   // [casc_cap]
+    int32_t* c_best = nullptr;     // [casc_cap]
+    uint8_t* c_dist = nullptr;     // [casc_cap]
+    uint8_t* c_nb = nullptr;       // [casc_cap]
+    uint32_t* c_count = nullptr;   // [4]
 };
 
 }  // namespace bc
@@ -138,6 +162,7 @@ struct bc_lib {
     bool slab_ok[bc::MAX_SEG] = {false, false, false, false};
     bool slab_wide[bc::MAX_SEG] = {false, false, false, false};  // wide entries: only k_match_wq reads them
     const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
+    const bc::PairParams* d_pairs = nullptr;   // 3-mismatch pair index (NULL: k outside 8..25)
     bc::Knobs knobs;
     std::deque<bc::TallyWs> ws;    // tally workspaces by stream (deque: pointers stay valid as it grows)
     std::mutex ws_mutex;

@@ -26,6 +26,7 @@
 // Bounds (measured): the lookup kernels sit on the L2's random-request rate
 // under a concurrent stream (~1.1 requests per read is the floor: 0.67 ms per 1e8 reads) and on
 // VALU issue (86 %) at the same time; the tally kernels are HBM streams.
+#include <string.h>
 #include <dlfcn.h>
 #include <math.h>
 #include <stddef.h>
@@ -1476,6 +1477,60 @@ int launch_hist(bc_lib* lib, const MatchOut& o, uint64_t n, hipStream_t st) {
     return BC_OK;
 }
 
+// ---- d = 3 cascade ---------------------------------------------------------------------------------------------
+// A guide within two substitutions, once found, is the best hit whatever the budget; only reads the d <= 2 pass left
+// without a hit need the 3-mismatch search, whose four 5-base seeds put ~G/1024 guides in every bucket (9.4 G reads/s
+// over all reads at 1e5 guides against 75 for d <= 2).  The missed reads are compacted (order irrelevant: results
+// return by position), searched by the d = 3 kernels, and scattered back.
+constexpr uint64_t COLLECT_CHUNK = 16384;  // reads per workgroup: one global append per chunk (a shared counter takes
+                                           // ~90 appends per microsecond on this part: one per wave cost 17 ms per 1e8 reads)
+__global__ __launch_bounds__(BLOCK) void k_collect_missed(const int32_t* __restrict__ best_idx, const uint64_t* __restrict__ reads,
+                                                         uint64_t n, uint32_t* __restrict__ idx, uint64_t* __restrict__ out_reads,
+                                                         uint32_t* __restrict__ count) {
+    __shared__ uint32_t w_cnt[BLOCK / 64];
+    __shared__ uint32_t w_base[BLOCK / 64];
+    const uint64_t c0 = (uint64_t)blockIdx.x * COLLECT_CHUNK, c1 = min(n, c0 + COLLECT_CHUNK);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t mine = 0;  // misses this wave has met (wave-uniform)
+    for (uint64_t b = c0; b < c1; b += BLOCK) {
+        const uint64_t i = b + threadIdx.x;
+        mine += (uint32_t)__popcll(__ballot(i < c1 && best_idx[i] == BC_IDX_MISS));
+    }
+    if (lane == 0) w_cnt[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) { w_base[w] = tot; tot += w_cnt[w]; }
+        const uint32_t base = tot ? atomicAdd(count, tot) : 0u;
+        for (int w = 0; w < BLOCK / 64; ++w) w_base[w] += base;
+    }
+    __syncthreads();
+    uint32_t at = w_base[wv];
+    for (uint64_t b = c0; b < c1; b += BLOCK) {  // second sweep of the chunk's results (L2-resident)
+        const uint64_t i = b + threadIdx.x;
+        const bool miss = i < c1 && best_idx[i] == BC_IDX_MISS;
+        const unsigned long long m = __ballot(miss);
+        if (miss) {
+            const uint32_t pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            idx[pos] = (uint32_t)(i);
+            out_reads[pos] = reads[i];
+        }
+        at += (uint32_t)__popcll(m);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scatter_results(const uint32_t* __restrict__ idx, uint32_t nm, const int32_t* __restrict__ c_best,
+                                                          const uint8_t* __restrict__ c_dist, const uint8_t* __restrict__ c_nb,
+                                                          int32_t* __restrict__ best_idx, uint8_t* __restrict__ best_dist,
+                                                          uint8_t* __restrict__ n_best) {
+    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= nm) return;
+    const uint32_t i = idx[j];
+    best_idx[i] = c_best[j];
+    if (best_dist) best_dist[i] = c_dist[j];
+    if (n_best) n_best[i] = c_nb[j];
+}
+
 // ---- tally records: geometry and per-stream workspace -------------------------------------------------------
 // ranges: as few as the LDS allows (HIST_R guides each), equal sizes; range(g) = umulhi(g, magic) must be exact
 bool part_geometry(uint32_t G, PartOut& P) {
@@ -1492,8 +1547,7 @@ bool part_geometry(uint32_t G, PartOut& P) {
 }
 
 // launches on one stream are ordered, so one workspace per stream is enough; it only ever grows
-int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, TallyWs** out) {
-    std::lock_guard<std::mutex> g(lib->ws_mutex);
+static int stream_workspace(bc_lib* lib, hipStream_t st, TallyWs** out) {  // caller holds ws_mutex
     TallyWs* w = nullptr;
     for (auto& e : lib->ws) if (e.stream == (void*)st) w = &e;
     if (!w) {
@@ -1506,6 +1560,37 @@ int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, 
         BC_HIP(hipMemset(w->first_tile, 0xFF, (size_t)lib->G * 4));
         BC_HIP(hipMemset(w->ovf_count, 0, 16));
     }
+    *out = w;
+    return BC_OK;
+}
+
+// buffers of the d = 3 cascade for launches of up to n reads on this stream
+int cascade_workspace(bc_lib* lib, hipStream_t st, uint64_t n, TallyWs** out) {
+    std::lock_guard<std::mutex> g(lib->ws_mutex);
+    TallyWs* w = nullptr;
+    int rc = stream_workspace(lib, st, &w);
+    if (rc != BC_OK) return rc;
+    if (!w->c_count) BC_HIP(hipMalloc((void**)&w->c_count, 16));
+    if (n > w->casc_cap) {
+        BC_HIP(hipStreamSynchronize(st));
+        for (void* p : {(void*)w->c_idx, (void*)w->c_reads, (void*)w->c_best, (void*)w->c_dist, (void*)w->c_nb}) if (p) (void)hipFree(p);
+        w->c_idx = nullptr; w->c_reads = nullptr; w->c_best = nullptr; w->c_dist = nullptr; w->c_nb = nullptr; w->casc_cap = 0;
+        BC_HIP(hipMalloc((void**)&w->c_idx, (size_t)n * 4));
+        BC_HIP(hipMalloc((void**)&w->c_reads, (size_t)n * 8));
+        BC_HIP(hipMalloc((void**)&w->c_best, (size_t)n * 4));
+        BC_HIP(hipMalloc((void**)&w->c_dist, (size_t)n));
+        BC_HIP(hipMalloc((void**)&w->c_nb, (size_t)n));
+        w->casc_cap = n;
+    }
+    *out = w;
+    return BC_OK;
+}
+
+int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, TallyWs** out) {
+    std::lock_guard<std::mutex> g(lib->ws_mutex);
+    TallyWs* w = nullptr;
+    int rc = stream_workspace(lib, st, &w);
+    if (rc != BC_OK) return rc;
     if (n_tiles > w->tiles_cap) {
         BC_HIP(hipStreamSynchronize(st));  // nothing of this stream may still use the old buffers
         if (w->rec) (void)hipFree(w->rec);
@@ -1535,6 +1620,67 @@ int launch_hist_part(bc_lib* lib, const MatchOut& o, const TallyWs* w, uint64_t 
 // which kernel ran last (tests assert the path, bc_lib_last_kernel)
 void note_kernel(bc_lib* lib, const char* name) { lib->last_kernel.store(name, std::memory_order_relaxed); }
 
+// max_mismatch = 3 as a cascade (see k_collect_missed).  One host synchronisation per launch: the number of reads left
+// for the second stage sizes its grid.
+int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o_in, hipStream_t st) {
+    const uint64_t CH = 1ull << 27;  // reads per round: bounds the workspace (18 bytes per read)
+    const bool want_tally = o_in.counts || o_in.first_seen;
+    const char* second = nullptr;
+    for (uint64_t a = 0; a < n; a += CH) {
+        const uint64_t m = std::min(CH, n - a);
+        MatchOut o = o_in;
+        o.best_idx += a;
+        if (o.best_dist) o.best_dist += a;
+        if (o.n_best) o.n_best += a;
+        o.base += a;
+        o.counts = nullptr; o.first_seen = nullptr; o.part = PartOut{};
+        TallyWs* w = nullptr;
+        int rc = cascade_workspace(lib, st, m, &w);
+        if (rc != BC_OK) return rc;
+        bool pd = false;
+        uint64_t tb = m;
+        rc = launch_match_kernel(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, 2, BC_ALGO_SEED, o, st, &pd, &tb);
+        if (rc != BC_OK) return rc;
+        BC_HIP(hipMemsetAsync(w->c_count, 0, 4, st));
+        const uint64_t blocks = (m + COLLECT_CHUNK - 1) / COLLECT_CHUNK;
+        hipLaunchKernelGGL(k_collect_missed, dim3((unsigned)blocks), dim3(BLOCK), 0, st, o.best_idx, d_reads + a, m, w->c_idx,
+                           w->c_reads, w->c_count);
+        BC_HIP(hipGetLastError());
+        uint32_t nm = 0;
+        BC_HIP(hipMemcpyAsync(&nm, w->c_count, 4, hipMemcpyDeviceToHost, st));
+        BC_HIP(hipStreamSynchronize(st));
+        if (nm) {
+            MatchOut o2{w->c_best, o.best_dist ? w->c_dist : nullptr, o.n_best ? w->c_nb : nullptr, nullptr, nullptr, 0, PartOut{}};
+            if (lib->d_pairs) {
+                rc = launch_pairs(lib, 3, w->c_reads, nullptr, nm, o2, st);
+                if (rc == BC_OK) note_kernel(lib, "k_match_pairs");
+            } else {
+                rc = launch_match_kernel(lib, w->c_reads, nullptr, nm, 3, BC_ALGO_SEED, o2, st, &pd, &tb);
+            }
+            if (rc != BC_OK) return rc;
+            second = lib->last_kernel.load(std::memory_order_relaxed);
+            hipLaunchKernelGGL(k_scatter_results, dim3((nm + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, w->c_idx, nm, w->c_best,
+                               w->c_dist, w->c_nb, o.best_idx, o.best_dist, o.n_best);
+            BC_HIP(hipGetLastError());
+        }
+        if (want_tally) {
+            MatchOut t = o;
+            t.counts = o_in.counts; t.first_seen = o_in.first_seen;
+            rc = launch_hist(lib, t, m, st);
+            if (rc != BC_OK) return rc;
+        }
+    }
+    // which kernels ran: the d <= 2 pass, then (if any read was left) the d = 3 kernel
+    const char* name = "cascade3:d2";
+    if (second) {
+        name = !strcmp(second, "k_match_pairs") ? "cascade3:d2+k_match_pairs"
+             : !strcmp(second, "k_match_fused") ? "cascade3:d2+k_match_fused"
+             : !strcmp(second, "k_match_slab") ? "cascade3:d2+k_match_slab" : "cascade3:d2+k_match_seed";
+    }
+    note_kernel(lib, name);
+    return BC_OK;
+}
+
 int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
                  int max_mm, int algo, const MatchOut& o_in, hipStream_t st) {
     if (n == 0) return BC_OK;
@@ -1545,6 +1691,10 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
         return BC_EINVAL;
     }
     if (algo == BC_ALGO_AUTO) algo = (max_mm == 0) ? BC_ALGO_HASH : BC_ALGO_SEED;
+    // d = 3: the d <= 2 pass, then the pair index for the reads it left (without a pair index — k outside 8..25 — the
+    // four-segment kernels take every read: they spend their time on exactly those reads either way)
+    if (algo == BC_ALGO_SEED && max_mm == 3 && lib->knobs.cascade == 1 && lib->d_pairs && aligned16(o_in.best_idx))
+        return launch_cascade3(lib, d_reads, d_flags, n, o_in, st);
     // tally: in-kernel global atomics for small launches; otherwise LDS-privatised, from the matcher's range-partitioned
     // records (k_hist_part) when the kernel that runs can write them, else by sweeping best_idx once per range (k_hist)
     const int tally_mode = lib->knobs.tally;  // 0 auto, 1 atomics, 2 k_hist, 3 records when possible
@@ -1632,6 +1782,12 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
         if (max_mm < 0 || max_mm >= MAX_SEG) {
             set_error("bc_match: the seed index supports 0 <= max_mismatch <= %d", MAX_SEG - 1);
             return BC_EINVAL;
+        }
+        if (algo == BC_ALGO_SEED && max_mm == 3 && lib->knobs.cascade == 2 && lib->d_pairs) {  // BC_CASCADE=2: tests, timing
+            int rc = launch_pairs(lib, max_mm, d_reads, d_flags, n, o, st);
+            if (rc != BC_OK) return rc;
+            note_kernel(lib, "k_match_pairs");
+            return BC_OK;
         }
         // the slab form serves k_match_wq (narrow and wide entries) and, narrow only, the quad / single slab kernels
         const SlabParams& hp = lib->slab[max_mm];
@@ -1916,11 +2072,13 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.tally = env_int("BC_TALLY", 0);
     lib->knobs.phase_prof = env_int("BC_PHASE_PROF", 0);
     lib->knobs.host_pin = env_int("BC_HOST_PIN", 1);
+    lib->knobs.cascade = env_int("BC_CASCADE", 1);
     lib->h_guides.assign(h_guides, h_guides + n_guides);
     int rc = dev_upload(lib, lib->h_guides, &lib->d_guides);
     if (rc == BC_OK) rc = compute_nn(lib);
     if (rc == BC_OK) rc = build_hash(lib);
     for (int d = 0; d < MAX_SEG && rc == BC_OK; ++d) rc = build_seed_index(lib, d);
+    if (rc == BC_OK) rc = build_pair_index(lib);
     if (rc != BC_OK) { bc_lib_destroy(lib); return rc; }
     *out = lib;
     return BC_OK;
@@ -1932,7 +2090,8 @@ int bc_lib_destroy(bc_lib* lib) {
     (void)hipDeviceSynchronize();
     for (void* p : lib->owned) (void)hipFree(p);
     for (auto& w : lib->ws)
-        for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile, (void*)w.c_idx, (void*)w.c_reads,
+                        (void*)w.c_best, (void*)w.c_dist, (void*)w.c_nb, (void*)w.c_count}) if (p) (void)hipFree(p);
     if (lib->host_slots) {
         HostSlot* hs = (HostSlot*)lib->host_slots;
         for (int w = 0; w < 3; ++w) {

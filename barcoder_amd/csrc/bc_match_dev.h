@@ -42,6 +42,11 @@ int launch_quad_fused(bc_lib* lib, int max_mm, const uint64_t* d_reads, const ui
 int launch_quad_slab(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
                      const MatchOut& o, hipStream_t st);
 
+// bc_match_pairs.hip: the pair index of the 3-mismatch matcher and its kernel (exact for any read, budget <= 3)
+int build_pair_index(bc_lib* lib);
+int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o,
+                 hipStream_t st);
+
 }  // namespace bc
 
 namespace {

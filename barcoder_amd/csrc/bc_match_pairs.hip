@@ -1,0 +1,199 @@
+// bc_match_pairs.hip — the 3-mismatch matcher (gfx950 only): a pigeonhole index on PAIRS of pieces.
+//
+// The d + 1 = 4 segment index of bc_match.hip keys every table on one 5-base segment of a 20-mer: ~G/1024 guides
+// per bucket, and a read that matches nothing closer pays for all four buckets (392 candidates at 1e5 guides: the
+// quad kernels spend their whole 10 ms per 1e8 reads on the tenth of the reads that reaches this far).  Cut the
+// k-mer into FIVE pieces instead: a guide within three substitutions leaves at least TWO pieces clean, so it shares
+// one of the C(5,2) = 10 piece pairs with the read.  Table (a, b) is keyed on piece a and the first bases of piece
+// b — about log4(G / 6) bases in all: 16 384 buckets of 6 guides at G = 1e5 — and a read visits ten 64-byte slabs
+// (61 candidates) instead of four chains of seven 128-byte slabs.
+//
+// A guide with more than two clean pieces sits in several of the read's buckets; it is counted in ONE: the table of
+// the lexicographically first pair of its clean pieces (the entry's mismatch mask tells which pieces are clean), so
+// n_best needs no candidate list.  The kernel is exact for any read and any budget <= 3 — best distance, lowest
+// index, tie count — and is used as the second stage of the d = 3 cascade (launch_cascade3 in bc_match.hip), where
+// only the reads the d <= 2 pass left without a hit arrive.  One lane per read: the stage sees a tenth of the reads
+// and is bound by its ten dependent-free L2 / Infinity-Cache requests per read, not by instructions.
+//
+// Geometry limits: 8-byte entries hold a rest of at most 16 bases per plane, so key >= k - 16 bases; the key is
+// capped at 9 bases (10 tables x 262 144 slabs).  k from 8 to 25; other lengths keep the four-segment index.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "bc_match_dev.h"
+
+namespace bc {
+
+BC_HD static inline uint32_t pair_drop(uint32_t v, uint32_t start, uint32_t len) {  // remove the bit field [start, start + len)
+    const uint32_t below = (1u << start) - 1u;
+    const uint32_t sh = start + len;
+    return (v & below) | ((sh >= 32u ? 0u : (v >> sh)) << start);
+}
+BC_HD static inline uint32_t pair_rest_plane(const PairTable& T, uint32_t plane) {
+    return pair_drop(pair_drop(plane, T.b_start, T.b_len), T.a_start, T.a_len);  // b lies above a
+}
+BC_HD static inline uint32_t pair_bucket(const PairTable& T, uint32_t lo, uint32_t hi) {
+    const uint32_t ma = (1u << T.a_len) - 1u, mb = (1u << T.b_len) - 1u, kb = T.a_len + T.b_len;
+    const uint32_t klo = ((lo >> T.a_start) & ma) | (((lo >> T.b_start) & mb) << T.a_len);
+    const uint32_t khi = ((hi >> T.a_start) & ma) | (((hi >> T.b_start) & mb) << T.a_len);
+    return klo | (khi << kb);
+}
+
+}  // namespace bc
+
+namespace {
+
+using namespace bc;
+
+__global__ __launch_bounds__(BLOCK) void k_match_pairs(const PairParams* __restrict__ ppp, const uint64_t* __restrict__ reads,
+                                                      const uint8_t* __restrict__ flags, uint64_t n, int k, uint64_t kmask,
+                                                      int max_mm, MatchOut o) {
+    const PairParams& pp = *ppp;
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t r = reads[i];
+    if (read_skipped(r, flags, i, k)) {
+        emit(o, i, BC_IDX_SKIP, BC_DIST_NONE, 0u);
+        return;
+    }
+    r &= kmask;
+    const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+    uint32_t mind = 0xFFu, cnt = 0u, bidx = 0xFFFFFFFFu;
+    for (int t = 0; t < pp.ntab; ++t) {
+        const PairTable& T = pp.t[t];
+        const uint32_t rest = pair_rest_plane(T, rlo) | (pair_rest_plane(T, rhi) << 16);
+        uint32_t slab = pair_bucket(T, rlo, rhi);
+        while (slab != 0xFFFFFFFFu) {
+            const uint4* p = reinterpret_cast<const uint4*>(T.slabs + (size_t)slab * 8u);
+            const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+            const uint32_t er[7] = {w0.x, w0.z, w1.x, w1.z, w2.x, w2.z, w3.x};
+            const uint32_t eg[7] = {w0.y, w0.w, w1.y, w1.w, w2.y, w2.w, w3.y};
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {
+                const uint32_t x = rest ^ er[e];
+                const uint32_t mm = (x | (x >> 16)) & 0xFFFFu;
+                const uint32_t d = (uint32_t)__popc(mm);
+                // counted here only if this table's pair is the first pair of the guide's clean pieces: what is left
+                // of pieces a and b is clean, every earlier piece is dirty
+                bool ok = eg[e] < SLAB_LINK && d <= (uint32_t)max_mm && (mm & T.must_clean) == 0u;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ok = ok && (c >= (int)T.n_other || (mm & T.other[c]) != 0u);
+                if (ok) {
+                    if (d < mind) { mind = d; cnt = 1u; bidx = eg[e]; }
+                    else if (d == mind) { ++cnt; bidx = min(bidx, eg[e]); }
+                }
+            }
+            slab = (w3.w == SLAB_LINK) ? w3.z : 0xFFFFFFFFu;  // the last slot: link or empty
+        }
+    }
+    if (mind <= (uint32_t)max_mm) emit(o, i, (int32_t)(bidx & SLAB_GIDX_MASK), mind, cnt > 255u ? 255u : cnt);
+    else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0u);
+}
+
+template <typename T>
+int upload(bc_lib* lib, const std::vector<T>& h, T** d) {
+    void* p = nullptr;
+    BC_HIP(hipMalloc(&p, std::max<size_t>(h.size() * sizeof(T), 16)));
+    lib->owned.push_back(p);
+    if (!h.empty()) BC_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *d = (T*)p;
+    return BC_OK;
+}
+
+}  // namespace
+
+namespace bc {
+
+int build_pair_index(bc_lib* lib) {
+    lib->d_pairs = nullptr;
+    const int k = lib->k;
+    if (k < 8 || k > 25 || lib->G >= (1u << SLAB_GIDX_BITS)) return BC_OK;  // other lengths: the four-segment index
+    // five pieces, the longer ones first
+    int p_start[5], p_len[5], at = 0;
+    for (int c = 0; c < 5; ++c) { p_len[c] = k / 5 + (c < k % 5 ? 1 : 0); p_start[c] = at; at += p_len[c]; }
+    // key length in bases: ~6 guides per bucket, at least k - 16 (the rest must fit 16 bases per plane), at most 9
+    int want = 1;
+    while (want < 9 && ((double)lib->G / (double)(1ull << (2 * want))) > 8.0) ++want;
+    want = std::max(want, k - 16);
+    if (want > 9) return BC_OK;
+    PairParams pp{};
+    pp.ntab = 0;
+    for (int a = 0; a < 5; ++a) {
+        for (int b = a + 1; b < 5; ++b) {
+            PairTable T{};
+            const int la = std::min(p_len[a], (want + 1) / 2 + std::max(0, (want / 2) - p_len[b]));
+            const int lb = std::min(p_len[b], want - la);
+            if (la < 1 || lb < 1 || k - la - lb > 16) return BC_OK;
+            T.a_start = (uint32_t)p_start[a]; T.a_len = (uint32_t)la;
+            T.b_start = (uint32_t)p_start[b]; T.b_len = (uint32_t)lb;
+            auto rest_mask = [&](int start, int len) {  // bases [start, start + len) in rest coordinates
+                const uint32_t m = len >= 32 ? 0xFFFFFFFFu : (((1u << len) - 1u) << start);
+                return pair_rest_plane(T, m);
+            };
+            T.must_clean = rest_mask(p_start[a] + la, p_len[a] - la) | rest_mask(p_start[b] + lb, p_len[b] - lb);
+            T.n_other = 0;
+            for (int c = 0; c < b; ++c)
+                if (c != a) T.other[T.n_other++] = rest_mask(p_start[c], p_len[c]);
+            // slabs of 7 entries + link, bucket = slab number, overflow slabs appended
+            const uint32_t nb = 1u << (2 * (la + lb));
+            std::vector<uint32_t> cnt(nb + 1, 0u);
+            std::vector<uint32_t> bucket_of(lib->G);
+            for (uint32_t g = 0; g < lib->G; ++g) {
+                const uint64_t v = lib->h_guides[g];
+                bucket_of[g] = pair_bucket(T, (uint32_t)v, (uint32_t)(v >> 32));
+                ++cnt[bucket_of[g] + 1];
+            }
+            for (uint32_t i = 0; i < nb; ++i) cnt[i + 1] += cnt[i];
+            std::vector<uint32_t> order(lib->G), fill(cnt.begin(), cnt.end() - 1);
+            for (uint32_t g = 0; g < lib->G; ++g) order[fill[bucket_of[g]]++] = g;  // ascending guide index inside a bucket
+            std::vector<uint2> slabs((size_t)nb * 8, make_uint2(0u, SLAB_EMPTY));
+            for (uint32_t bkt = 0; bkt < nb; ++bkt) {
+                size_t cur = bkt;
+                uint32_t pos = 0;
+                for (uint32_t j = cnt[bkt]; j < cnt[bkt + 1]; ++j) {
+                    if (pos == 7) {
+                        const size_t nxt = slabs.size() / 8;
+                        slabs.resize(slabs.size() + 8, make_uint2(0u, SLAB_EMPTY));
+                        slabs[cur * 8 + 7] = make_uint2((uint32_t)nxt, SLAB_LINK);
+                        cur = nxt;
+                        pos = 0;
+                    }
+                    const uint32_t g = order[j];
+                    const uint64_t v = lib->h_guides[g];
+                    slabs[cur * 8 + pos++] =
+                        make_uint2(pair_rest_plane(T, (uint32_t)v) | (pair_rest_plane(T, (uint32_t)(v >> 32)) << 16), g);
+                }
+            }
+            if ((slabs.size() / 8) >> 31) return BC_OK;
+            uint2* d_slabs;
+            int rc = upload(lib, slabs, &d_slabs);
+            if (rc != BC_OK) return rc;
+            T.slabs = d_slabs;
+            pp.t[pp.ntab++] = T;
+        }
+    }
+    std::vector<PairParams> one(1, pp);
+    PairParams* d_pp;
+    int rc = upload(lib, one, &d_pp);
+    if (rc != BC_OK) return rc;
+    lib->d_pairs = d_pp;
+    return BC_OK;
+}
+
+int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o,
+                 hipStream_t st) {
+    if (!lib->d_pairs) { set_error("bc_match: no pair index for k = %d", lib->k); return BC_EINVAL; }
+    if (n == 0) return BC_OK;
+    const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
+    if (blocks >> 31) { set_error("bc_match: launch too large"); return BC_EINVAL; }
+    hipLaunchKernelGGL(k_match_pairs, dim3((unsigned)blocks), dim3(BLOCK), 0, st, lib->d_pairs, d_reads, d_flags, n, lib->k,
+                       lib->kmask, max_mm, o);
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+}  // namespace bc

@@ -9,6 +9,6 @@ python3 - <<PY
 import csv,glob
 for f in glob.glob("gpurun_out/kt_$tag/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_match" in r["Name"] or "k_hist" in r["Name"]:
+        if "k_" in r["Name"]:
             print("$tag", r["Name"][:60].replace("(anonymous namespace)::",""), r["Calls"], "avg_us %.1f" % (float(r["AverageNs"])/1e3))
 PY

@@ -38,8 +38,9 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
     assert (res.best_idx >= 0).sum() > n // 2
     if algo == "seed":  # which kernel took it: the wave matcher for d = 1, 2 at every k (wide entries for k = 32)
         wide = k == 32
+        # d = 3 is a cascade: the d <= 2 pass over every read, the 3-mismatch kernels over the reads it left
         want = {0: "k_match_seed" if wide else "k_match_slab", 1: "k_match_wq", 2: "k_match_wq",
-                3: "k_match_seed" if wide else "k_match_fused"}[max_mm]
+                3: "k_match_seed" if wide else "cascade3:d2+k_match_pairs"}[max_mm]
         assert dl.last_kernel == want, (k, max_mm, dl.last_kernel)
 
 
@@ -47,7 +48,7 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
                                  {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4", "BC_SINGLE_SLAB": "1"},
                                  {"BC_SLAB_LOG2S": "3,3,3,3"}, {"BC_SLAB_LOG2S": "5,5,5,5"}, {"BC_SLAB_LOG2S": "4,3,5,4"},
                                  {"BC_SINGLE_SLAB": "1"}, {"BC_LANE": "0"}, {"BC_LANE": "0", "BC_PHASE2_SM": "0"},
-                                 {"BC_T2_FILTER": "0"},
+                                 {"BC_T2_FILTER": "0"}, {"BC_CASCADE": "0"}, {"BC_CASCADE": "2"},
                                  {"BC_HASH_SLOTS_PCT": "120"}, {"BC_HASH_SLOTS_PCT": "3000"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
     """Tally by global atomics vs LDS histogram vs records, wave vs quad vs single
@@ -405,3 +406,43 @@ def test_tally_export_and_reset(gpu_device):
         np.testing.assert_array_equal(f[seen], want.first_seen[seen].astype(np.int64))
         assert (f[~seen] == np.iinfo(np.int64).max).all()
         assert int(c32.sum().item()) == 0 and bool((fs == -1).all().item())
+
+
+@pytest.mark.parametrize("k", [8, 11, 16, 20, 25])
+@pytest.mark.parametrize("cluster", [0, 6])
+def test_three_mismatch_pair_index(gpu_device, oracle, k, cluster, monkeypatch):
+    """max_mismatch = 3 through the pair index (bc_match_pairs.hip): as the second stage of the cascade (default)
+    and over every read (BC_CASCADE=2), against the oracle and the four-segment kernels (BC_CASCADE=0).  Clustered
+    libraries put guides with three, four and five clean pieces next to each other: every one of them must be counted
+    once (first clean pair), ties at distance 1..3 included; reads with skip flags and a ragged launch size."""
+    n = 12011
+    rng = np.random.default_rng(5 + k + cluster)
+    if cluster:
+        centres = rng.integers(0, 4, size=(300, k))
+        fam = np.repeat(centres, cluster, axis=0)
+        fam = _mutate(rng, fam, rng.integers(0, 3, size=fam.shape[0]))
+        codes = np.unique(fam, axis=0)
+    else:
+        codes = np.unique(rng.integers(0, 4, size=(3000, k)), axis=0)
+    codes = codes[rng.permutation(codes.shape[0])]
+    G = codes.shape[0]
+    letters = np.array(list("ACGT"))
+    lib_s = ["".join(letters[r]) for r in codes]
+    nsub = rng.choice([0, 1, 2, 3, 4], size=n, p=[0.2, 0.2, 0.2, 0.3, 0.1])
+    rd = _mutate(rng, codes[rng.integers(0, G, size=n)], nsub)
+    rd[rng.random(n) < 0.05] = rng.integers(0, 4, size=k)
+    reads_s = ["".join(letters[r]) for r in rd]
+    lib, _ = E.pack_kmers(lib_s, k)
+    reads, _ = E.pack_kmers(reads_s, k)
+    flags = (rng.random(n) < 0.02).astype(np.uint8)
+    ref = oracle.best_hit(lib_s, reads_s, 3, skip=flags, base=9)
+    if k >= 16:  # (short k-mers: the library is dense, nearly every read has a guide within two)
+        assert (ref["best_dist"] == 3).sum() > 500
+        if cluster:
+            assert ((ref["n_best"] > 1) & (ref["best_dist"] == 3)).sum() > 50
+    for mode, want in (("1", "cascade3:d2+k_match_pairs"), ("2", "k_match_pairs"), ("0", None)):
+        monkeypatch.setenv("BC_CASCADE", mode)
+        dl = DeviceLibrary(lib, k, gpu_device)
+        _check(GpuMatcher(dl).match(reads, flags, max_mismatch=3, algo="seed", first_index=9), ref)
+        if want:  # (a dense library of short k-mers may leave the second stage nothing to do)
+            assert dl.last_kernel == want or (mode == "1" and k < 16 and dl.last_kernel == "cascade3:d2"), (mode, dl.last_kernel)
