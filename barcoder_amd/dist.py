@@ -142,11 +142,27 @@ def _group_backend():
     return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
-def reduce_counts(counts, first_seen=None, device=None):
+class Pending:
+    """Collectives started by reduce_counts(..., async_op=True): `wait()` before the tensors are read or reused
+    (on RCCL that orders the caller's stream behind the collective, it does not block the host)."""
+    def __init__(self, works=()):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def reduce_counts(counts, first_seen=None, device=None, async_op=False):
     """All-reduce SUM of int64 counts[G] and MIN of int64 first_seen[G] (I64_MAX
     = unseen) across the group.  numpy arrays in -> numpy arrays out on every
     rank; torch tensors are reduced in place on their device (staged through the
-    host when the group's backend is gloo and the tensor lives on a GPU)."""
+    host when the group's backend is gloo and the tensor lives on a GPU).
+
+    async_op (torch tensors only): start both collectives and return
+    (counts, first_seen, Pending) so that the next shard's matching overlaps them
+    (RCCL runs them on its own stream); the caller waits before touching the tensors."""
     import torch
     import torch.distributed as dist
     is_np = isinstance(counts, np.ndarray)
@@ -160,6 +176,7 @@ def reduce_counts(counts, first_seen=None, device=None):
             f = None if f is None else f.to(device)
     else:
         c, f = counts, first_seen
+    pending = Pending()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         gloo_on_gpu = _group_backend() == "gloo" and c.is_cuda
         for t, op in ((c, dist.ReduceOp.SUM), (f, dist.ReduceOp.MIN)):
@@ -169,10 +186,14 @@ def reduce_counts(counts, first_seen=None, device=None):
                 h = t.cpu()
                 dist.all_reduce(h, op=op)
                 t.copy_(h)
+            elif async_op and not is_np:
+                pending.works.append(dist.all_reduce(t, op=op, async_op=True))
             else:
                 dist.all_reduce(t, op=op)
     if is_np:
         return c.cpu().numpy(), (None if f is None else f.cpu().numpy())
+    if async_op:
+        return c, f, pending
     return c, f
 
 
@@ -205,7 +226,7 @@ def gather_objects(obj):
     return out
 
 
-def count_sharded(n_total: int, match_shard, n_guides: int, rank: int, world: int, device=None):
+def count_sharded(n_total: int, match_shard, n_guides: int, rank: int, world: int, device=None, async_op=False):
     """Run `match_shard(a, b) -> (counts[G], first_seen[G])` on this rank's read
     range and combine over ranks.  `first_seen` carries GLOBAL read indices, so
     MIN over ranks is the job-wide first occurrence.  numpy arrays (uint64,
@@ -216,7 +237,7 @@ def count_sharded(n_total: int, match_shard, n_guides: int, rank: int, world: in
     else:
         counts = np.zeros(n_guides, np.uint64)
         first_seen = np.full(n_guides, U64_MAX, np.uint64)
-    return reduce_counts(counts, first_seen, device=device)
+    return reduce_counts(counts, first_seen, device=device, async_op=async_op and not isinstance(counts, np.ndarray))
 
 
 def shutdown():

@@ -264,9 +264,14 @@ def run(args):
     best_dist = torch.empty(n, dtype=torch.uint8, device=dev)
     n_best = torch.empty(n, dtype=torch.uint8, device=dev)
     counts32 = torch.zeros(Gn, dtype=torch.int32, device=dev)
-    counts64 = torch.zeros(Gn, dtype=torch.int64, device=dev)
     first_seen = torch.full((Gn,), -1, dtype=torch.int64, device=dev)  # 0xFFFF.. = unseen
-    first_min = torch.empty(Gn, dtype=torch.int64, device=dev)
+    # job-wide results, double-buffered: the all-reduce of one step runs (on RCCL's stream) under the next step's
+    # matcher; a buffer is reused only after its collectives have been waited for
+    out_c = [torch.zeros(Gn, dtype=torch.int64, device=dev) for _ in range(2)]
+    out_f = [torch.empty(Gn, dtype=torch.int64, device=dev) for _ in range(2)]
+    pending = [D.Pending(), D.Pending()]
+    overlap = world > 1 and os.environ.get("BC_BENCH_ASYNC_REDUCE", "1") != "0"
+    turn = [0]
     first = rank * n  # global index of this rank's first read (weak scaling: n per GPU)
     m.synth_reads_dev(seed, first, n, args.mixture, reads.data_ptr(), stream)
     torch.cuda.synchronize()
@@ -278,15 +283,30 @@ def run(args):
                     d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), d_counts=counts32.data_ptr(),
                     d_first_seen=first_seen.data_ptr(), first_index=first, stream=stream)
         # one launch: 64-bit sums, unseen -> the identity of MIN over int64, accumulators reset for the next pass
-        m.tally_export_dev(counts32.data_ptr(), first_seen.data_ptr(), counts64.data_ptr(), first_min.data_ptr(),
+        b_ = turn[0]
+        pending[b_].wait()  # the collectives that last used this buffer (two steps ago)
+        m.tally_export_dev(counts32.data_ptr(), first_seen.data_ptr(), out_c[b_].data_ptr(), out_f[b_].data_ptr(),
                            reset=True, stream=stream)
-        return counts64, first_min
+        return out_c[b_], out_f[b_]
 
     def step():
-        return D.count_sharded(world * n, match_shard, Gn, rank, world, device=dev)
+        """One pass over this rank's shard + the job-wide reduction (started here; awaited before its buffer is
+        reused, and by finish() at the end of the timed region)."""
+        b_ = turn[0]
+        if overlap:
+            c, f, pending[b_] = D.count_sharded(world * n, match_shard, Gn, rank, world, device=dev, async_op=True)
+        else:
+            c, f = D.count_sharded(world * n, match_shard, Gn, rank, world, device=dev)
+        turn[0] ^= 1
+        return c, f
+
+    def finish():
+        for p_ in pending:
+            p_.wait()
 
     for _ in range(args.warmup):
         step()
+    finish()
     D.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -295,6 +315,7 @@ def run(args):
     for i in range(args.steps):
         step()
         marks[i + 1].record()
+    finish()  # every step's job-wide result is complete inside the timed region
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
@@ -302,6 +323,7 @@ def run(args):
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     med_ms = D.reduce_scalar_max(statistics.median(step_ms), device=dev)
     job_counts, job_first = step()  # the job-wide result (identical on every rank)
+    finish()
     total_hits = int(job_counts.sum().item())
 
     # dominant kernel alone (the matcher without the tally), HIP events on the launch stream: roofline.achieved;

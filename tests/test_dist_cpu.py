@@ -38,6 +38,20 @@ def _worker(rank, world, port, n_total, G, out_dir):
         return res["counts"], res["first_seen"]
 
     counts, first = D.count_sharded(n_total, match_shard, G, r, w)
+    # the same reduction on torch tensors, started asynchronously and awaited (bench.py runs it under the next pass)
+    import torch
+    a, b = D.shard_range(n_total, r, w)
+    if b > a:
+        lc, lf = match_shard(a, b)
+    else:
+        lc, lf = np.zeros(G, np.uint64), np.full(G, D.U64_MAX, np.uint64)
+    tc = torch.from_numpy(np.asarray(lc).astype(np.int64))
+    tf = torch.from_numpy(np.minimum(np.asarray(lf, np.uint64), np.uint64(D.I64_MAX)).astype(np.int64))
+    tc, tf, pend = D.reduce_counts(tc, tf, async_op=True)
+    assert len(pend.works) == 2
+    pend.wait()
+    assert np.array_equal(tc.numpy(), np.asarray(counts).astype(np.int64))
+    assert np.array_equal(tf.numpy(), np.asarray(first).astype(np.int64))
     np.save(os.path.join(out_dir, f"counts_{rank}.npy"), counts)
     np.save(os.path.join(out_dir, f"first_{rank}.npy"), first)
     dist.barrier()
