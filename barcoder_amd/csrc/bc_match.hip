@@ -12,8 +12,10 @@
 //                    the exact stage); a wave owns 256 reads, quad-cooperative slab loads for
 //                    the full-width stages, a quad work list for the sparse ones, a filter line
 //                    in front of table 2.
-//   k_match_fused  : previous generation (hash stage + LDS queue + DPP quad per queued read):
-//                    d = 3, buckets above 16 guides (libraries above ~2.6e5 20-mers), BC_LANE=0.
+//   cascade (d = 3): k_match_wq at d <= 2 over every read, then the reads it left through the
+//                    pair-of-pieces index (k_match_pairs, bc_match_pairs.hip); launch_cascade3.
+//   k_match_fused  : previous generation (bc_match_quad.hip: hash stage + LDS queue + DPP quad per
+//                    queued read): buckets above 40 guides (libraries above ~6.5e5 20-mers), BC_LANE=0.
 //   k_match_slab   : the slab index as one simple kernel (small / unaligned inputs, d = 0 via seed).
 //   k_match_seed   : CSR form of the seed index, lane = read (k - seed > 16 bases, huge libraries).
 //   k_match_all    : every (query, guide, dist) within d, optionally gated by a PAM bitmap:
@@ -23,9 +25,9 @@
 //   k_hist_part + k_first_refine : per-guide counts / first-seen from the range-partitioned
 //                    records the matchers write while a tile's results are on chip;
 //   k_hist         : the same from best_idx, one sweep per guide range (other kernels, few ranges).
-// Bounds (measured): the lookup kernels sit on the L2's random-request rate
-// under a concurrent stream (~1.1 requests per read is the floor: 0.67 ms per 1e8 reads) and on
-// VALU issue (86 %) at the same time; the tally kernels are HBM streams.
+// Bounds (measured): the lookup kernels sit on the rate of 64-byte L2 requests
+// under a concurrent stream (~165 G/s; 1.1 requests per read is the floor: 0.66 ms per 1e8 reads;
+// k_match_wq makes 1.79); the tally kernels are HBM streams.
 #include <string.h>
 #include <dlfcn.h>
 #include <math.h>
