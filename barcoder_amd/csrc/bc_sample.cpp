@@ -102,6 +102,7 @@ struct StrSet {
         }
     }
     bool contains(std::string_view v) const { return contains(str_hash(v), v); }
+    void prefetch(uint64_t h) const { __builtin_prefetch(&tab[(size_t)h & mask]); }
     void grow() {
         std::vector<Slot> old;
         old.swap(tab);
@@ -172,7 +173,19 @@ int next_chunk(bc_reader* r, uint64_t want, Chunk& c) {
     return BC_OK;
 }
 
+constexpr int PF_SMALL_BITS = 20;
 constexpr int PF_BITS = 24;  // bits of the pre-filter table (2 MiB): 20 / 22 / 24 / 26 measured 1.00 / 0.84 / 0.75 / 0.75 s per sampling pass
+// base code by table (a switch on sequence characters mispredicts on nearly every base)
+struct CodeTable {
+    unsigned char t[256];
+    constexpr CodeTable() : t() {
+        for (int i = 0; i < 256; ++i) t[i] = 4;
+        t[(int)'A'] = 0; t[(int)'C'] = 1; t[(int)'G'] = 2; t[(int)'T'] = 3;
+    }
+    constexpr unsigned char operator[](unsigned char c) const { return t[c]; }
+};
+constexpr CodeTable kCode{};
+
 // rolling 2-bit value of the k-mer window at position i of a read (positions visited in ascending order)
 struct Roll {
     int k;
@@ -181,15 +194,20 @@ struct Roll {
     int run = 0;       // ACGT characters in a row up to `next`
     explicit Roll(int k_) : k(k_), mask(k_ >= 32 ? ~0ull : ((1ull << (2 * k_)) - 1ull)) {}
     static uint32_t hash(uint64_t v) { return (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> (64 - PF_BITS)); }
+    // first level: 2^20 bits (128 KiB, stays in the core's L2) under an independent hash; at 2e5 keys it turns away
+    // five windows in six before the 2 MiB table (an L3 access per window otherwise: two thirds of the sampler's time)
+    static uint32_t hash_small(uint64_t v) { return (uint32_t)((v * 0xD6E8FEB86659FD93ull) >> (64 - PF_SMALL_BITS)); }
     // can the window [i, i + k) be a library entry?  (pure ACGT and its hash bit is set)
-    bool at(std::string_view s, size_t i, const std::vector<uint64_t>& bits) {
+    bool at(std::string_view s, size_t i, const std::vector<uint64_t>& bits, const std::vector<uint64_t>& small) {
         const size_t end = i + (size_t)k;
         for (; next < end; ++next) {
-            const int c = base_code((unsigned char)s[next]);
+            const int c = kCode[(unsigned char)s[next]];
             if (c < 4) { v = ((v << 2) | (uint64_t)c) & mask; ++run; }
             else { v = (v << 2) & mask; run = 0; }
         }
         if (run < k) return false;
+        const uint32_t hs = hash_small(v);
+        if (!((small[hs >> 6] >> (hs & 63)) & 1ull)) return false;
         const uint32_t h = hash(v);
         return (bits[h >> 6] >> (h & 63)) & 1ull;
     }
@@ -239,15 +257,17 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     bool prefilter = k <= 32;
     for (uint32_t g = 0; g < G && prefilter; ++g)
         for (int j = 0; j < k; ++j) prefilter = prefilter && base_code((unsigned char)fwd_store[g][j]) < 4;
-    std::vector<uint64_t> pf_bits;
+    std::vector<uint64_t> pf_bits, pf_small;
     if (prefilter) {
         pf_bits.assign((1u << PF_BITS) / 64, 0);
+        pf_small.assign((1u << PF_SMALL_BITS) / 64, 0);
         for (uint32_t g = 0; g < G; ++g)
             for (const std::string* sp : {&fwd_store[g], &rev_store[g]}) {
                 uint64_t v = 0;
                 for (int j = 0; j < k; ++j) v = (v << 2) | (uint64_t)base_code((unsigned char)(*sp)[j]);
-                const uint32_t h = Roll::hash(v);
+                const uint32_t h = Roll::hash(v), hs = Roll::hash_small(v);
                 pf_bits[h >> 6] |= 1ull << (h & 63);
+                pf_small[hs >> 6] |= 1ull << (hs & 63);
             }
     }
     bc_reader *r1 = nullptr, *r2 = nullptr;
@@ -278,12 +298,97 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         // zip(read1_chunk, read2_chunk if read2_chunk else [None]*len): an EMPTY mate chunk means "None" mates
         const bool have2 = paired && c2.n > 0;
         const uint64_t nz = have2 ? std::min(c1.n, c2.n) : c1.n;
+        // Single-end input with the pre-filter: the set look-ups of a read are independent cache misses into tables of
+        // several MB.  A few reads ahead of the one being processed, hash the read, sweep its windows through the
+        // pre-filter, hash the windows that pass and prefetch every slot the read will touch; the processing below then
+        // runs the reference's sequential logic unchanged on warm lines.
+        constexpr uint64_t AHEAD = 12;
+        constexpr int MAXC = 6;
+        struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint64_t hk[MAXC]; };
+        Ahead ring[AHEAD];
+        const bool lookahead = !paired && prefilter;
+        auto prepare = [&](uint64_t q) {
+            Ahead& a = ring[q % AHEAD];
+            const std::string_view rd = c1.read(q);
+            a.h1 = str_hash(rd);
+            a.ncand = 0;
+            a.overflow = false;
+            c_reads.prefetch(a.h1); seen_reads.prefetch(a.h1); valid[0].prefetch(a.h1);
+            if ((int64_t)rd.size() < k) return;
+            // one pass over the characters: rolling packed value, length of the current ACGT run, both filter levels
+            const uint64_t kmask2 = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+            const uint64_t* const small = pf_small.data();
+            const uint64_t* const big = pf_bits.data();
+            uint64_t v = 0;
+            int run = 0;
+            const size_t len = rd.size();
+            for (size_t e = 0; e < len; ++e) {
+                const unsigned c = kCode[(unsigned char)rd[e]];
+                v = ((v << 2) | (c & 3u)) & kmask2;
+                run = c < 4 ? run + 1 : 0;
+                if (run < k) continue;
+                const uint32_t hs = Roll::hash_small(v);
+                if (!((small[hs >> 6] >> (hs & 63)) & 1ull)) continue;
+                const uint32_t hb = Roll::hash(v);
+                if (!((big[hb >> 6] >> (hb & 63)) & 1ull)) continue;
+                if (a.ncand == MAXC) { a.overflow = true; break; }
+                const size_t i = e + 1 - (size_t)k;
+                const uint64_t hk = str_hash(rd.substr(i, k));
+                a.pos[a.ncand] = (uint32_t)i; a.hk[a.ncand] = hk; ++a.ncand;
+                c_barcodes.prefetch(hk); fwd.prefetch(hk); rev.prefetch(hk); observed.prefetch(hk);
+            }
+        };
+        if (lookahead)
+            for (uint64_t q = 0; q < std::min<uint64_t>(AHEAD, nz); ++q) prepare(q);
         for (uint64_t q = 0; q < nz; ++q) {
             const std::string_view read1 = c1.read(q);
             const std::string_view read2 = have2 ? c2.read(q) : std::string_view();
             any_read = true;
             last1_truthy = !read1.empty();
             last2_truthy = have2 && !read2.empty();
+            if (lookahead) {
+                const Ahead a = ring[q % AHEAD];  // (copied: the slot is reused for read q + AHEAD right away)
+                if (q + AHEAD < nz) prepare(q + AHEAD);
+                const uint64_t h1 = a.h1;
+                if (c_reads.contains(h1, read1)) continue;
+                seen_reads.insert(h1, read1);
+                if ((int64_t)read1.size() < k) continue;
+                if (!a.overflow) {
+                    // the windows that pass the pre-filter, in ascending position: exactly the iterations of the loop
+                    // below that do anything
+                    for (int c = 0; c < a.ncand; ++c) {
+                        const size_t i = a.pos[c];
+                        const uint64_t hk = a.hk[c];
+                        const std::string_view kmer = read1.substr(i, k);
+                        if (c_barcodes.contains(hk, kmer)) continue;
+                        for (int lib = 0; lib < 2; ++lib)
+                            if ((lib == 0 ? fwd : rev).contains(hk, kmer)) {
+                                div[0]++; c_barcodes.insert(hk, kmer); observed.insert(hk, kmer);
+                                c_or[0].push_back(lib); c_off[0].push_back((int64_t)i);
+                                if (valid[0].insert(h1, read1)) valid_store[0].emplace_back(read1);
+                                c_reads.insert(h1, read1);
+                            }
+                    }
+                    continue;
+                }
+                // more candidate windows than the look-ahead keeps: the plain sweep (the sets are idempotent up to here:
+                // nothing of this read has been entered yet except seen_reads)
+                Roll roll1(k);
+                for (size_t i = 0; i + k <= read1.size(); ++i) {
+                    const std::string_view kmer = read1.substr(i, k);
+                    if (!roll1.at(read1, i, pf_bits, pf_small)) continue;
+                    const uint64_t hk = str_hash(kmer);
+                    if (c_barcodes.contains(hk, kmer)) continue;
+                    for (int lib = 0; lib < 2; ++lib)
+                        if ((lib == 0 ? fwd : rev).contains(hk, kmer)) {
+                            div[0]++; c_barcodes.insert(hk, kmer); observed.insert(hk, kmer);
+                            c_or[0].push_back(lib); c_off[0].push_back((int64_t)i);
+                            if (valid[0].insert(h1, read1)) valid_store[0].emplace_back(read1);
+                            c_reads.insert(h1, read1);
+                        }
+                }
+                continue;
+            }
             const uint64_t h1 = str_hash(read1), h2 = last2_truthy ? str_hash(read2) : 0;
             if (c_reads.contains(h1, read1) || (last2_truthy && c_reads.contains(h2, read2))) continue;
             seen_reads.insert(h1, read1);
@@ -294,7 +399,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 const std::string_view kmer = read1.substr(i, k);
                 // pre-filter: a window that cannot be a library entry (or its reverse complement) takes none of the
                 // set look-ups below — they would all miss (c_barcodes only ever holds k-mers found in a set)
-                const bool maybe1 = !prefilter || roll1.at(read1, i, pf_bits);
+                const bool maybe1 = !prefilter || roll1.at(read1, i, pf_bits, pf_small);
                 const uint64_t hk = maybe1 ? str_hash(kmer) : 0;
                 if (maybe1 && c_barcodes.contains(hk, kmer)) continue;
                 if (maybe1) for (int lib = 0; lib < 2; ++lib)
@@ -306,7 +411,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                     }
                 if (paired && have2) {
                     const std::string_view kmer2 = i < read2.size() ? read2.substr(i, k) : std::string_view();
-                    if (prefilter && (kmer2.size() != (size_t)k || !roll2.at(read2, i, pf_bits))) continue;  // same argument
+                    if (prefilter && (kmer2.size() != (size_t)k || !roll2.at(read2, i, pf_bits, pf_small))) continue;  // same argument
                     const uint64_t hk2 = str_hash(kmer2);
                     if (c_barcodes.contains(hk2, kmer2)) continue;
                     for (int lib = 0; lib < 2; ++lib)
