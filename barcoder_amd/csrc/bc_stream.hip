@@ -16,6 +16,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -184,6 +185,23 @@ int grid_for(uint64_t items) {
     return (int)std::max<uint64_t>(1, std::min<uint64_t>(b, 4096));
 }
 
+// newlines in [p, p + n): the one pass the host makes over the text (a chunk's line count orders the chunks)
+__attribute__((target("avx2"))) static uint64_t count_nl_avx2(const uint8_t* p, uint64_t n) {
+    const __m256i nl = _mm256_set1_epi8('\n');
+    uint64_t c = 0, i = 0;
+    for (; i + 32 <= n; i += 32)
+        c += (uint64_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i)), nl)));
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+static uint64_t count_nl(const uint8_t* p, uint64_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return count_nl_avx2(p, n);
+    uint64_t c = 0;
+    for (uint64_t i = 0; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -217,7 +235,15 @@ struct Slot {  // one worker's buffers
 struct bc_stream_result {
     uint64_t n_reads = 0;
     double seconds = 0;
-    std::vector<uint64_t> u_words, u_counts, u_first;
+    // the table of undocumented windows stays on the device until the caller hands over its arrays
+    // (bc_stream_result_undoc copies straight into them: 24 bytes x 2.5e7 entries on the benchmark file)
+    int device = 0;
+    uint64_t n_undoc = 0;
+    uint64_t *d_words = nullptr, *d_counts = nullptr, *d_first = nullptr;
+    ~bc_stream_result() {
+        if (d_words || d_counts || d_first) (void)hipSetDevice(device);
+        for (void* q : {(void*)d_words, (void*)d_counts, (void*)d_first}) if (q) (void)hipFree(q);
+    }
     std::vector<uint64_t> odd_keys, odd_off;  // odd_off: n_odd + 1 offsets into odd_text
     std::string odd_text;
 };
@@ -233,7 +259,7 @@ int bc_stream_result_info(const bc_stream_result* r, uint64_t* n_reads, uint64_t
                           uint64_t* odd_bytes, double* seconds) {
     if (!r) { set_error("bc_stream_result_info: null"); return BC_EINVAL; }
     if (n_reads) *n_reads = r->n_reads;
-    if (n_undoc) *n_undoc = r->u_words.size();
+    if (n_undoc) *n_undoc = r->n_undoc;
     if (n_odd) *n_odd = r->odd_keys.size();
     if (odd_bytes) *odd_bytes = r->odd_text.size();
     if (seconds) *seconds = r->seconds;
@@ -241,10 +267,12 @@ int bc_stream_result_info(const bc_stream_result* r, uint64_t* n_reads, uint64_t
 }
 
 int bc_stream_result_undoc(const bc_stream_result* r, uint64_t* words, uint64_t* counts, uint64_t* first) {
-    if (!r || ((!words || !counts || !first) && !r->u_words.empty())) { set_error("bc_stream_result_undoc: null"); return BC_EINVAL; }
-    std::copy(r->u_words.begin(), r->u_words.end(), words);
-    std::copy(r->u_counts.begin(), r->u_counts.end(), counts);
-    std::copy(r->u_first.begin(), r->u_first.end(), first);
+    if (!r || ((!words || !counts || !first) && r->n_undoc)) { set_error("bc_stream_result_undoc: null"); return BC_EINVAL; }
+    if (!r->n_undoc) return BC_OK;
+    BC_HIP(hipSetDevice(r->device));
+    BC_HIP(hipMemcpy(words, r->d_words, r->n_undoc * 8, hipMemcpyDeviceToHost));
+    BC_HIP(hipMemcpy(counts, r->d_counts, r->n_undoc * 8, hipMemcpyDeviceToHost));
+    BC_HIP(hipMemcpy(first, r->d_first, r->n_undoc * 8, hipMemcpyDeviceToHost));
     return BC_OK;
 }
 
@@ -332,6 +360,8 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
         order_cv.notify_all();
     };
 
+    std::atomic<uint64_t> prof_us[5];
+    for (auto& x : prof_us) x = 0;
     auto work = [&](int ti) {
         Slot& s = slots[(size_t)ti];
         auto body = [&]() -> int {
@@ -342,9 +372,14 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
             BC_HIP(hipMalloc((void**)&s.d_nodd, 16));
             int rc2;
             if ((rc2 = s.text.reserve(1 + CHUNK + SLACK + 64)) != BC_OK) return rc2;
+            auto tick = [] { return std::chrono::steady_clock::now(); };
+            auto since = [](std::chrono::steady_clock::time_point a) {
+                return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - a).count();
+            };
             for (;;) {
                 const uint64_t c = next_chunk.fetch_add(1);
                 if (c >= n_chunks || first_rc.load() != BC_OK) break;
+                auto t_a = tick();
                 // ---- read: bytes [base, hi) of the file; the chunk owns newlines in [own_lo, own_hi)
                 const uint64_t core_lo = byte_begin + c * CHUNK, core_hi = std::min(byte_end, core_lo + CHUNK);
                 const int virt = (c == 0) ? 1 : 0;                 // the line at the start of the range
@@ -360,9 +395,12 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                 // owned newlines: file positions [core_lo - 1, core_hi - 1) = buffer offsets [0, own_hi); the first chunk
                 // starts at the range's first line instead (a virtual newline in front of it).  The newline at
                 // core_hi - 1 belongs to the next chunk — or to the next range, or ends the file.
+                prof_us[0] += since(t_a);
+                t_a = tick();
                 const uint64_t own_hi = core_hi - 1 - base;
-                uint64_t n_real = 0;
-                for (uint64_t i = 0; i < own_hi; ++i) n_real += (s.h_text[i] == '\n');
+                const uint64_t n_real = count_nl(s.h_text, own_hi);
+                prof_us[1] += since(t_a);
+                t_a = tick();
                 const uint64_t n_own = n_real + (uint64_t)virt;
                 // ---- position in the run: lines and reads in front of this chunk
                 uint64_t line_base, reads_before;
@@ -379,6 +417,8 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                     ++next_to_publish;
                 }
                 order_cv.notify_all();
+                prof_us[2] += since(t_a);
+                t_a = tick();
                 const uint64_t gri0 = g.fastq ? ((line_base + 2) >> 2) : line_base;
                 const uint64_t gri1 = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
                 const uint64_t n_reads = gri1 - gri0;
@@ -435,7 +475,10 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                 // ---- odd windows: their text is still in the pinned buffer
                 uint32_t fl[2] = {0, 0};
                 BC_HIP(hipMemcpyAsync(fl, s.d_nodd, 8, hipMemcpyDeviceToHost, s.st));
+                prof_us[3] += since(t_a);
+                t_a = tick();
                 BC_HIP(hipStreamSynchronize(s.st));
+                prof_us[4] += since(t_a);
                 if (fl[1]) { set_error("%s: a line longer than %llu bytes", path, (unsigned long long)SLACK); return BC_EINVAL; }
                 const uint32_t n_odd = fl[0];
                 if (n_odd > odd_cap) { set_error("%s: more than %u odd windows in one chunk", path, odd_cap); return BC_EINVAL; }
@@ -453,6 +496,7 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
         const int code = body();
         if (code != BC_OK) fail(code);
     };
+    const auto t_workers = std::chrono::steady_clock::now();
     if (T == 1) {
         work(0);
     } else {
@@ -460,6 +504,10 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
         for (int ti = 0; ti < T; ++ti) th.emplace_back(work, ti);
         for (auto& t : th) t.join();
     }
+    if (getenv("BC_STREAM_PROF"))
+        fprintf(stderr, "stream: %d threads, workers %.3f s; per-thread-summed ms: pread %.0f count %.0f order %.0f launch %.0f sync %.0f\n", T,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_workers).count(), prof_us[0] / 1e3,
+                prof_us[1] / 1e3, prof_us[2] / 1e3, prof_us[3] / 1e3, prof_us[4] / 1e3);
     if (first_rc.load() != BC_OK) {
         set_error("%s", err.c_str());
         delete res;
@@ -519,10 +567,10 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
             BC_HIP(hipDeviceSynchronize());
             uint64_t n_u = 0;
             BC_HIP(hipMemcpy(&n_u, un.p, 8, hipMemcpyDeviceToHost));
-            res->u_words.resize(n_u); res->u_first.resize(n_u); res->u_counts.resize(n_u);
-            BC_HIP(hipMemcpy(res->u_words.data(), uw.p, n_u * 8, hipMemcpyDeviceToHost));
-            BC_HIP(hipMemcpy(res->u_first.data(), uf.p, n_u * 8, hipMemcpyDeviceToHost));
-            BC_HIP(hipMemcpy(res->u_counts.data(), uc.p, n_u * 8, hipMemcpyDeviceToHost));
+            res->device = device;
+            res->n_undoc = n_u;
+            res->d_words = (uint64_t*)uw.p; res->d_first = (uint64_t*)uf.p; res->d_counts = (uint64_t*)uc.p;
+            uw.p = nullptr; uf.p = nullptr; uc.p = nullptr;  // ownership moves to the result
         }
         std::sort(odd_all.begin(), odd_all.end(), [](const OddOut& a, const OddOut& b) { return a.key < b.key; });
         res->odd_off.push_back(0);
