@@ -577,6 +577,10 @@ def main(args, device: int = 0, out=None):
         out.write(to_tsv(cols, table))
     lens = sorted({r["len"] for r in table})
     targeting = {r["spacer"] for r in table if r.get("target") is not None}
+    coords_of = {}
+    for r in table:
+        if r.get("target"):
+            coords_of.setdefault(r["spacer"], set()).add(r["coords"])
     summary = [("Barcodes", os.path.basename(args.sgrna_file)), ("Genbank Genome File", os.path.basename(args.genome_file)),
                ("PAM", args.pam), ("PAM Direction", args.pam_direction.capitalize()),
                ("Number of Mismatches", args.mismatches), ("Spacer Lengths", ",".join(str(x) for x in lens)),
@@ -587,9 +591,7 @@ def main(args, device: int = 0, out=None):
                ("Genes Targeted", len({r["locus_tag"] for r in table if r.get("locus_tag")})),
                ("Unique Barcodes", len({r["spacer"] for r in table})),
                ("Intergenic Barcodes", len({r["spacer"] for r in table if r.get("locus_tag") is None and r.get("chr")})),
-               ("Off-targeting Barcodes", sum(1 for sp in targeting
-                                              if len({r["coords"] for r in table if r["spacer"] == sp and r.get("target")}) > 1)
-                if len(targeting) < 20000 else "n/a"),
+               ("Off-targeting Barcodes", sum(1 for sp in targeting if len(coords_of.get(sp, ())) > 1)),
                ("Non-targeting Barcodes", len({r["spacer"] for r in table if r.get("target") is None}))]
     for k_, v in summary:
         log(f"{k_:>30}  {v}")

@@ -31,5 +31,8 @@ echo "d3 kernels" >> $OUT/progress.log
 bash profiles/ktime.sh d3 --max-mismatch 3 > $OUT/${TAG}_d3_kernels.txt 2>&1
 echo "e2e" >> $OUT/progress.log
 python3 profiles/e2e_bench.py 1e8 > $OUT/${TAG}_e2e_bench.txt 2>&1
+echo "targets" >> $OUT/progress.log
+python3 profiles/targets_bench.py 20000 1 > $OUT/${TAG}_targets_bench.txt 2>&1
+python3 profiles/targets_bench.py 100000 1 >> $OUT/${TAG}_targets_bench.txt 2>&1
 echo done >> $OUT/progress.log
 tail -c 400 $OUT/${TAG}_bench_n1.json
