@@ -162,7 +162,8 @@ struct bc_lib {
     bool slab_ok[bc::MAX_SEG] = {false, false, false, false};
     bool slab_wide[bc::MAX_SEG] = {false, false, false, false};  // wide entries: only k_match_wq reads them
     const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
-    const bc::PairParams* d_pairs = nullptr;   // 3-mismatch pair index (NULL: k outside 8..25)
+    const bc::PairParams* d_pairs = nullptr;   // 3-mismatch pair index (NULL: not built yet, or k outside 8..25)
+    bool pairs_tried = false;                  // under ws_mutex
     bc::Knobs knobs;
     std::deque<bc::TallyWs> ws;    // tally workspaces by stream (deque: pointers stay valid as it grows)
     std::mutex ws_mutex;

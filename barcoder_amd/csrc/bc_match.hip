@@ -1622,6 +1622,15 @@ int launch_hist_part(bc_lib* lib, const MatchOut& o, const TallyWs* w, uint64_t 
 // which kernel ran last (tests assert the path, bc_lib_last_kernel)
 void note_kernel(bc_lib* lib, const char* name) { lib->last_kernel.store(name, std::memory_order_relaxed); }
 
+// the pair index is built when a 3-mismatch search first asks for it (ten tables: 13 MB and ~50 ms at 1e5 guides)
+int ensure_pair_index(bc_lib* lib) {
+    std::lock_guard<std::mutex> g(lib->ws_mutex);
+    if (lib->pairs_tried) return BC_OK;
+    int rc = build_pair_index(lib);
+    if (rc == BC_OK) lib->pairs_tried = true;
+    return rc;
+}
+
 // max_mismatch = 3 as a cascade (see k_collect_missed).  One host synchronisation per launch: the number of reads left
 // for the second stage sizes its grid.
 int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o_in, hipStream_t st) {
@@ -1695,8 +1704,11 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     if (algo == BC_ALGO_AUTO) algo = (max_mm == 0) ? BC_ALGO_HASH : BC_ALGO_SEED;
     // d = 3: the d <= 2 pass, then the pair index for the reads it left (without a pair index — k outside 8..25 — the
     // four-segment kernels take every read: they spend their time on exactly those reads either way)
-    if (algo == BC_ALGO_SEED && max_mm == 3 && lib->knobs.cascade == 1 && lib->d_pairs && aligned16(o_in.best_idx))
-        return launch_cascade3(lib, d_reads, d_flags, n, o_in, st);
+    if (algo == BC_ALGO_SEED && max_mm == 3 && lib->knobs.cascade) {
+        int rc = ensure_pair_index(lib);
+        if (rc != BC_OK) return rc;
+        if (lib->knobs.cascade == 1 && lib->d_pairs && aligned16(o_in.best_idx)) return launch_cascade3(lib, d_reads, d_flags, n, o_in, st);
+    }
     // tally: in-kernel global atomics for small launches; otherwise LDS-privatised, from the matcher's range-partitioned
     // records (k_hist_part) when the kernel that runs can write them, else by sweeping best_idx once per range (k_hist)
     const int tally_mode = lib->knobs.tally;  // 0 auto, 1 atomics, 2 k_hist, 3 records when possible
@@ -2080,7 +2092,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     if (rc == BC_OK) rc = compute_nn(lib);
     if (rc == BC_OK) rc = build_hash(lib);
     for (int d = 0; d < MAX_SEG && rc == BC_OK; ++d) rc = build_seed_index(lib, d);
-    if (rc == BC_OK) rc = build_pair_index(lib);
+    // (the pair index of the 3-mismatch matcher is built on first use: ensure_pair_index)
     if (rc != BC_OK) { bc_lib_destroy(lib); return rc; }
     *out = lib;
     return BC_OK;
