@@ -430,7 +430,7 @@ __device__ __forceinline__ void slab_slow_wide(const SlabParams& sp, uint32_t rl
 // ---------------------------------------------------------------------------
 constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 64 drains first when fewer are free
 
-template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01>
+template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01, bool FAST = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wq(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,
                                                    const uint8_t* __restrict__ flags, uint64_t n, int k,
@@ -440,6 +440,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     // (16 narrow entries for buckets above 16 guides, or 8 wide entries)
     static_assert(NQ01 == 1 || NQ01 == 2, "table 0/1 slabs are 64 or 128 bytes");
     static_assert(!WIDE || NQ01 == 2, "wide entries: 8-entry slabs of 128 bytes");
+    // FAST: tables 0/1 in their second form (FastTable): primary slabs of eight entries, the next seven at an implied
+    // address; an item's slab number then counts in the secondary region, item code 3 = a primary slab of table 1
+    static_assert(!FAST || (!WIDE && NQ01 == 1), "the second form exists for 64-byte slabs of 8-byte entries");
     constexpr uint32_t S01 = NQ01 == 2 ? 7u : 6u;     // log2 of that slab's bytes
     (void)o_arg;  // read from the kernel-argument segment in the last phase, see there
     __shared__ uint64_t q_read[WAVE_T];                                 // listed read; later its result
@@ -461,14 +464,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     const SlabTable& T0 = sp.t[0];
     const SlabTable& T1 = sp.t[1];
     const SlabTable& T2 = sp.t[NSEG - 1];
-    const char* const b0 = reinterpret_cast<const char*>(T0.slabs);
-    const char* const b1 = reinterpret_cast<const char*>(T1.slabs);
+    // FAST: one base for tables 0/1, the region (primary / secondary, table) is a 32-bit offset
+    const char* const b0 = FAST ? sp.fast.base + sp.fast.prim[0] : reinterpret_cast<const char*>(T0.slabs);   // primary slabs
+    const char* const b1 = FAST ? sp.fast.base + sp.fast.prim[1] : reinterpret_cast<const char*>(T1.slabs);
     const char* const b2 = reinterpret_cast<const char*>(T2.slabs);
     const uint32_t lane = threadIdx.x;
     const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
     const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;  // (the masks are not used by the wide format)
     const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u, sh2 = T2.log2S + (WIDE ? 4u : 3u);
-    const uint32_t empty0 = T0.empty << S01, empty1 = T1.empty << S01, empty2 = T2.empty << sh2;  // what idle lanes fetch
+    const uint32_t empty0 = (FAST ? sp.fast.empty : T0.empty) << S01, empty1 = (FAST ? sp.fast.empty : T1.empty) << S01,
+                   empty2 = T2.empty << sh2;  // what idle lanes fetch (same slab number in every region of the fast tables)
     const int s = (int)(lane & 3u);
     const uint32_t none4[4] = {0u, 0u, 0u, 0u};
     unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull, t_acc[4] = {0ull, 0ull, 0ull, 0ull};
@@ -507,14 +512,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const uint32_t item = act ? wl[wn + q] : 0u;
             const uint32_t qi = item & 255u, slab = item >> 10;
             const bool t1 = (item & 0x100u) != 0u;
+            const bool prim1 = FAST && (item & 0x300u) == 0x300u;  // a primary slab of table 1 (listed reads beyond 64)
             const uint64_t r = q_read[qi];
             const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
             // the rest of the read with the table picked per lane
             const uint32_t st = t1 ? T1.start : T0.start, sh = t1 ? T1.start + T1.slen : T0.start + T0.slen;
             const uint32_t hf = t1 ? half1 : half0, hm = t1 ? hm1 : hm0;
             const RestW rest = rest_of<WIDE>(st, sh, hf, rlo, rhi);
-            const char* base = t1 ? b1 : b0;
-            const uint32_t off = act ? (slab << S01) : empty0;
+            const char* base = FAST ? sp.fast.base : (t1 ? b1 : b0);
+            const uint32_t region = FAST ? (prim1 ? sp.fast.prim[1] : t1 ? sp.fast.sec[1] : sp.fast.sec[0]) : 0u;
+            const uint32_t off = region + (act ? (slab << S01) : empty0);
             uint4 w[NQ01];
 #pragma unroll
             for (int h = 0; h < NQ01; ++h) w[h] = load16(base, off + (uint32_t)(s + 4 * h) * 16u);
@@ -523,11 +530,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             for (int h = 0; h < NQ01; ++h) m = min(m, piece_min<WIDE>(w[h], rest.lo, rest.hi, hf, hm));
             m = min(m, quad_perm<0xB1>(m));
             m = min(m, quad_perm<0x4E>(m));
-            const uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ01 - 1]));  // the slab's last slot: link or empty (0)
+            uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ01 - 1]));  // the slab's last slot: link or empty (0)
+            uint32_t next = (item & 0x3FFu) | (lnk << 10);
+            if (FAST) {  // a primary slab has no link: an occupied last slot means the bucket goes on in its secondary slab
+                const uint32_t more = quad_bcast<3>(w[0].w) != SLAB_EMPTY ? 1u : 0u;
+                lnk = prim1 ? more : lnk;
+                next = prim1 ? ((item & 0xFFu) | 0x100u | (slab << 10)) : next;
+            }
             const bool lead = act && s == 0;
             uint32_t now = 0xFFFFFFFFu;
             if (lead) now = min(m, atomicMin(&q_key[qi], m));
-            push_items(lead && lnk != 0u && !settled(now), (item & 0x3FFu) | (lnk << 10));  // a settled read's chain ends here
+            push_items(lead && lnk != 0u && !settled(now), next);  // a settled read's chain ends here
         }
         wave_lds_sync();
     };
@@ -600,12 +613,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         }
         // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
         auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << S01) : 0u; };
-        auto finish = [&](int j, const uint4 (&w)[4][NQ01]) {
+        // myoff: the byte offset the read's own slab was fetched from (FAST: the secondary slab has the bucket's number)
+        auto finish = [&](int j, const uint4 (&w)[4][NQ01], uint32_t myoff) {
             uint32_t l[4], key = 0xFFFFFFFFu;
             visit_scan<NQ01, WIDE>(w, rest_of<WIDE>(T0.start, T0.start + T0.slen, half0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)),
                                    half0, hm0, s, key, l);
+            if (FAST) {  // no link slot: slot 7's index word says whether the bucket goes on
+#pragma unroll
+                for (int u = 0; u < 4; ++u) l[u] = w[u][0].w;
+            }
             const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
-            const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner's overflow link
+            uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner's overflow link
+            if (FAST) lnk = lnk != SLAB_EMPTY ? ((myoff >> S01) | 0x80000000u) : 0u;
             const uint32_t d = key >> 24;
             const bool fin = ok[j] && d <= max_mm && key_unique(key, max_mm);
             idx[j] = !ok[j] ? BC_IDX_SKIP : fin ? (int32_t)(key & SLAB_GIDX_MASK) : BC_IDX_MISS;
@@ -622,20 +641,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         };
         if constexpr (NQ01 == 1) {
             uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
-            visit_issue<1, false>(b0, off0(0), none4, s, wa);
-            visit_issue<1, false>(b0, off0(1), none4, s, wb);
-            finish(0, wa);
-            visit_issue<1, false>(b0, off0(2), none4, s, wa);
-            finish(1, wb);
-            visit_issue<1, false>(b0, off0(3), none4, s, wb);
-            finish(2, wa);
-            finish(3, wb);
+            const uint32_t o0 = off0(0), o1 = off0(1);
+            visit_issue<1, false>(b0, o0, none4, s, wa);
+            visit_issue<1, false>(b0, o1, none4, s, wb);
+            finish(0, wa, o0);
+            const uint32_t o2 = off0(2);
+            visit_issue<1, false>(b0, o2, none4, s, wa);
+            finish(1, wb, o1);
+            const uint32_t o3 = off0(3);
+            visit_issue<1, false>(b0, o3, none4, s, wb);
+            finish(2, wa, o2);
+            finish(3, wb, o3);
         } else {
             uint4 wa[4][2];  // 128-byte slabs: one round in flight (two would take 64 registers)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                visit_issue<2, false>(b0, off0(j), none4, s, wa);
-                finish(j, wa);
+                const uint32_t oj = off0(j);
+                visit_issue<2, false>(b0, oj, none4, s, wa);
+                finish(j, wa, oj);
             }
         }
     }
@@ -659,8 +682,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         uint32_t l1[4];
         visit_issue<NQ01, false>(b1, off1, none4, s, wa);
         visit_scan<NQ01, WIDE>(wa, rest1, half1, hm1, s, kmin, l1);
+        if (FAST) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) l1[u] = wa[u][0].w;
+        }
         const uint32_t t0 = quad_bcast<3>(l1[0]), t1 = quad_bcast<3>(l1[1]), t2 = quad_bcast<3>(l1[2]), t3 = quad_bcast<3>(l1[3]);
-        const uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;
+        uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;
+        if (FAST) lnk = lnk != SLAB_EMPTY ? ((off1 >> S01) | 0x80000000u) : 0u;
         // a read that table 1's primary slab settles (a third of the listed ones) needs neither overflow slab
         const bool more = mine && !settled(kmin);
         uint32_t lnk0 = 0;
@@ -668,8 +696,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             q_key[qi] = kmin;
             lnk0 = q_lnk[qi];
         }
-        push_items(more && lnk0 != 0u, qi | (lnk0 << 10));
-        push_items(more && lnk != 0u, qi | 0x100u | (lnk << 10));
+        push_items(more && lnk0 != 0u, qi | ((lnk0 & 0x3FFFFFu) << 10));  // (FAST: bit 31 marks "there is more", the rest is the bucket)
+        push_items(more && lnk != 0u, qi | 0x100u | ((lnk & 0x3FFFFFu) << 10));
         for (uint32_t qb = 64; qb < qn; qb += 64) {
             if (wn > WL_CAP - 128) drain01();
             const uint32_t qj = qb + lane;
@@ -680,8 +708,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
                 sv = seed_value((uint32_t)r, (uint32_t)(r >> 32), T1.start, T1.slen);
                 lj = q_lnk[qj];
             }
-            push_items(mj, qj | 0x100u | (sv << 10));
-            push_items(mj && lj != 0u, qj | (lj << 10));
+            push_items(mj, qj | (FAST ? 0x300u : 0x100u) | (sv << 10));
+            push_items(mj && lj != 0u, qj | ((lj & 0x3FFFFFu) << 10));
         }
     }
     if (!(diag & 2u)) drain01();
@@ -1264,6 +1292,57 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     T.log2S = (uint32_t)log2S;
     for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
         T.dmask[t] = (t < s) ? (((1u << cs.slen[t]) - 1u) << cs.start[t]) : 0u;
+    if (s == 0) { sl.fast = FastTables{}; for (auto& v : lib->fast_stage) v.clear(); }
+    if (s < 2 && !wide && log2S == 3 && (cs.nseg == 2 || cs.nseg == 3) && env_int("BC_FAST01", 1)) {  // see FastTables
+        std::vector<uint2> prim((size_t)(nb + 1) * 8, make_uint2(0u, SLAB_EMPTY)), sec((size_t)(nb + 1) * 8, make_uint2(0u, SLAB_EMPTY));
+        for (uint32_t b = 0; b < nb; ++b) {
+            size_t cur = b;      // slab of `sec` being filled
+            uint32_t pos = 0;    // entries of the bucket placed so far
+            for (uint32_t j = off[b]; j < off[b + 1]; ++j, ++pos) {
+                uint32_t fl = 0;
+                if (!lib->h_nn.empty()) {
+                    const int nn = lib->h_nn[gidx[j]];
+                    if (nn > 2 * d) fl |= SLAB_F_ISO;
+                    if (nn > 2 * (d - 1)) fl |= SLAB_F_ISO1;
+                }
+                const uint32_t lo = (uint32_t)keys[j], hi = (uint32_t)(keys[j] >> 32);
+                const uint32_t lo_r = (lo & below) | ((sh >= 32 ? 0u : (lo >> sh)) << start);
+                const uint32_t hi_r = (hi & below) | ((sh >= 32 ? 0u : (hi >> sh)) << start);
+                const uint2 e = make_uint2(lo_r | (hi_r << 16), gidx[j] | fl);
+                if (pos < 8) { prim[(size_t)b * 8 + pos] = e; continue; }
+                uint32_t p2 = (pos - 8) % 7;
+                if (pos > 8 && p2 == 0) {  // the secondary slab is full: chain another
+                    const size_t nxt = sec.size() / 8;
+                    sec.resize(sec.size() + 8, make_uint2(0u, SLAB_EMPTY));
+                    sec[cur * 8 + 7] = make_uint2((uint32_t)nxt, SLAB_LINK);
+                    cur = nxt;
+                }
+                sec[cur * 8 + p2] = e;
+            }
+        }
+        if ((sec.size() / 8) < (1u << 22)) {
+            lib->fast_stage[2 * s] = std::move(prim);
+            lib->fast_stage[2 * s + 1] = std::move(sec);
+        }
+        if (s == 1 && !lib->fast_stage[0].empty() && !lib->fast_stage[2].empty() &&
+            lib->fast_stage[0].size() == lib->fast_stage[2].size()) {  // (equal bucket counts: one empty-slab number)
+            std::vector<uint2> arena;
+            uint32_t offs[4];
+            for (int r = 0; r < 4; ++r) {
+                offs[r] = (uint32_t)(arena.size() * sizeof(uint2));
+                arena.insert(arena.end(), lib->fast_stage[r].begin(), lib->fast_stage[r].end());
+            }
+            if ((arena.size() * sizeof(uint2)) >> 31 == 0) {
+                uint2* d_arena;
+                if ((rc = dev_upload(lib, arena, &d_arena)) != BC_OK) return rc;
+                sl.fast.base = reinterpret_cast<const char*>(d_arena);
+                sl.fast.prim[0] = offs[0]; sl.fast.sec[0] = offs[1]; sl.fast.prim[1] = offs[2]; sl.fast.sec[1] = offs[3];
+                sl.fast.empty = nb;
+                sl.fast.ok = 1u;
+            }
+        }
+        if (s == 1) for (auto& v : lib->fast_stage) { v.clear(); v.shrink_to_fit(); }
+    }
     if (s == cs.nseg - 1) {  // descriptor block for the kernel (read through scalar loads)
         sl.nbr_slot = lib->h_nn.empty() ? nullptr : lib->d_nbr_slot;
         sl.nbr = lib->h_nn.empty() ? nullptr : lib->d_nbr;
@@ -1833,7 +1912,10 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o)
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#define BC_WAVE_FAST(NSEG_, NQ2_)                                                                                    \
+    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
+                       lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
                     if (!wide && nq01 == 1) {
                         if (nseg == 2) BC_WAVE_P(2, 1);
                         else if (nq2 == 1) BC_WAVE_P(3, 1);
@@ -1849,6 +1931,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                         else BC_WAVE_LAUNCH(3, 4, false, true, 2);
                     }
 #undef BC_WAVE_P
+#undef BC_WAVE_FAST
 #undef BC_WAVE_LAUNCH
                     note_kernel(lib, "k_match_wq");
                     BC_HIP(hipGetLastError());
