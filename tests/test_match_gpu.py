@@ -446,3 +446,35 @@ def test_three_mismatch_pair_index(gpu_device, oracle, k, cluster, monkeypatch):
         _check(GpuMatcher(dl).match(reads, flags, max_mismatch=3, algo="seed", first_index=9), ref)
         if want:  # (a dense library of short k-mers may leave the second stage nothing to do)
             assert dl.last_kernel == want or (mode == "1" and k < 16 and dl.last_kernel == "cascade3:d2"), (mode, dl.last_kernel)
+
+
+@pytest.mark.parametrize("which", ["seed0", "seed1", "seed2"])
+def test_bucket_size_boundaries(gpu_device, oracle, which):
+    """Buckets of exactly 1 ... 40 guides in one table (guides that share one segment's seed): the slab forms' edges —
+    7 / 8 entries of a primary slab, 15 of primary + secondary, chained slabs behind them — for the wave matcher
+    (eight-entry primaries for tables 0/1, 16-entry slabs for table 2) and the d = 3 cascade, against the oracle."""
+    k = 20
+    rng = np.random.default_rng({"seed0": 1, "seed1": 2, "seed2": 3}[which])
+    lo, hi = {"seed0": (0, 7), "seed1": (7, 14), "seed2": (14, 20)}[which]
+    rows = []
+    for size in list(range(1, 41)) * 3:
+        shared = rng.integers(0, 4, size=hi - lo)
+        grp = rng.integers(0, 4, size=(size, k))
+        grp[:, lo:hi] = shared
+        rows.append(grp)
+    codes = np.unique(np.concatenate(rows + [rng.integers(0, 4, size=(2000, k))]), axis=0)
+    codes = codes[rng.permutation(codes.shape[0])]
+    G = codes.shape[0]
+    letters = np.array(list("ACGT"))
+    lib_s = ["".join(letters[r]) for r in codes]
+    n = 30011
+    nsub = rng.choice([0, 1, 2, 3], size=n, p=[0.3, 0.3, 0.3, 0.1])
+    rd = _mutate(rng, codes[rng.integers(0, G, size=n)], nsub)
+    rd[rng.random(n) < 0.05] = rng.integers(0, 4, size=k)
+    reads_s = ["".join(letters[r]) for r in rd]
+    lib, _ = E.pack_kmers(lib_s, k)
+    reads, _ = E.pack_kmers(reads_s, k)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    for d in (1, 2, 3):
+        _check(GpuMatcher(dl).match(reads, None, max_mismatch=d, algo="seed", first_index=0), oracle.best_hit(lib_s, reads_s, d))
+        assert dl.last_kernel == ("k_match_wq" if d < 3 else "cascade3:d2+k_match_pairs"), dl.last_kernel
