@@ -87,14 +87,16 @@ BC_HD static inline uint32_t flt_hash7(uint32_t v) { return (v * 0x9E3779B1u) >>
 // (no link slot) and a bucket's next seven sit at an implied address — slab `bucket` of a second region, 7 entries +
 // link from there on — so a read learns "there is more" from slot 7 being occupied, needs no link to follow, and a
 // size-biased 27 % of the visits continue instead of 41 %.  The exact path and the quad kernels keep reading t[].
-// One allocation and 32-bit offsets: a per-lane choice between four 64-bit base pointers costs registers the kernel
+// Measured (1e8 reads, 1e5 guides, d <= 2): matcher 1.067 -> 1.054 ms, L2 requests 1.79 -> 1.72 per read, but the sparse
+// secondary regions cost L2 capacity (misses +20 %, HBM traffic 1.87 -> 2.07 GB per pass) and rocprofv3's average over a
+// run does not move: built only with BC_FAST01=1.  One allocation and 32-bit offsets: a per-lane choice between four 64-bit base pointers costs registers the kernel
 // does not have (80 VGPRs and scratch against 53).
 struct FastTables {
     const char* base;     // one allocation: [table 0 primary | table 0 secondary | table 1 primary | table 1 secondary]
     uint32_t prim[2];     // byte offsets of the primary regions: (buckets + 1) slabs each, the last one empty
     uint32_t sec[2];      // byte offsets of the secondary regions: slab `buckets` is empty, chained slabs behind it
     uint32_t empty;       // = buckets (number of the empty slab in every region)
-    uint32_t ok;          // built (BC_FAST01=0: never)
+    uint32_t ok;          // built (only with BC_FAST01=1)
 };
 struct SlabParams {
     int nseg;

@@ -1293,7 +1293,7 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
         T.dmask[t] = (t < s) ? (((1u << cs.slen[t]) - 1u) << cs.start[t]) : 0u;
     if (s == 0) { sl.fast = FastTables{}; for (auto& v : lib->fast_stage) v.clear(); }
-    if (s < 2 && !wide && log2S == 3 && (cs.nseg == 2 || cs.nseg == 3) && env_int("BC_FAST01", 1)) {  // see FastTables
+    if (s < 2 && !wide && log2S == 3 && (cs.nseg == 2 || cs.nseg == 3) && env_int("BC_FAST01", 0)) {  // see FastTables: measured, not the default
         std::vector<uint2> prim((size_t)(nb + 1) * 8, make_uint2(0u, SLAB_EMPTY)), sec((size_t)(nb + 1) * 8, make_uint2(0u, SLAB_EMPTY));
         for (uint32_t b = 0; b < nb; ++b) {
             size_t cur = b;      // slab of `sec` being filled
