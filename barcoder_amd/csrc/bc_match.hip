@@ -458,7 +458,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     uint16_t* const l_tie = l_slow;
     const SlabParams& sp = *spp;
     const uint32_t max_mm = (uint32_t)max_mm_ & 0xFFu;
-    const uint32_t diag = (uint32_t)max_mm_ >> 8;  // BC_DIAG: timing experiments only (results are wrong with any bit set)
+    const uint32_t diag = ((uint32_t)max_mm_ >> 8) & 0xFFu;  // BC_DIAG: timing experiments only (results are wrong with any bit set)
+    const uint32_t pf_dist = ((uint32_t)max_mm_ >> 16) << 9;  // read-stream prefetch distance in tiles (0 = none), see the kernel's end
+    (void)pf_dist;
     const uint64_t tile0 = (uint64_t)blockIdx.x * WAVE_T;
     const uint32_t tn = (uint32_t)min((uint64_t)WAVE_T, n - tile0);
     const SlabTable& T0 = sp.t[0];
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     {
         uint64_t r[4] = {0, 0, 0, 0};
         if (full) {
-            load_reads4(reads + tile0 + p0, r);
+            load_reads4(reads + ((diag & 16u) ? (uint64_t)(blockIdx.x & 255u) * WAVE_T : tile0) + p0, r);  // BC_DIAG 16: the read stream from 512 KB that stay in L2 (timing experiment)
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -874,6 +876,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_key), wl);
         }
     }
+    // ---- read-stream prefetch (experiment, BC_PREFETCH; off by default).  With the read stream served from L2 the kernel
+    // runs 0.84 instead of 1.07 ms (BC_DIAG=16): the stream's HBM round trips cost a fifth of its time.  So, on its way
+    // out, a wave can pull the tile of a workgroup that starts a little after this one's slot is reused (pf_dist tiles
+    // ahead, a multiple of 8: same XCD, same L2 — workgroup i runs on XCD i % 8, profiles/xcc_map.hip) into the L2
+    // through the SCALAR cache: thirty-two 4-byte loads, one per 64-byte sector (the L2 fills sectors), which occupy no
+    // vector-L1 miss slot.  Measured (profiles/r02_prefetch_sweep.txt): the lines do not stay — at the best distance
+    // (6 144-7 168 tiles) 57 % of the stream's sectors are still there when the demand load comes, mean L1->L2 latency
+    // 230 -> 171 cycles, kernel -3 %, and every sector is fetched from HBM twice (+0.8 GB per pass).  Not worth it.
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (pf_dist) {
+        const uint64_t pt = (uint64_t)blockIdx.x + pf_dist;
+        if ((pt + 1) * WAVE_T <= n) {
+            typedef const uint32_t __attribute__((address_space(4)))* cu32_t;
+            cu32_t pl = (cu32_t)(uintptr_t)(reads + pt * WAVE_T);
+            uint32_t v[32];  // one load per 64-byte sector (the L2 fills sectors, not whole 128-byte lines)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = pl[i * 16];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc ^= v[i];
+            asm volatile("" ::"s"(acc));
+        }
+    }
+#endif
     phase_mark(3);
     if (PROF && threadIdx.x == 0) {
         for (int i = 0; i < 4; ++i) atomicAdd(&g_phase_cycles[i], t_acc[i]);
@@ -1911,10 +1937,10 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
-                       lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o)
+                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | (lib->knobs.prefetch << 16), o)
 #define BC_WAVE_FAST(NSEG_, NQ2_)                                                                                    \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
-                       lib->k, lib->kmask, max_mm | (lib->knobs.diag << 8), o)
+                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | (lib->knobs.prefetch << 16), o)
 #define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
                     if (!wide && nq01 == 1) {
                         if (nseg == 2) BC_WAVE_P(2, 1);
@@ -2170,6 +2196,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.phase_prof = env_int("BC_PHASE_PROF", 0);
     lib->knobs.host_pin = env_int("BC_HOST_PIN", 1);
     lib->knobs.cascade = env_int("BC_CASCADE", 1);
+    lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 0)));
     lib->h_guides.assign(h_guides, h_guides + n_guides);
     int rc = dev_upload(lib, lib->h_guides, &lib->d_guides);
     if (rc == BC_OK) rc = compute_nn(lib);
