@@ -133,7 +133,7 @@ struct Knobs {
     int tally = 0;        // BC_TALLY: 0 auto, 1 global atomics, 2 k_hist sweeps, 3 range-partitioned records
     int phase_prof = 0;   // BC_PHASE_PROF=1: per-stage cycle sums of the wave kernel on stderr
     int host_pin = 1;     // BC_HOST_PIN=0: bc_match_host does not pin the caller's buffers
-    int prefetch = 0;     // BC_PREFETCH: read-stream prefetch distance of k_match_wq in units of 512 tiles (0 = none)
+    int prefetch = 8;     // BC_PREFETCH: read-stream prefetch distance of k_match_wq in units of 128 tiles (0 = none)
     int cascade = 1;      // BC_CASCADE=0: d = 3 by the four-segment index over every read (round 1's path); 2: the pair
                           // index over every read (no d <= 2 pass first); 1: cascade
 };

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     const SlabParams& sp = *spp;
     const uint32_t max_mm = (uint32_t)max_mm_ & 0xFFu;
     const uint32_t diag = ((uint32_t)max_mm_ >> 8) & 0xFFu;  // BC_DIAG: timing experiments only (results are wrong with any bit set)
-    const uint32_t pf_dist = ((uint32_t)max_mm_ >> 16) << 9;  // read-stream prefetch distance in tiles (0 = none), see the kernel's end
+    const uint32_t pf_dist = ((uint32_t)max_mm_ >> 16) << 7;  // read-stream prefetch distance in tiles (0 = none), see phase 1
     (void)pf_dist;
     const uint64_t tile0 = (uint64_t)blockIdx.x * WAVE_T;
     const uint32_t tn = (uint32_t)min((uint64_t)WAVE_T, n - tile0);
@@ -592,6 +592,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         return inrange;
     };
 
+    // ---- read-stream prefetch (BC_PREFETCH = distance / 128 tiles, default 8; 0 = none).  With the read stream served
+    // from L2 the kernel runs 0.84 instead of 1.07 ms (BC_DIAG=16): the stream's HBM round trips cost a fifth of its time,
+    // because a line of the stream holds a vector-L1 miss slot for an HBM round trip where a table slab holds one for an
+    // L2 hit.  Workgroups start in id order, ~365 per microsecond on the whole chip, so the workgroup pf_dist ids after
+    // this one (a multiple of 8: same XCD, same L2 — workgroup i runs on XCD i % 8, profiles/xcc_map.hip) starts
+    // pf_dist / 365 us from now: pull its tile into the L2 now, through the SCALAR cache — thirty-two 4-byte loads, one
+    // per 64-byte sector (the L2 fills sectors), which occupy no vector-L1 miss slot and are awaited with phase 1's own
+    // waits.  Measured (profiles/r02_prefetch_sweep.txt): at 512-1024 tiles 62 % of the stream's sectors are in L2 when
+    // the demand load comes (the L2 keeps a line it has seen once for a few microseconds only: 29 % at 2048 tiles, 9 %
+    // beyond 4096), mean L1->L2 latency 230 -> 167 cycles, kernel -5...-7 %; the sectors that were evicted again are
+    // fetched from HBM twice (+0.3 GB per pass).
+    uint32_t pfv[32];
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        // (a tile past the end of the input: the last tile again — harmless, and no branch around the loads)
+        const uint64_t last = (n - 1) / WAVE_T;
+        const uint64_t pt = pf_dist ? min((uint64_t)blockIdx.x + pf_dist, last ? last - 1 : 0) : 0;
+        typedef const uint32_t __attribute__((address_space(4)))* cu32_t;
+        cu32_t pl = (cu32_t)(uintptr_t)(reads + pt * WAVE_T);
+        if (pf_dist) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pfv[i] = pl[i * 16];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pfv[i] = 0;
+        }
+    }
+#else
+    for (int i = 0; i < 32; ++i) pfv[i] = 0;
+#endif
     // ---- phase 1: table 0, primary slab, every read (exact hits and isolated near hits are final)
     const uint32_t p0 = lane * 4u;
     const bool full = p0 + 3 < tn;
@@ -665,6 +695,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         }
     }
     wave_lds_sync();
+    if (pf_dist) {  // the prefetch loads have long returned: their registers are free again
+        uint32_t pf_acc = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) pf_acc ^= pfv[i];
+        asm volatile("" ::"s"(pf_acc));
+    }
     phase_mark(0);
 
     // ---- phase 2: table 1's primary slab — the first 64 listed reads as one full-width batch, the rest as items
@@ -877,30 +913,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_key), wl);
         }
     }
-    // ---- read-stream prefetch (experiment, BC_PREFETCH; off by default).  With the read stream served from L2 the kernel
-    // runs 0.84 instead of 1.07 ms (BC_DIAG=16): the stream's HBM round trips cost a fifth of its time.  So, on its way
-    // out, a wave can pull the tile of a workgroup that starts a little after this one's slot is reused (pf_dist tiles
-    // ahead, a multiple of 8: same XCD, same L2 — workgroup i runs on XCD i % 8, profiles/xcc_map.hip) into the L2
-    // through the SCALAR cache: thirty-two 4-byte loads, one per 64-byte sector (the L2 fills sectors), which occupy no
-    // vector-L1 miss slot.  Measured (profiles/r02_prefetch_sweep.txt): the lines do not stay — at the best distance
-    // (6 144-7 168 tiles) 57 % of the stream's sectors are still there when the demand load comes, mean L1->L2 latency
-    // 230 -> 171 cycles, kernel -3 %, and every sector is fetched from HBM twice (+0.8 GB per pass).  Not worth it.
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (pf_dist) {
-        const uint64_t pt = (uint64_t)blockIdx.x + pf_dist;
-        if ((pt + 1) * WAVE_T <= n) {
-            typedef const uint32_t __attribute__((address_space(4)))* cu32_t;
-            cu32_t pl = (cu32_t)(uintptr_t)(reads + pt * WAVE_T);
-            uint32_t v[32];  // one load per 64-byte sector (the L2 fills sectors, not whole 128-byte lines)
-#pragma unroll
-            for (int i = 0; i < 32; ++i) v[i] = pl[i * 16];
-            uint32_t acc = 0;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) acc ^= v[i];
-            asm volatile("" ::"s"(acc));
-        }
-    }
-#endif
     phase_mark(3);
     if (PROF && threadIdx.x == 0) {
         for (int i = 0; i < 4; ++i) atomicAdd(&g_phase_cycles[i], t_acc[i]);
@@ -1938,10 +1950,10 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
-                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | (lib->knobs.prefetch << 16), o)
+                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
 #define BC_WAVE_FAST(NSEG_, NQ2_)                                                                                    \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
-                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | (lib->knobs.prefetch << 16), o)
+                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
 #define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
                     if (!wide && nq01 == 1) {
                         if (nseg == 2) BC_WAVE_P(2, 1);
@@ -2197,7 +2209,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.phase_prof = env_int("BC_PHASE_PROF", 0);
     lib->knobs.host_pin = env_int("BC_HOST_PIN", 1);
     lib->knobs.cascade = env_int("BC_CASCADE", 1);
-    lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 0)));
+    lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));
     lib->h_guides.assign(h_guides, h_guides + n_guides);
     int rc = dev_upload(lib, lib->h_guides, &lib->d_guides);
     if (rc == BC_OK) rc = compute_nn(lib);

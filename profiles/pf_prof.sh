@@ -1,5 +1,5 @@
 #!/bin/bash
-# read-stream prefetch of k_match_wq (BC_PREFETCH, units of 512 tiles): L2 misses, fetched bytes and L1->L2 latency
+# read-stream prefetch of k_match_wq (BC_PREFETCH, units of 128 tiles): L2 misses, fetched bytes and L1->L2 latency
 # against the distance.  usage: bash profiles/pf_prof.sh "0 16 24 ..."
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT

@@ -48,7 +48,7 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
                                  {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4", "BC_SINGLE_SLAB": "1"},
                                  {"BC_SLAB_LOG2S": "3,3,3,3"}, {"BC_SLAB_LOG2S": "5,5,5,5"}, {"BC_SLAB_LOG2S": "4,3,5,4"},
                                  {"BC_SINGLE_SLAB": "1"}, {"BC_LANE": "0"}, {"BC_LANE": "0", "BC_PHASE2_SM": "0"},
-                                 {"BC_T2_FILTER": "0"}, {"BC_CASCADE": "0"}, {"BC_CASCADE": "2"}, {"BC_FAST01": "1"},
+                                 {"BC_T2_FILTER": "0"}, {"BC_CASCADE": "0"}, {"BC_CASCADE": "2"}, {"BC_FAST01": "1"}, {"BC_PREFETCH": "0"}, {"BC_PREFETCH": "1"},
                                  {"BC_HASH_SLOTS_PCT": "120"}, {"BC_HASH_SLOTS_PCT": "3000"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
     """Tally by global atomics vs LDS histogram vs records, wave vs quad vs single
