@@ -380,6 +380,9 @@ def run(args):
                     dom = [v["hbm_bytes"] for k_, v in t.get("per_kernel", {}).items() if k_.startswith("k_match")]
                     out["roofline"]["traffic"] = dom[0] if dom else t["hbm_bytes_per_pass"]
                     out["roofline"]["pass_traffic"] = t["hbm_bytes_per_pass"]
+                    notes = [v["note"] for k_, v in t.get("per_kernel", {}).items() if k_.startswith("k_match") and v.get("note")]
+                    if notes:  # e.g. the read-stream prefetch: part of the stream is fetched twice on purpose
+                        out["roofline"]["traffic_note"] = notes[0]
             except Exception:
                 pass
         if world == 1 and not args.no_cpu:
