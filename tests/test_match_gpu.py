@@ -318,9 +318,10 @@ def test_edge_sizes(gpu_device, oracle):
     lib = S.library(50, k)
     dl = DeviceLibrary(lib, k, gpu_device)
     m = GpuMatcher(dl)
-    for n in (0, 1, 3, 4, 5, 255, 257):
+    # (from 1 024 reads on the wave matcher prefetches a later tile of the read stream: the clamp at the end of the input)
+    for n in (0, 1, 3, 4, 5, 255, 257, 1023, 1024, 1025, 1279, 1281, 2047, 2049):
         reads = S.reads(lib, k, 3, 0, n, 1)
-        for algo, d in [("hash", 0), ("seed", 2), ("brute", 2)]:
+        for algo, d in [("hash", 0), ("seed", 2), ("seed", 3), ("brute", 2)]:
             res = m.match(reads, None, max_mismatch=d, algo=algo)
             if n:
                 _check(res, oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads, k), d))
