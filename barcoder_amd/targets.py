@@ -334,10 +334,11 @@ def annotate(rows, genes):
     by_chr = {}
     for g in genes:
         by_chr.setdefault(g.chrom, []).append(g)
-    starts = {}
+    starts, longest = {}, {}
     for c, lst in by_chr.items():
         lst.sort(key=lambda g: g.start)
         starts[c] = np.array([g.start for g in lst])
+        longest[c] = max((g.end - g.start for g in lst), default=0)  # a gene that reaches a starts after a - longest
     out = []
     for r in rows:
         if r.get("target") is None:
@@ -347,8 +348,10 @@ def annotate(rows, genes):
         a, b = r["tar_start"], r["tar_end"]
         hit = []
         if lst:
-            hi = int(np.searchsorted(starts[r["chr"]], b, side="left"))  # genes starting before tar_end
-            hit = [g for g in lst[:hi] if g.end > a and g.start < b and max(a, g.start) < min(b, g.end)]
+            st = starts[r["chr"]]
+            hi = int(np.searchsorted(st, b, side="left"))  # genes starting before tar_end
+            lo = int(np.searchsorted(st, a - longest[r["chr"]], side="left"))
+            hit = [g for g in lst[lo:hi] if g.end > a and g.start < b and max(a, g.start) < min(b, g.end)]
         if not hit:
             out.append(dict(r, locus_tag=None, gene=None, offset=None, overlap=None, tar_dir=None))
             continue
