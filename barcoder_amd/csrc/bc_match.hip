@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_part(PartOut P, const int32
         take(v3, (uint32_t)((q + 3 * HIST_BLOCK) >> 3));
     }
     for (; q < q1; q += HIST_BLOCK) take(__builtin_nontemporal_load(pv + q), (uint32_t)(q >> 3));
-    // tiles whose records did not fit: their share of the overflow list, straight from best_idx
+    // tiles whose records did not fit (overflow flag): straight from best_idx
     auto take_idx = [&](int32_t v, uint32_t tile) {
         const uint32_t g = (uint32_t)v - lo;  // negative sentinels wrap far above width
         if (g < width) {
@@ -1043,11 +1043,19 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_part(PartOut P, const int32
             if (first_tile) atomicMin(&ft[g], tile);
         }
     };
-    const uint32_t novf = *P.ovf_count;
-    for (uint32_t e = slice; e < novf; e += (uint32_t)slices) {
-        const uint32_t tile = P.ovf_list[e];
-        const uint64_t a = (uint64_t)tile << 8, b = min(tail_begin, a + 256);
-        for (uint64_t i = a + threadIdx.x; i < b; i += HIST_BLOCK) take_idx(best_idx[i], tile);
+    // every wave walks its share of the slice's tiles and takes the flagged ones (256 results, four per lane) itself
+    {
+        const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+        for (uint64_t c = t0 + (uint64_t)wv * 64; c < t1; c += HIST_BLOCK) {  // 64 tiles' flags per load
+            const uint64_t tl = c + ln;
+            unsigned long long m = __ballot(tl < t1 && P.ovf_flag[tl] != 0u);
+            while (m) {  // wave-uniform
+                const uint64_t t = c + (uint64_t)(__ffsll((long long)m) - 1);
+                m &= m - 1;
+                const uint64_t a = t << 8, b = min(tail_begin, a + 256);
+                for (uint64_t i = a + ln; i < b; i += 64) take_idx(best_idx[i], (uint32_t)t);
+            }
+        }
     }
     if (slice == (uint32_t)slices - 1)  // reads the matcher's record path did not cover
         for (uint64_t i = tail_begin + threadIdx.x; i < n; i += HIST_BLOCK) take_idx(best_idx[i], (uint32_t)(i >> 8));
@@ -1066,7 +1074,7 @@ __global__ __launch_bounds__(BLOCK) void k_first_refine(const int32_t* __restric
                                                         uint32_t* __restrict__ first_tile,
                                                         uint64_t* __restrict__ first_seen, uint64_t base,
                                                         uint32_t* __restrict__ ovf_count) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *ovf_count = 0u;  // every consumer of the list ran in an earlier launch
+    (void)ovf_count;
     const uint32_t g = (blockIdx.x * BLOCK + threadIdx.x) >> 4;
     const uint32_t sub = threadIdx.x & 15u;
     if (g >= G) return;
@@ -1654,10 +1662,14 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_results(const uint32_t* __res
 // ---- tally records: geometry and per-stream workspace -------------------------------------------------------
 // ranges: as few as the LDS allows (HIST_R guides each), equal sizes; range(g) = umulhi(g, magic) must be exact
 bool part_geometry(uint32_t G, PartOut& P) {
-    const uint32_t nr = (G + HIST_R - 1) / HIST_R;
+    uint32_t nr = (G + HIST_R - 1) / HIST_R;
     // one or two ranges: sweeping best_idx costs no more.  Above eight the lines are mostly empty (256 reads over nr
     // ranges) and writing + reading them costs what the sweeps cost (measured, 25 ranges: 1.13 vs 1.07 ms per 1e8 reads)
     if (nr < 3 || nr > (uint32_t)PART_MAX_NR) return false;
+    // a line holds 64 records: with three or four ranges a tile's 256 results overflow it as a rule (77 / 58 hits per
+    // range at a 90 % hit rate) and every tile falls back to best_idx (measured at 6e4 / 8e4 guides: 7.2 / 4.7 ms per
+    // pass instead of 1.2): at least five ranges, i.e. at most 51 expected hits per line
+    nr = std::max(nr, 5u);
     const uint32_t R = (G + nr - 1) / nr;
     const uint32_t magic = (uint32_t)((0x100000000ull + R - 1) / R);
     for (uint32_t g = 0; g < G; ++g)
@@ -1730,7 +1742,6 @@ int launch_hist_part(bc_lib* lib, const MatchOut& o, const TallyWs* w, uint64_t 
     const int slices = std::max(1, 256 / (int)o.part.nr);
     hipLaunchKernelGGL(k_hist_part, dim3(o.part.nr * slices), dim3(HIST_BLOCK), HIST_LDS_BYTES, st, o.part, o.best_idx, n,
                        tail_begin, lib->G, slices, o.counts, o.first_seen ? w->first_tile : nullptr);
-    // always: it also resets the overflow counter for the next launch on this stream
     hipLaunchKernelGGL(k_first_refine, dim3((lib->G * 16 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, o.best_idx, n,
                        o.first_seen ? lib->G : 0u, w->first_tile, o.first_seen, o.base, w->ovf_count);
     BC_HIP(hipGetLastError());
@@ -1852,7 +1863,7 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
                 o.part.n_tiles = (uint32_t)((m + 255) >> 8);
                 int rc = tally_workspace(lib, st, o.part.n_tiles, o.part.nr, &w);
                 if (rc != BC_OK) return rc;
-                o.part.rec = w->rec; o.part.ovf_list = w->ovf_list; o.part.ovf_count = w->ovf_count;
+                o.part.rec = w->rec; o.part.ovf_flag = w->ovf_list;
             }
         }
         uint64_t tail_begin = m;

@@ -12,14 +12,15 @@ namespace bc {
 // of the NR guide ranges the tally kernel owns in LDS, one 128-byte line of up to 64 two-byte records (guide index
 // inside the range, 0xFFFF = empty) to rec[range][tile][64].  The tally then streams every range's records ONCE
 // (2.5 B per read in all at NR = 5) instead of sweeping best_idx once per range (4 B per read and range).
-// A tile with more than 64 hits in one range writes empty lines and puts its number on the overflow list; the
-// tally takes such tiles from best_idx.
+// A tile with more than 64 hits in one range writes empty lines and raises its overflow flag; the tally takes such
+// tiles from best_idx.
 constexpr int PART_CAP = 64;        // records per range and tile: one 128-byte line
 constexpr int PART_MAX_NR = 8;      // ranges the staging area of a wave holds (512 two-byte records)
 struct PartOut {
     uint16_t* rec;        // [nr][n_tiles][PART_CAP]; NULL = no records wanted
-    uint32_t* ovf_list;   // [n_tiles] tiles whose records did not fit
-    uint32_t* ovf_count;
+    uint32_t* ovf_flag;   // [n_tiles] 1: the tile's records did not fit (its lines are empty), 0: they did; written for
+                          // every tile (no shared append counter: one took ~90 appends per microsecond, 4 ms when every
+                          // tile overflowed)
     uint32_t n_tiles;     // tiles of this launch (record stride between ranges)
     uint32_t nr;          // ranges
     uint32_t R;           // guides per range (<= HIST_R)
@@ -82,7 +83,7 @@ __device__ __forceinline__ void part_emit(const PartOut& P, uint32_t tile, const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const uint32_t c = lane < P.nr ? cnt[lane] : 0u;
     const bool ovf = __ballot(c > (uint32_t)PART_CAP) != 0ull;
-    if (ovf && lane == 0) P.ovf_list[atomicAdd(P.ovf_count, 1u)] = tile;
+    if (lane == 0) P.ovf_flag[tile] = ovf ? 1u : 0u;
     // lines out: lane l stores dword (l & 31) of range r + (l >> 5): two ranges (256 staged bytes, read in lane
     // order) per store instruction; the upper half-wave's line lies one range stride (< 2^31 bytes) further on
     const uint32_t* sw = reinterpret_cast<const uint32_t*>(stage);

@@ -18,7 +18,7 @@ cp profiles/traffic.json $OUT/traffic.json 2>/dev/null
 echo "default bench" >> $OUT/progress.log
 python3 bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench_n1.err
 for spec in "exact|--algo hash --max-mismatch 0 --mixture 0" "d1|--max-mismatch 1" "d3|--max-mismatch 3" "k32|--k 32" \
-            "G2e4|--guides 20000" "G2e5|--guides 200000" "G5e5|--guides 500000"; do
+            "G2e4|--guides 20000" "G6e4|--guides 60000" "G8e4|--guides 80000" "G2e5|--guides 200000" "G5e5|--guides 500000"; do
   label=${spec%%|*}; args=${spec#*|}
   echo "bench $label" >> $OUT/progress.log
   python3 bench.py --no-cpu --no-secondary $args > $OUT/${TAG}_bench_${label}_n1.json 2>> $OUT/bench_variants.err
