@@ -83,6 +83,9 @@ SIGNATURES = {
     "bc_genome_pack": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
     "bc_pam_scan_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int, vp, vp, vp]),
     "bc_pam_scan_host": (C.c_int, [C.c_int, vp, vp, C.c_uint64, vp, C.c_int, vp, vp]),
+    "bc_pam_scan_time_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int, vp, vp, C.c_int, vp, C.POINTER(C.c_float)]),
+    "bc_pam_sites_count_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "bc_pam_sites_emit_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_uint64, vp, vp]),
     "bc_sites_expand_dev": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp]),
     "bc_windows_dev": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int64, C.c_int, C.c_int, vp, vp, vp]),
     "bc_score_mismatch_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp]),

@@ -351,7 +351,9 @@ __device__ __forceinline__ bool resolve_ties(const SlabParams& sp, uint32_t rlo,
     return ok;
 }
 
-__device__ unsigned long long g_phase_cycles[8];  // BC_PHASE_PROF=1: summed cycles per stage over all waves
+#ifdef BC_DIAG_BUILD
+__device__ unsigned long long g_phase_cycles[8];  // BC_PHASE_PROF=1 (diag build): summed cycles per stage over all waves
+#endif
 
 // single-wave workgroups: LDS operations of one wave execute in issue order, so making another lane's list
 // entry visible only takes a compiler barrier and the LDS counter — not __syncthreads(), whose fence also waits
@@ -458,7 +460,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     uint16_t* const l_tie = l_slow;
     const SlabParams& sp = *spp;
     const uint32_t max_mm = (uint32_t)max_mm_ & 0xFFu;
-    const uint32_t diag = ((uint32_t)max_mm_ >> 8) & 0xFFu;  // BC_DIAG: timing experiments only (results are wrong with any bit set)
+#ifdef BC_DIAG_BUILD  // `make diag` only (build/libbarcoder_hip_diag.so, profiles/diag.sh): stages switched off for timing
+    const uint32_t diag = ((uint32_t)max_mm_ >> 8) & 0xFFu;  // attribution — results are wrong with any bit set
+#else
+    constexpr uint32_t diag = 0u;  // the release library has no such mode: every `diag &` below folds away
+#endif
     const uint32_t pf_dist = ((uint32_t)max_mm_ >> 16) << 7;  // read-stream prefetch distance in tiles (0 = none), see phase 1
     (void)pf_dist;
     const uint64_t tile0 = (uint64_t)blockIdx.x * WAVE_T;
@@ -914,10 +920,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         }
     }
     phase_mark(3);
+#ifdef BC_DIAG_BUILD
     if (PROF && threadIdx.x == 0) {
         for (int i = 0; i < 4; ++i) atomicAdd(&g_phase_cycles[i], t_acc[i]);
         atomicAdd(&g_phase_cycles[7], 1ull);
     }
+#else
+    static_assert(!PROF, "per-phase cycle sums exist in the diag build only");
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1958,7 +1968,12 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                 // default: the wave kernel (lane-owned reads, quad-cooperative loads, no hash table);
                 // BC_LANE=0 selects the quad kernels
                 if (wave_ok) {
+#ifdef BC_DIAG_BUILD
                     const bool prof = lib->knobs.phase_prof != 0 && !wide && nq01 == 1;  // tuning aid: per-stage cycle sums on stderr
+#else
+                    constexpr bool prof = false;
+                    (void)prof;
+#endif
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
@@ -1966,7 +1981,11 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
 #define BC_WAVE_FAST(NSEG_, NQ2_)                                                                                    \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
+#ifdef BC_DIAG_BUILD
 #define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#else
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#endif
                     if (!wide && nq01 == 1) {
                         if (nseg == 2) BC_WAVE_P(2, 1);
                         else if (nq2 == 1) BC_WAVE_P(3, 1);
@@ -1987,6 +2006,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     note_kernel(lib, "k_match_wq");
                     BC_HIP(hipGetLastError());
                     if (o.part.rec) { *part_done = true; *tail_begin = n; }
+#ifdef BC_DIAG_BUILD
                     if (prof) {
                         unsigned long long c[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                         BC_HIP(hipStreamSynchronize(st));
@@ -1995,6 +2015,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                         fprintf(stderr, "match stages (cycles/wave): 1 %.0f  2 %.0f  3 %.0f  4 %.0f  waves %llu\n",
                                 (double)c[0] / c[7], (double)c[1] / c[7], (double)c[2] / c[7], (double)c[3] / c[7], c[7]);
                     }
+#endif
                     return BC_OK;
                 }
                 // quad kernels (previous generation, bc_match_quad.hip): d = 3, buckets above 16 guides, BC_LANE=0
@@ -2213,12 +2234,14 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->device = device; lib->G = n_guides; lib->k = k; lib->kmask = km;
     // experiment knobs: the environment is read here, once per library, never per launch
     lib->knobs.lane = env_int("BC_LANE", 1);
+#ifdef BC_DIAG_BUILD
     lib->knobs.diag = env_int("BC_DIAG", 0);
+    lib->knobs.phase_prof = env_int("BC_PHASE_PROF", 0);
+#endif
     lib->knobs.phase2_sm = env_int("BC_PHASE2_SM", 1);
     lib->knobs.single_slab = env_int("BC_SINGLE_SLAB", 0);
     lib->knobs.slab_lpr = env_int("BC_SLAB_LPR", 4);
     lib->knobs.tally = env_int("BC_TALLY", 0);
-    lib->knobs.phase_prof = env_int("BC_PHASE_PROF", 0);
     lib->knobs.host_pin = env_int("BC_HOST_PIN", 1);
     lib->knobs.cascade = env_int("BC_CASCADE", 1);
     lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));

@@ -34,37 +34,106 @@ __device__ __forceinline__ uint32_t allowed(uint32_t lo, uint32_t hi, uint32_t m
     return a;
 }
 
+// One pattern position j of one strand, branch-free: sel[c] is all ones where the position accepts base code c.
+// a = (hi ? (lo ? T : G) : (lo ? C : A)) bit by bit: three v_bfi.
+struct PamSel { uint32_t s[4]; };
+__device__ __forceinline__ uint32_t allowed_sel(uint32_t lo, uint32_t hi, const PamSel& m) {
+    const uint32_t u1 = (lo & m.s[3]) | (~lo & m.s[2]), u0 = (lo & m.s[1]) | (~lo & m.s[0]);
+    return (hi & u1) | (~hi & u0);
+}
+__device__ __forceinline__ PamSel sel_of(uint8_t m) {
+    return PamSel{{(m & 1u) ? 0xFFFFFFFFu : 0u, (m & 2u) ? 0xFFFFFFFFu : 0u, (m & 4u) ? 0xFFFFFFFFu : 0u,
+                   (m & 8u) ? 0xFFFFFFFFu : 0u}};
+}
+// (w1:w0) >> sh, low 32 bits; sh in 0..31: v_alignbit_b32
+__device__ __forceinline__ uint32_t funnel(uint32_t w0, uint32_t w1, int sh) { return __builtin_amdgcn_alignbit(w1, w0, (uint32_t)sh); }
+
+// pattern bitmaps (forward pattern, reverse-complemented pattern) for the 32 positions of word A; B = the next word.
+// inv = not ACGT or past the end (bc_genome_pack sets the bits past the end of the last word; words past the
+// last one are passed as all ones), out = past the end (only looked at when a pattern position carries
+// BC_PAM_ANY_CHAR, the '.' of targets.py:224: an odd character matches there, the end of the sequence does not).
+template <int LEN, bool ANY>
+__device__ __forceinline__ void pam_eval(const PamParams& pp, uint32_t loA, uint32_t hiA, uint32_t invA, uint32_t outA,
+                                         uint32_t loB, uint32_t hiB, uint32_t invB, uint32_t outB, uint32_t& f,
+                                         uint32_t& r) {
+    f = 0xFFFFFFFFu; r = 0xFFFFFFFFu;
+    auto step = [&](int j) {
+        const uint32_t lo = funnel(loA, loB, j), hi = funnel(hiA, hiB, j), odd = funnel(invA, invB, j);
+        const uint32_t af = allowed_sel(lo, hi, sel_of(pp.fwd[j])) & ~odd, ar = allowed_sel(lo, hi, sel_of(pp.rev[j])) & ~odd;
+        if (ANY) {
+            const uint32_t in = ~funnel(outA, outB, j);
+            f &= in & (af | ((pp.fwd[j] & 16u) ? odd : 0u));
+            r &= in & (ar | ((pp.rev[j] & 16u) ? odd : 0u));
+        } else {
+            f &= af;
+            r &= ar;
+        }
+    };
+    if constexpr (LEN > 0) {  // compiled lengths: the position loop is straight-line code
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) step(j);
+    } else {
+        for (int j = 0; j < pp.len; ++j) step(j);
+    }
+}
+
+// bits of word w that lie at or past total_len
+__device__ __forceinline__ uint32_t outside_bits(uint64_t w, uint64_t n_words, uint64_t total_len) {
+    if (w + 1 < n_words) return 0u;
+    if (w >= n_words) return 0xFFFFFFFFu;
+    return (total_len & 31) ? ~((1u << (total_len & 31)) - 1u) : 0u;
+}
+
 // mask bit 4 (BC_PAM_ANY_CHAR): the pattern position also accepts a character that is not ACGT — the '.' that
-// targets.py:224 (pam_matches) writes for N, as opposed to the [ATCG] of PAMProcessor.py:31 / design_guides.py:26
+// targets.py:224 (pam_matches) writes for N, as opposed to the [ATCG] of PAMProcessor.py:31 / design_guides.py:26.
+// One lane = two consecutive words (64 positions): one 16-byte load of bases, one 8-byte load of the invalid bits,
+// 8-byte stores; the word after the pair comes from the next lane (ds_bpermute), only the wave's last lane loads it.
+// Round 2's form (one word per lane, every word loaded twice, 8-byte loads, run-time pattern loop) reached 3.8 TB/s.
+template <int LEN, bool ANY>
 __global__ __launch_bounds__(BLOCK) void k_pam_scan(const uint64_t* __restrict__ bases,
                                                     const uint32_t* __restrict__ invalid,
                                                     uint64_t total_len, uint64_t n_words, PamParams pp,
                                                     uint32_t* __restrict__ out_fwd,
-                                                    uint32_t* __restrict__ out_rev) {
+                                                    uint32_t* __restrict__ out_rev, bool vec) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const uint64_t n_pairs = (n_words + 1) / 2;
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t w = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; w < n_words; w += stride) {
-        uint64_t b0 = bases[w];
-        uint32_t c0 = invalid[w];          // characters that are not ACGT
-        uint32_t t0 = 0, t1 = 0xFFFFFFFFu; // positions at or past total_len
-        uint64_t b1 = 0;
-        uint32_t c1 = 0xFFFFFFFFu;
-        if (w + 1 < n_words) { b1 = bases[w + 1]; c1 = invalid[w + 1]; t1 = 0; }
-        if (w == n_words - 1 && (total_len & 31)) t0 = ~((1u << (total_len & 31)) - 1u);
-        if (w + 2 == n_words && (total_len & 31)) t1 = ~((1u << (total_len & 31)) - 1u);
-        const uint32_t lo0 = (uint32_t)b0, hi0 = (uint32_t)(b0 >> 32);
-        const uint32_t lo1 = (uint32_t)b1, hi1 = (uint32_t)(b1 >> 32);
-        uint32_t f = 0xFFFFFFFFu, r = 0xFFFFFFFFu;
-        for (int j = 0; j < pp.len; ++j) {
-            const uint32_t lo = take32(lo0, lo1, j), hi = take32(hi0, hi1, j);
-            const uint32_t in = ~take32(t0, t1, j);         // inside the sequence
-            const uint32_t odd = take32(c0, c1, j);         // not ACGT
-            const uint32_t fa = (pp.fwd[j] & 16u) ? odd : 0u, ra = (pp.rev[j] & 16u) ? odd : 0u;
-            f &= in & ((allowed(lo, hi, pp.fwd[j]) & ~odd) | fa);
-            r &= in & ((allowed(lo, hi, pp.rev[j]) & ~odd) | ra);
+    const uint32_t lane = threadIdx.x & 63u;
+    // wave-uniform loop bound: every lane of a wave takes part in the exchange
+    for (uint64_t t0 = (uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u); t0 < n_pairs; t0 += stride) {
+        const uint64_t t = t0 + lane, w = 2 * t;
+        uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
+        if (w + 1 < n_words && vec) {
+            const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bases) + t);
+            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(invalid) + t);
+            lo0 = b.x; hi0 = b.y; lo1 = b.z; hi1 = b.w; c0 = c.x; c1 = c.y;
+        } else if (w < n_words) {  // (pointers that are not 16 / 8-byte aligned, or the odd last word)
+            const uint64_t b = bases[w];
+            lo0 = (uint32_t)b; hi0 = (uint32_t)(b >> 32); c0 = invalid[w];
+            if (w + 1 < n_words) { const uint64_t b1 = bases[w + 1]; lo1 = (uint32_t)b1; hi1 = (uint32_t)(b1 >> 32); c1 = invalid[w + 1]; }
         }
-        // a pattern that would run past total_len meets a position outside the sequence: no match
-        out_fwd[w] = f;
-        out_rev[w] = r;
+        // the word after the pair: the next lane's first word
+        uint32_t lo2 = (uint32_t)__shfl_down((int)lo0, 1), hi2 = (uint32_t)__shfl_down((int)hi0, 1), c2 = (uint32_t)__shfl_down((int)c0, 1);
+        if (lane == 63u) {
+            lo2 = 0; hi2 = 0; c2 = 0xFFFFFFFFu;
+            if (w + 2 < n_words) { const uint64_t b = bases[w + 2]; lo2 = (uint32_t)b; hi2 = (uint32_t)(b >> 32); c2 = invalid[w + 2]; }
+        }
+        // positions past total_len never match, whatever the caller left in the invalid bits there
+        const uint32_t o0 = outside_bits(w, n_words, total_len), o1 = outside_bits(w + 1, n_words, total_len),
+                       o2 = outside_bits(w + 2, n_words, total_len);
+        c0 |= o0; c1 |= o1; c2 |= o2;
+        uint32_t f0, r0, f1, r1;
+        pam_eval<LEN, ANY>(pp, lo0, hi0, c0, o0, lo1, hi1, c1, o1, f0, r0);
+        pam_eval<LEN, ANY>(pp, lo1, hi1, c1, o1, lo2, hi2, c2, o2, f1, r1);
+        if (w + 1 < n_words && vec) {
+            __builtin_nontemporal_store(u32x2{f0, f1}, reinterpret_cast<u32x2*>(out_fwd) + t);
+            __builtin_nontemporal_store(u32x2{r0, r1}, reinterpret_cast<u32x2*>(out_rev) + t);
+        } else if (w < n_words) {
+            out_fwd[w] = f0;
+            out_rev[w] = r0;
+            if (w + 1 < n_words) { out_fwd[w + 1] = f1; out_rev[w + 1] = r1; }
+        }
     }
 }
 
@@ -184,11 +253,219 @@ __global__ __launch_bounds__(BLOCK) void k_windows(const uint64_t* __restrict__ 
     }
 }
 
+// ---- fused site pipeline: PAM test + spacer window test -> compact site list, two launches ---------------------
+// find_sites (pam.py) used to run scan -> popcount -> scan -> expand -> windows per strand (six launches, bitmaps and
+// position lists through HBM, flagged windows dropped on the host).  Here a block stages its 1 024 words (+ halo) in
+// LDS once and evaluates, per position p, "PAM matches at p AND the k-mer window at p + off is inside the sequence
+// and pure ACGT" as bit operations; launch 1 counts such sites per block and strand, launch 2 re-evaluates (12 bytes
+// per 32 positions: cheaper than writing and re-reading bitmaps), derives its output offset from the block counts
+// and writes {PAM position, oriented spacer word} for every site — forward-strand sites in ascending order, then
+// reverse-strand sites in ascending order, which is the order find_sites always had.
+constexpr int SITE_WPT = 4;                   // words per thread
+constexpr int SITE_WPB = BLOCK * SITE_WPT;    // words per block
+constexpr int SITE_BEFORE = 1, SITE_AFTER = 3;  // halo words: windows reach from p - 32 to p + 32 + 31 + 32
+constexpr uint32_t SITE_MAX_DIRECT = 4096;    // up to this many blocks every block sums the counts itself (two launches)
+
+struct SiteParams {
+    PamParams pp;
+    int k;                 // spacer length, 1..32
+    int off_fwd, off_rev;  // window start relative to the PAM position, per strand (-k or +pam_len)
+};
+
+struct SiteLds {
+    uint32_t lo[SITE_WPB + SITE_BEFORE + SITE_AFTER];
+    uint32_t hi[SITE_WPB + SITE_BEFORE + SITE_AFTER];
+    uint32_t inv[SITE_WPB + SITE_BEFORE + SITE_AFTER];
+};
+
+__device__ __forceinline__ void site_stage(const uint64_t* __restrict__ bases, const uint32_t* __restrict__ invalid,
+                                           uint64_t total_len, uint64_t n_words, uint64_t w0, SiteLds& L) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(SITE_WPB + SITE_BEFORE + SITE_AFTER); i += BLOCK) {
+        const int64_t w = (int64_t)w0 - SITE_BEFORE + (int64_t)i;
+        uint32_t lo = 0, hi = 0, inv = 0xFFFFFFFFu;
+        if (w >= 0 && (uint64_t)w < n_words) {
+            const uint64_t b = bases[w];
+            lo = (uint32_t)b; hi = (uint32_t)(b >> 32);
+            inv = invalid[w] | outside_bits((uint64_t)w, n_words, total_len);
+        }
+        L.lo[i] = lo; L.hi[i] = hi; L.inv[i] = inv;
+    }
+    __syncthreads();
+}
+
+// bit s of the result: the k positions from (32 * word(li) + s + off) on are all valid.  off in [-32, 32].
+__device__ __forceinline__ uint32_t window_ok(const SiteLds& L, int li, int off, int k) {
+    const int wi = li + (off >> 5), sh = off & 31;  // arithmetic shift: -32..-1 -> -1, 0..31 -> 0, 32 -> 1
+    const uint32_t a = ~L.inv[wi], b = ~L.inv[wi + 1], c = ~L.inv[wi + 2];
+    const uint64_t V = (uint64_t)funnel(a, b, sh) | ((uint64_t)funnel(b, c, sh) << 32);
+    // AND over a run of k by doubling: P(s) = AND of plen bits from s; acc collects the binary digits of k
+    uint64_t acc = ~0ull, P = V;
+    int pos = 0, plen = 1;
+    for (int kk = k; kk; kk >>= 1) {
+        if (kk & 1) { acc &= P >> pos; pos += plen; }
+        P &= P >> plen;
+        plen <<= 1;
+    }
+    return (uint32_t)acc;  // s + k - 1 <= 62: the zeros shifted in at the top never reach the low word
+}
+
+// valid-site bitmaps of the block's word number q (LDS index li)
+template <int LEN>
+__device__ __forceinline__ void site_bits(const SiteParams& sp, const SiteLds& L, int li, uint32_t& fv, uint32_t& rv) {
+    uint32_t f, r;
+    pam_eval<LEN, false>(sp.pp, L.lo[li], L.hi[li], L.inv[li], 0u, L.lo[li + 1], L.hi[li + 1], L.inv[li + 1], 0u, f, r);
+    fv = f ? (f & window_ok(L, li, sp.off_fwd, sp.k)) : 0u;
+    rv = r ? (r & window_ok(L, li, sp.off_rev, sp.k)) : 0u;
+}
+
+// launch 1: sites per block and strand -> counts[2 * block], counts[2 * block + 1]
+template <int LEN>
+__global__ __launch_bounds__(BLOCK) void k_sites_count(const uint64_t* __restrict__ bases, const uint32_t* __restrict__ invalid,
+                                                       uint64_t total_len, uint64_t n_words, SiteParams sp,
+                                                       uint32_t* __restrict__ counts) {
+    __shared__ SiteLds L;
+    const uint64_t w0 = (uint64_t)blockIdx.x * SITE_WPB;
+    site_stage(bases, invalid, total_len, n_words, w0, L);
+    uint32_t cf = 0, cr = 0;
+#pragma unroll
+    for (int q = 0; q < SITE_WPT; ++q) {
+        const int li = SITE_BEFORE + (int)threadIdx.x * SITE_WPT + q;
+        if (w0 + (uint64_t)(li - SITE_BEFORE) < n_words) {
+            uint32_t fv, rv;
+            site_bits<LEN>(sp, L, li, fv, rv);
+            cf += __popc(fv); cr += __popc(rv);
+        }
+    }
+    uint32_t tf, tr;
+    block_exclusive_scan(cf, &tf);
+    block_exclusive_scan(cr, &tr);
+    if (threadIdx.x == 0) { counts[2 * blockIdx.x] = tf; counts[2 * blockIdx.x + 1] = tr; }
+}
+
+// many blocks (genomes above 134 Mbp): counts -> exclusive prefixes in place, totals in counts[2 * n_blocks ..]
+__global__ __launch_bounds__(BLOCK) void k_sites_prefix(uint32_t* __restrict__ counts, uint32_t n_blocks) {
+    uint32_t carry_f = 0, carry_r = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += BLOCK) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t vf = i < n_blocks ? counts[2 * i] : 0u, vr = i < n_blocks ? counts[2 * i + 1] : 0u;
+        uint32_t tf, tr;
+        const uint32_t ef = block_exclusive_scan(vf, &tf), er = block_exclusive_scan(vr, &tr);
+        if (i < n_blocks) { counts[2 * i] = carry_f + ef; counts[2 * i + 1] = carry_r + er; }
+        carry_f += tf; carry_r += tr;
+    }
+    if (threadIdx.x == 0) { counts[2 * n_blocks] = carry_f; counts[2 * n_blocks + 1] = carry_r; }
+}
+
+// launch 2: the same evaluation, then one record per site
+template <int LEN, bool PREFIXED>
+__global__ __launch_bounds__(BLOCK) void k_sites_emit(const uint64_t* __restrict__ bases, const uint32_t* __restrict__ invalid,
+                                                      uint64_t total_len, uint64_t n_words, SiteParams sp,
+                                                      const uint32_t* __restrict__ counts, uint32_t n_blocks,
+                                                      uint32_t* __restrict__ out_pos, uint64_t* __restrict__ out_word,
+                                                      uint64_t cap, uint64_t* __restrict__ n_out) {
+    __shared__ SiteLds L;
+    __shared__ uint32_t red[4][BLOCK / 64];
+    const uint64_t w0 = (uint64_t)blockIdx.x * SITE_WPB;
+    site_stage(bases, invalid, total_len, n_words, w0, L);
+    // where this block's records go: forward sites of earlier blocks; all forward sites + reverse sites of earlier blocks
+    uint32_t before_f, before_r, total_f, total_r;
+    if (PREFIXED) {
+        before_f = counts[2 * blockIdx.x]; before_r = counts[2 * blockIdx.x + 1];
+        total_f = counts[2 * n_blocks]; total_r = counts[2 * n_blocks + 1];
+    } else {
+        uint32_t a[4] = {0, 0, 0, 0};  // before_f, before_r, total_f, total_r
+        for (uint32_t i = threadIdx.x; i < n_blocks; i += BLOCK) {
+            const uint32_t vf = counts[2 * i], vr = counts[2 * i + 1];
+            a[2] += vf; a[3] += vr;
+            if (i < blockIdx.x) { a[0] += vf; a[1] += vr; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) a[c] += (uint32_t)__shfl_xor((int)a[c], d);
+            if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = a[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[c] = 0; for (int q = 0; q < BLOCK / 64; ++q) a[c] += red[c][q]; }
+        before_f = a[0]; before_r = a[1]; total_f = a[2]; total_r = a[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { n_out[0] = total_f; n_out[1] = total_r; }
+    uint32_t fv[SITE_WPT], rv[SITE_WPT], cf = 0, cr = 0;
+#pragma unroll
+    for (int q = 0; q < SITE_WPT; ++q) {
+        const int li = SITE_BEFORE + (int)threadIdx.x * SITE_WPT + q;
+        fv[q] = 0; rv[q] = 0;
+        if (w0 + (uint64_t)(li - SITE_BEFORE) < n_words) site_bits<LEN>(sp, L, li, fv[q], rv[q]);
+        cf += __popc(fv[q]); cr += __popc(rv[q]);
+    }
+    uint32_t tf, tr;
+    uint64_t at_f = (uint64_t)before_f + block_exclusive_scan(cf, &tf);
+    uint64_t at_r = (uint64_t)total_f + before_r + block_exclusive_scan(cr, &tr);
+    const int k = sp.k;
+    const uint32_t km = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    auto emit = [&](uint32_t m, int li, int off, bool rev, uint64_t& at) {
+        while (m) {
+            const int b = __ffs(m) - 1;
+            m &= m - 1;
+            if (at < cap) {
+                const int s = b + off;  // window start relative to the word, -32 .. 63
+                const int wi = li + (s >> 5), sh = s & 31;
+                uint32_t lo = funnel(L.lo[wi], L.lo[wi + 1], sh) & km, hi = funnel(L.hi[wi], L.hi[wi + 1], sh) & km;
+                if (rev) { lo = (__brev(~lo) >> (32 - k)) & km; hi = (__brev(~hi) >> (32 - k)) & km; }
+                out_pos[at] = (uint32_t)((w0 + (uint64_t)(li - SITE_BEFORE)) * 32 + (uint32_t)b);
+                out_word[at] = (uint64_t)lo | ((uint64_t)hi << 32);
+            }
+            ++at;
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < SITE_WPT; ++q) {
+        const int li = SITE_BEFORE + (int)threadIdx.x * SITE_WPT + q;
+        emit(fv[q], li, sp.off_fwd, false, at_f);
+        emit(rv[q], li, sp.off_rev, true, at_r);
+    }
+}
+
 int grid_for(uint64_t items) {
     uint64_t b = (items + BLOCK - 1) / BLOCK;
     if (b < 1) b = 1;
     if (b > MAX_BLOCKS) b = MAX_BLOCKS;
     return (int)b;
+}
+
+bool pam_has_any(const PamParams& pp) {
+    bool any = false;
+    for (int j = 0; j < pp.len; ++j) any = any || (pp.fwd[j] & 16u) || (pp.rev[j] & 16u);
+    return any;
+}
+
+// pattern lengths 2..8 are compiled with the position loop unrolled; others take the run-time loop
+int launch_pam_scan(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t total_len, uint64_t n_words,
+                    const PamParams& pp, uint32_t* d_fwd, uint32_t* d_rev, hipStream_t st) {
+    const bool vec = (((uintptr_t)d_bases) & 15u) == 0 && (((uintptr_t)d_invalid) & 7u) == 0 &&
+                     (((uintptr_t)d_fwd) & 7u) == 0 && (((uintptr_t)d_rev) & 7u) == 0;
+    const bool any = pam_has_any(pp);
+    const int grid = grid_for((n_words + 1) / 2);
+#define BC_PAM_LAUNCH(LEN_)                                                                                            \
+    do {                                                                                                               \
+        if (any) hipLaunchKernelGGL((k_pam_scan<LEN_, true>), dim3(grid), dim3(BLOCK), 0, st, d_bases, d_invalid,       \
+                                    total_len, n_words, pp, d_fwd, d_rev, vec);                                        \
+        else hipLaunchKernelGGL((k_pam_scan<LEN_, false>), dim3(grid), dim3(BLOCK), 0, st, d_bases, d_invalid,          \
+                                total_len, n_words, pp, d_fwd, d_rev, vec);                                            \
+    } while (0)
+    switch (pp.len) {
+        case 2: BC_PAM_LAUNCH(2); break;
+        case 3: BC_PAM_LAUNCH(3); break;
+        case 4: BC_PAM_LAUNCH(4); break;
+        case 5: BC_PAM_LAUNCH(5); break;
+        case 6: BC_PAM_LAUNCH(6); break;
+        case 7: BC_PAM_LAUNCH(7); break;
+        case 8: BC_PAM_LAUNCH(8); break;
+        default: BC_PAM_LAUNCH(0); break;
+    }
+#undef BC_PAM_LAUNCH
+    return BC_OK;
 }
 
 uint8_t comp_mask(uint8_t m) {  // A<->T, C<->G; the any-character flag stays
@@ -207,7 +484,7 @@ int bc_pam_scan_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t
         return BC_EINVAL;
     }
     if (total_len == 0) return BC_OK;
-    PamParams pp;
+    PamParams pp{};
     pp.len = pam_len;
     for (int j = 0; j < pam_len; ++j) {
         if ((pam_masks[j] & 15) == 0 || pam_masks[j] > 31) {
@@ -218,9 +495,35 @@ int bc_pam_scan_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t
         pp.rev[j] = comp_mask(pam_masks[pam_len - 1 - j]);
     }
     uint64_t n_words = (total_len + 31) / 32;
-    hipLaunchKernelGGL(k_pam_scan, dim3(grid_for(n_words)), dim3(BLOCK), 0, (hipStream_t)stream, d_bases,
-                       d_invalid, total_len, n_words, pp, d_fwd, d_rev);
+    int rc = launch_pam_scan(d_bases, d_invalid, total_len, n_words, pp, d_fwd, d_rev, (hipStream_t)stream);
+    if (rc != BC_OK) return rc;
     BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+// the scan launched `iters` times back to back from this loop (no per-launch trip through the caller's language),
+// HIP events around them on the launch stream: mean milliseconds per launch
+int bc_pam_scan_time_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t total_len,
+                         const uint8_t* pam_masks, int pam_len, uint32_t* d_fwd, uint32_t* d_rev, int iters,
+                         void* stream, float* ms_out) {
+    if (!ms_out || iters < 1) { set_error("bc_pam_scan_time_dev: bad argument"); return BC_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    BC_HIP(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return BC_EHIP; }
+    int rc = BC_OK;
+    hipError_t e = hipEventRecord(e0, st);
+    for (int it = 0; it < iters && rc == BC_OK && e == hipSuccess; ++it)
+        rc = bc_pam_scan_dev(d_bases, d_invalid, total_len, pam_masks, pam_len, d_fwd, d_rev, stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != BC_OK) return rc;
+    if (e != hipSuccess) { set_error("bc_pam_scan_time_dev: %s", hipGetErrorString(e)); return BC_EHIP; }
+    *ms_out = ms / iters;
     return BC_OK;
 }
 
@@ -285,6 +588,98 @@ int bc_windows_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t 
     uint64_t n_words = (total_len + 31) / 32;
     hipLaunchKernelGGL(k_windows, dim3(grid_for(n_pos)), dim3(BLOCK), 0, (hipStream_t)stream, d_bases,
                        d_invalid, total_len, n_words, d_pos, n_pos, offset, k, strand, d_out, d_flags);
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int site_params(const uint8_t* pam_masks, int pam_len, int k, int direction, const char* who, SiteParams* sp) {
+    if (!pam_masks || pam_len < 1 || pam_len > 32 || k < 1 || k > 32 || direction < 0 || direction > 1) {
+        set_error("%s: bad argument (pam_len=%d k=%d direction=%d)", who, pam_len, k, direction);
+        return BC_EINVAL;
+    }
+    *sp = SiteParams{};
+    sp->pp.len = pam_len;
+    for (int j = 0; j < pam_len; ++j) {
+        if ((pam_masks[j] & 15) == 0 || pam_masks[j] > 15) {  // (no BC_PAM_ANY_CHAR here: a spacer next to it could not be ACGT-checked the same way)
+            set_error("%s: pattern position %d has an empty or unsupported base set", who, j);
+            return BC_EINVAL;
+        }
+        sp->pp.fwd[j] = pam_masks[j];
+        sp->pp.rev[j] = comp_mask(pam_masks[pam_len - 1 - j]);
+    }
+    sp->k = k;
+    // downstream PAM (direction 0): spacer ends where the PAM starts on its own strand (design_guides.py:33-38);
+    // on the reverse strand that is the window right after the reverse-complemented pattern.  Upstream: mirrored.
+    sp->off_fwd = direction == 0 ? -k : pam_len;
+    sp->off_rev = direction == 0 ? pam_len : -k;
+    return BC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int bc_pam_sites_count_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t total_len,
+                           const uint8_t* pam_masks, int pam_len, int k, int direction, uint32_t* d_counts,
+                           void* stream) {
+    SiteParams sp;
+    int rc = site_params(pam_masks, pam_len, k, direction, "bc_pam_sites_count_dev", &sp);
+    if (rc != BC_OK) return rc;
+    if (!d_bases || !d_invalid || !d_counts) { set_error("bc_pam_sites_count_dev: null argument"); return BC_EINVAL; }
+    if (total_len > 0xFFFFFFFFull) { set_error("bc_pam_sites_count_dev: positions must fit 32 bits"); return BC_EINVAL; }
+    if (total_len == 0) return BC_OK;
+    const uint64_t n_words = (total_len + 31) / 32;
+    const uint32_t n_blocks = (uint32_t)((n_words + SITE_WPB - 1) / SITE_WPB);
+    hipStream_t st = (hipStream_t)stream;
+#define BC_SITES_COUNT(LEN_) hipLaunchKernelGGL((k_sites_count<LEN_>), dim3(n_blocks), dim3(BLOCK), 0, st, d_bases, d_invalid, total_len, n_words, sp, d_counts)
+    switch (pam_len) {
+        case 2: BC_SITES_COUNT(2); break;
+        case 3: BC_SITES_COUNT(3); break;
+        case 4: BC_SITES_COUNT(4); break;
+        case 5: BC_SITES_COUNT(5); break;
+        case 6: BC_SITES_COUNT(6); break;
+        default: BC_SITES_COUNT(0); break;
+    }
+#undef BC_SITES_COUNT
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+int bc_pam_sites_emit_dev(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t total_len,
+                          const uint8_t* pam_masks, int pam_len, int k, int direction, uint32_t* d_counts,
+                          uint32_t* d_pos, uint64_t* d_words, uint64_t cap, uint64_t* d_n_out, void* stream) {
+    SiteParams sp;
+    int rc = site_params(pam_masks, pam_len, k, direction, "bc_pam_sites_emit_dev", &sp);
+    if (rc != BC_OK) return rc;
+    if (!d_bases || !d_invalid || !d_counts || !d_n_out || (cap && (!d_pos || !d_words))) {
+        set_error("bc_pam_sites_emit_dev: null argument");
+        return BC_EINVAL;
+    }
+    if (total_len > 0xFFFFFFFFull) { set_error("bc_pam_sites_emit_dev: positions must fit 32 bits"); return BC_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    if (total_len == 0) { BC_HIP(hipMemsetAsync(d_n_out, 0, 16, st)); return BC_OK; }
+    const uint64_t n_words = (total_len + 31) / 32;
+    const uint32_t n_blocks = (uint32_t)((n_words + SITE_WPB - 1) / SITE_WPB);
+    const bool prefixed = n_blocks > SITE_MAX_DIRECT;
+    if (prefixed) hipLaunchKernelGGL(k_sites_prefix, dim3(1), dim3(BLOCK), 0, st, d_counts, n_blocks);
+#define BC_SITES_EMIT(LEN_)                                                                                          \
+    do {                                                                                                             \
+        if (prefixed) hipLaunchKernelGGL((k_sites_emit<LEN_, true>), dim3(n_blocks), dim3(BLOCK), 0, st, d_bases,    \
+                                         d_invalid, total_len, n_words, sp, d_counts, n_blocks, d_pos, d_words, cap, d_n_out); \
+        else hipLaunchKernelGGL((k_sites_emit<LEN_, false>), dim3(n_blocks), dim3(BLOCK), 0, st, d_bases, d_invalid,  \
+                                total_len, n_words, sp, d_counts, n_blocks, d_pos, d_words, cap, d_n_out);           \
+    } while (0)
+    switch (pam_len) {
+        case 2: BC_SITES_EMIT(2); break;
+        case 3: BC_SITES_EMIT(3); break;
+        case 4: BC_SITES_EMIT(4); break;
+        case 5: BC_SITES_EMIT(5); break;
+        case 6: BC_SITES_EMIT(6); break;
+        default: BC_SITES_EMIT(0); break;
+    }
+#undef BC_SITES_EMIT
     BC_HIP(hipGetLastError());
     return BC_OK;
 }

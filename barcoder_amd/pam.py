@@ -83,10 +83,58 @@ class Sites:
     pam_pos: np.ndarray  # int64: forward-coordinate start of the PAM footprint
 
 
+def _at(p, off: int):
+    return N.vp((p.value or 0) + off)
+
+
 def find_sites(g: PackedGenome, pam: str, k: int, direction: str = "downstream", device: int = 0,
                iupac: bool = False) -> Sites:
-    """Device pipeline: pattern bitmaps -> position lists -> k-mer windows.
-    Only sites whose spacer is pure ACGT and lies inside [0, total) are kept."""
+    """Device pipeline in two launches (bc_pam_sites_count_dev / bc_pam_sites_emit_dev): PAM test and spacer-window
+    test (inside [0, total), pure ACGT) per position, then one {PAM position, oriented spacer} record per site —
+    forward-strand sites in ascending order, then reverse-strand sites."""
+    if direction not in ("downstream", "upstream"):
+        raise ValueError("Direction must be 'upstream' or 'downstream'")  # PAMProcessor.py:53
+    L = N.load()
+    masks = pam_masks(pam, iupac)
+    pl = masks.size
+    nw = g.bases.size
+    if g.total == 0:
+        z = np.zeros(0, np.int64)
+        return Sites(z, np.zeros(0, np.uint8), np.zeros(0, np.uint64), z)
+    dirn = 0 if direction == "downstream" else 1
+    nb = (nw + 1023) // 1024
+    N.check(L.bc_dev_set(device))
+    # one allocation in: [bases | invalid | block counts]; one out: [spacer words | positions | totals]
+    o_inv, o_cnt = nw * 8, nw * 8 + ((nw * 4 + 15) // 16) * 16
+    with DevBuf(o_cnt + 2 * (nb + 1) * 4, device) as d_in:
+        N.check(L.bc_dev_h2d(d_in.ptr, N.ptr(np.ascontiguousarray(g.bases)), nw * 8, None))
+        N.check(L.bc_dev_h2d(_at(d_in.ptr, o_inv), N.ptr(np.ascontiguousarray(g.invalid)), nw * 4, None))
+        N.check(L.bc_pam_sites_count_dev(d_in.ptr, _at(d_in.ptr, o_inv), g.total, N.ptr(masks), pl, k, dirn,
+                                         _at(d_in.ptr, o_cnt), None))
+        cnt = np.empty(2 * nb, np.uint32)
+        N.check(L.bc_dev_d2h(N.ptr(cnt), _at(d_in.ptr, o_cnt), cnt.nbytes, None))
+        n_f, n_r = int(cnt[0::2].sum(dtype=np.uint64)), int(cnt[1::2].sum(dtype=np.uint64))
+        n = n_f + n_r
+        o_pos = n * 8
+        with DevBuf(n * 12 + 32, device) as d_out:
+            N.check(L.bc_pam_sites_emit_dev(d_in.ptr, _at(d_in.ptr, o_inv), g.total, N.ptr(masks), pl, k, dirn,
+                                            _at(d_in.ptr, o_cnt), _at(d_out.ptr, o_pos), d_out.ptr, n,
+                                            _at(d_out.ptr, ((n * 12 + 15) // 16) * 16), None))
+            raw = np.empty(n * 12, np.uint8)
+            if n:
+                N.check(L.bc_dev_d2h(N.ptr(raw), d_out.ptr, n * 12, None))
+    words = raw[:n * 8].view(np.uint64)
+    pos = raw[n * 8:].view(np.uint32).astype(np.int64)
+    strand = np.zeros(n, np.uint8)
+    strand[n_f:] = 1
+    off = np.where(strand == 0, -k if dirn == 0 else pl, pl if dirn == 0 else -k)
+    return Sites(pos + off, strand, words.copy(), pos)
+
+
+def find_sites_staged(g: PackedGenome, pam: str, k: int, direction: str = "downstream", device: int = 0,
+                      iupac: bool = False) -> Sites:
+    """The same result from the separate stages (pattern bitmaps -> position lists -> k-mer windows, six
+    launches): the building blocks targets.find_hits uses, kept as the cross-check of the fused pipeline."""
     if direction not in ("downstream", "upstream"):
         raise ValueError("Direction must be 'upstream' or 'downstream'")  # PAMProcessor.py:53
     L = N.load()

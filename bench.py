@@ -91,7 +91,39 @@ def cpu_baseline(lib_packed, n_sample, seed, max_mm):
                             indexed_equals_brute_force_on_prefix=bool(same))
 
 
-def secondary_workloads(torch, dev, local, stream, lib_packed, matcher, n, steps):
+def cpu_baseline_exact(lib_packed, best_idx_dev, n):
+    """configs[1] on the CPU: oracle.c's restatement of the reference's exact-match loop (orc_process_chunk_single =
+    heuristicount.py:520-538: N-skip, window slice, flank test, string hash-set lookup) over the first reads of the
+    same stream as 20-character strings, one thread (the reference runs one such loop per Pool worker)."""
+    import ctypes as C
+    import numpy as np
+    from barcoder_amd import synth as S
+    from oracle import oracle as orc
+    m = int(min(n, 20_000_000))
+    la = ascii_from_packed(lib_packed, K)
+    reads = np.concatenate([S.reads(lib_packed, K, 1, a, min(5_000_000, m - a), 0) for a in range(0, m, 5_000_000)])
+    text = ascii_from_packed(reads, K)
+    off = np.arange(m + 1, dtype=np.uint64) * np.uint64(K)
+    out = np.empty(m, np.int32)
+    so = np.empty(m, np.int64)
+    sl = np.empty(m, np.int64)
+    t0 = time.perf_counter()
+    orc.lib().orc_process_chunk_single(text.ctypes.data_as(C.c_char_p), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       C.c_uint64(m), la.ctypes.data_as(C.c_char_p), C.c_uint32(la.shape[0]), C.c_int(K),
+                                       C.c_int64(0), C.c_char_p(b""), C.c_int(0), C.c_char_p(b""), C.c_int(0), C.c_int(0),
+                                       out.ctypes.data_as(C.POINTER(C.c_int32)), so.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       sl.ctypes.data_as(C.POINTER(C.c_int64)))
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(best_idx_dev[:m].cpu().numpy(), out))
+    return {"value": m / dt / 1e6, "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": f"first {m} reads of the same stream as {K}-character strings, {dt:.2f} s, oracle/oracle.c "
+                      "orc_process_chunk_single (heuristicount.py:520-538)",
+            "parity_on_sample": same,
+            "reference_measured_in_container": {"value": 0.79, "unit": "Mreads/s per core", "marginal_4_workers": 0.73,
+                                                "source": "SURVEY.md section 6: heuristicount.process_chunk, 8 vCPU Xeon 2.6 GHz, Pool(4); not this host"}}
+
+
+def secondary_workloads(torch, dev, local, stream, lib_packed, matcher, n, steps, with_cpu=True):
     """The other BASELINE configurations and the host-inclusive rates, measured after the timed region (rank 0,
     N = 1).  Each entry is bounded to a few seconds and reports its own failure instead of taking the headline down."""
     import numpy as np
@@ -120,40 +152,77 @@ def secondary_workloads(torch, dev, local, stream, lib_packed, matcher, n, steps
         p_ms = matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=max(3, steps),
                                 d_counts=c32.data_ptr(), d_first_seen=fs.data_ptr(), **kw)
         hit = float((bi >= 0).float().mean().item())
-        return {"workload": f"20-mer exact match, {lib_packed.size} guides, {n} reads (BASELINE configs[1])",
-                "kernel": "k_match_hash", "kernel_ms": k_ms, "pass_ms": p_ms, "Mreads_per_s": n / p_ms / 1e3,
-                "frac": n * ALGO_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "pass_frac": n * ALGO_BYTES / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "matched_fraction": hit}
+        res = {"workload": f"20-mer exact match, {lib_packed.size} guides, {n} reads (BASELINE configs[1])",
+               "kernel": "k_match_hash", "kernel_ms": k_ms, "timing": "HIP events on the launch stream (bc_match_time_dev)",
+               "pass_ms": p_ms, "Mreads_per_s": n / p_ms / 1e3,
+               "frac": n * ALGO_BYTES / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "pass_frac": n * ALGO_BYTES / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "matched_fraction": hit}
+        if with_cpu:
+            res["cpu_baseline"] = cpu_baseline_exact(lib_packed, bi, n)
+        return res
 
     def pam():  # BASELINE configs[3]: NGG / 20-mer site scan over an E. coli-sized genome
+        import ctypes as C
         from barcoder_amd import _native as N, pam as P
         from barcoder_amd.devmem import DevBuf
         from barcoder_amd.encoding import pam_masks
         L = N.load()
         bp = 4_641_652
-        g = P.pack_genome(S.genome(bp, seed=4), wrap=22)
+        seq = S.genome(bp, seed=4)
+        g = P.pack_genome(seq, wrap=22)
         masks = pam_masks("NGG")
         nw = g.bases.size
-        iters = 500
+
+        def scan_ms(d_b, d_i, total, d_f, d_r, iters):
+            # launches issued back to back from C, HIP events around them on the launch stream: the old figure (a host
+            # timer around a Python loop of asynchronous launches) measured the host's launch rate — 7.7 us per launch
+            # on an idle host, 81 us on the driver's box right after the 128-thread OpenMP baseline (its worker threads
+            # still spinning) — not the kernel
+            ms = C.c_float(0)
+            N.check(L.bc_pam_scan_time_dev(d_b, d_i, total, N.ptr(masks), 3, d_f, d_r, iters, stream, C.byref(ms)))
+            return float(ms.value)
+
         with DevBuf.from_numpy(g.bases, local) as d_b, DevBuf.from_numpy(g.invalid, local) as d_i, \
                 DevBuf(nw * 4, local) as d_f, DevBuf(nw * 4, local) as d_r:
-            for _ in range(3):
-                N.check(L.bc_pam_scan_dev(d_b.ptr, d_i.ptr, g.total, N.ptr(masks), 3, d_f.ptr, d_r.ptr, None))
-            N.check(L.bc_dev_sync(None))
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                N.check(L.bc_pam_scan_dev(d_b.ptr, d_i.ptr, g.total, N.ptr(masks), 3, d_f.ptr, d_r.ptr, None))
-            N.check(L.bc_dev_sync(None))
-            dt = (time.perf_counter() - t0) / iters
+            scan_ms(d_b.ptr, d_i.ptr, g.total, d_f.ptr, d_r.ptr, 20)
+            ms = scan_ms(d_b.ptr, d_i.ptr, g.total, d_f.ptr, d_r.ptr, 500)
+            dev_bits = [np.unpackbits(d.to_numpy(np.uint32).view(np.uint8), bitorder="little")[:g.total] for d in (d_f, d_r)]
         P.find_sites(g, "NGG", 20)
         t0 = time.perf_counter()
         st = P.find_sites(g, "NGG", 20)
         pipe = time.perf_counter() - t0
         byts = nw * (8 + 4 + 4 + 4)
-        return {"workload": f"NGG site scan, both strands, {bp} bp synthetic circular genome (BASELINE configs[3])",
-                "kernel": "k_pam_scan", "us_per_scan": dt * 1e6, "Gbp_per_s": bp / dt / 1e9,
-                "frac": byts / dt / 1e9 / HBM_PEAK_GBPS, "note": "launch-bound at this size",
-                "find_sites_ms_incl_h2d_d2h": pipe * 1e3, "sites": int(st.start.size)}
+        res = {"workload": f"NGG site scan, both strands, {bp} bp synthetic circular genome (BASELINE configs[3])",
+               "kernel": "k_pam_scan", "kernel_ms": ms, "us_per_scan": ms * 1e3,
+               "timing": "HIP events around 500 back-to-back launches issued from C (bc_pam_scan_time_dev)",
+               "Gbp_per_s": bp / (ms * 1e-3) / 1e9, "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "note": "launch-bound at this size (2.9 MB of algorithmic bytes per launch)",
+               "find_sites_ms_incl_h2d_d2h": pipe * 1e3, "find_sites_launches": 2, "sites": int(st.start.size)}
+        # the same kernel where it is HBM-bound: a 3.1e9-position genome (packed words filled on the device)
+        big = 3_100_000_000
+        bw = (big + 31) // 32
+        tb = torch.randint(-2**62, 2**62, (bw,), dtype=torch.int64, device=dev)
+        ti = torch.zeros(bw, dtype=torch.int32, device=dev)
+        tf = torch.empty(bw, dtype=torch.int32, device=dev)
+        tr = torch.empty(bw, dtype=torch.int32, device=dev)
+        scan_ms(tb.data_ptr(), ti.data_ptr(), big, tf.data_ptr(), tr.data_ptr(), 2)
+        bms = scan_ms(tb.data_ptr(), ti.data_ptr(), big, tf.data_ptr(), tr.data_ptr(), 10)
+        del tb, ti, tf, tr
+        res["hbm_bound_3p1Gbp"] = {"bp": big, "kernel_ms": bms, "algorithmic_GB_per_s": bw * 20 / (bms * 1e-3) / 1e9,
+                                   "frac": bw * 20 / (bms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                   "bytes_per_32bp": "12 in (planes + invalid bits) + 8 out (two bitmaps)"}
+        if with_cpu:
+            from oracle import oracle as orc
+            topo = seq + seq[:22]
+            t0 = time.perf_counter()
+            of, orv = orc.pam_bitmaps(topo, "NGG")
+            cdt = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": bp / cdt / 1e6, "unit": "Mbp/s", "cores": 1, "kind": "port",
+                                   "sample": f"the whole {bp}-bp genome, both strands, oracle/oracle.c orc_pam_scan (characters), {cdt * 1e3:.1f} ms",
+                                   "reference_measured_elsewhere": "design_interactive.ipynb:306,344 logs ~6 s for the reference's "
+                                                                   "find_sequences_with_barcode_and_pam on E. coli (unknown hardware)",
+                                   "parity_on_sample": bool(np.array_equal(dev_bits[0], of) and np.array_equal(dev_bits[1], orv))}
+        return res
 
     def host_pcie():  # bc_match_host: host buffers in, host results out (PCIe included), <= 2 mismatches
         m = min(n, 20_000_000)
@@ -214,7 +283,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=float, default=1e8, help="reads per GPU")
+    ap.add_argument("--reads", type=float, default=None,
+                    help="reads per GPU (default 1e8 = BASELINE configs[2]; with --gpus 8: 1.25e8 = configs[4], 1e9 reads in all)")
     ap.add_argument("--guides", type=int, default=G)
     ap.add_argument("--k", type=int, default=K, help="k-mer length (default 20: BASELINE configs[2]; 32 = the shipped CN-32 geometry)")
     ap.add_argument("--algo", default="seed", choices=["seed", "seed_csr", "brute", "hash", "auto"])
@@ -225,6 +295,10 @@ def main():
     ap.add_argument("--mixture", type=int, default=1, help="synthetic stream: 1 = SURVEY cfg3 mismatch mix (default), 0 = cfg2 exact mix")
     args = ap.parse_args()
 
+    if args.reads is None:
+        args.reads = 1.25e8 if args.gpus == 8 else 1e8
+        if args.gpus > 1:  # the children parse the same value
+            sys.argv += ["--reads", repr(args.reads)]
     # ---- self-launch: N ranks as fresh child processes, before this process imports torch or touches the GPU
     if args.gpus > 1 and not ("WORLD_SIZE" in os.environ and "RANK" in os.environ):
         launcher = _dist_module_without_package()
@@ -355,7 +429,8 @@ def run(args):
             "value_median": world * n / (med_ms * 1e-3) / 1e6,
             "ms_per_step_median": med_ms,
             "config": {"workload": f"{K}-mer <={args.max_mismatch}-mismatch best hit, {Gn}-guide library, "
-                                   f"{n} reads per GPU" + (" (BASELINE configs[2])" if (K, args.max_mismatch, Gn) == (20, 2, 100_000) else ""),
+                                   f"{n} reads per GPU" + (" (BASELINE configs[4]: 1e9 reads over 8 GPUs)" if (K, args.max_mismatch, Gn, n, world) == (20, 2, 100_000, 125_000_000, 8)
+                                                           else " (BASELINE configs[2])" if (K, args.max_mismatch, Gn) == (20, 2, 100_000) else ""),
                        "algo": args.algo, "reads_per_gpu": n, "guides": Gn, "k": K,
                        "max_mismatch": args.max_mismatch, "matched_fraction": matched / n,
                        "job_matched_reads": total_hits,
@@ -371,20 +446,39 @@ def run(args):
                          "pass_achieved": n * ALGO_BYTES / (pass_ms * 1e-3) / 1e9,
                          "pass_frac": n * ALGO_BYTES / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         }
+        # roofline.traffic: HBM bytes per launch of the dominant kernel from the separate FETCH_SIZE / WRITE_SIZE passes
+        # (a PMC pass cannot run inside this process).  The tracked profile is quoted only when it was collected on the
+        # kernel sources this run was built from and on the kernel that just ran; otherwise the line says "stale".
         tr = os.path.join(ROOT, "profiles", "traffic.json")
+        out["roofline"]["traffic_source"] = "none (profiles/traffic.json absent)"
         if os.path.exists(tr):
             try:
+                from barcoder_amd.stamp import match_source_stamp
                 t = json.load(open(tr))
-                if t.get("reads") == n and t.get("algo") == args.algo and t.get("max_mismatch") == args.max_mismatch:
+                here = match_source_stamp()
+                same_cfg = t.get("reads") == n and t.get("algo") == args.algo and t.get("max_mismatch") == args.max_mismatch \
+                    and Gn == G and K == 20
+                same_src = t.get("match_source_stamp") == here
+                same_kernel = str(t.get("dominant_kernel", "")).startswith(str(dl.last_kernel))
+                if not same_cfg:
+                    out["roofline"]["traffic_source"] = "none (profiles/traffic.json is for another configuration)"
+                elif not (same_src and same_kernel):
+                    out["roofline"]["traffic_source"] = (f"stale: profiles/traffic.json was measured on kernel sources "
+                                                         f"{t.get('match_source_stamp')} / {t.get('dominant_kernel')}, this run is "
+                                                         f"{here} / {dl.last_kernel} (re-run profiles/refresh.sh)")
+                else:
                     # per launch of the dominant kernel, like `achieved`; the whole pass (with the tally) beside it
                     dom = [v["hbm_bytes"] for k_, v in t.get("per_kernel", {}).items() if k_.startswith("k_match")]
                     out["roofline"]["traffic"] = dom[0] if dom else t["hbm_bytes_per_pass"]
                     out["roofline"]["pass_traffic"] = t["hbm_bytes_per_pass"]
+                    out["roofline"]["traffic_source"] = (f"profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                         f"{t.get('dominant_kernel')} on kernel sources {here} ({t.get('source')}); "
+                                                         "not collected in this run")
                     notes = [v["note"] for k_, v in t.get("per_kernel", {}).items() if k_.startswith("k_match") and v.get("note")]
                     if notes:  # e.g. the read-stream prefetch: part of the stream is fetched twice on purpose
                         out["roofline"]["traffic_note"] = notes[0]
-            except Exception:
-                pass
+            except Exception as e:  # noqa: BLE001
+                out["roofline"]["traffic_source"] = f"none (profiles/traffic.json unreadable: {e})"
         if world == 1 and not args.no_cpu:
             ref, sample_reads, cb = cpu_baseline(lib_packed, args.cpu_sample, seed, args.max_mismatch)
             m_ = len(sample_reads)
@@ -393,7 +487,8 @@ def run(args):
                                           np.array_equal(n_best[:m_].cpu().numpy(), ref["n_best"]))
             out["cpu_baseline"] = cb
         if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_workloads(torch, dev, local, stream, lib_packed, m, n, args.steps)
+            out["secondary"] = secondary_workloads(torch, dev, local, stream, lib_packed, m, n, args.steps,
+                                                   with_cpu=not args.no_cpu)
     D.barrier()
     D.shutdown()
     return json.dumps(out) if rank == 0 else None

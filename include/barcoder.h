@@ -317,6 +317,35 @@ int bc_pam_scan_host(int device, const uint64_t *h_bases, const uint32_t *h_inva
                      uint64_t total_len, const uint8_t *pam_masks, int pam_len,
                      uint32_t *h_fwd, uint32_t *h_rev);
 
+/* Timing aid for benchmarks: bc_pam_scan_dev launched `iters` times back to back
+ * from C, HIP events around them on `stream`; *ms_out = mean ms per launch. */
+int bc_pam_scan_time_dev(const uint64_t *d_bases, const uint32_t *d_invalid, uint64_t total_len,
+                         const uint8_t *pam_masks, int pam_len, uint32_t *d_fwd, uint32_t *d_rev,
+                         int iters, void *stream, float *ms_out);
+
+/* bc_pam_sites_*: the whole site pipeline of design_guides.py:22-49
+ * (find_sequences_with_barcode_and_pam) / PAMProcessor.py:34-57 in two launches:
+ * every position p where the PAM matches (either strand) AND the k-mer window
+ * next to it — [p-k, p) forward / [p+pam_len, p+pam_len+k) reverse for
+ * direction 0 (PAM downstream of the spacer), mirrored for direction 1 — lies
+ * inside [0, total_len) and is pure ACGT (design_guides.py:36,46).
+ *   count: d_counts[2b], d_counts[2b+1] = forward / reverse sites of block b of
+ *          1024 words; d_counts holds 2*(ceil(n_words/1024)+1) uint32.  The
+ *          caller sums them to size the outputs.
+ *   emit:  d_pos[i] = PAM position, d_words[i] = the spacer, oriented 5'->3' on
+ *          its own strand (plane form), forward-strand sites first (ascending
+ *          position), then reverse-strand sites (ascending); d_n_out[0..1] =
+ *          the two totals (uint64).  Records beyond `cap` are not written.
+ *          Consumes d_counts (genomes above 134 Mbp prefix-sum it in place).
+ * pam_masks as for bc_pam_scan_dev, without BC_PAM_ANY_CHAR. */
+int bc_pam_sites_count_dev(const uint64_t *d_bases, const uint32_t *d_invalid, uint64_t total_len,
+                           const uint8_t *pam_masks, int pam_len, int k, int direction,
+                           uint32_t *d_counts, void *stream);
+int bc_pam_sites_emit_dev(const uint64_t *d_bases, const uint32_t *d_invalid, uint64_t total_len,
+                          const uint8_t *pam_masks, int pam_len, int k, int direction,
+                          uint32_t *d_counts, uint32_t *d_pos, uint64_t *d_words, uint64_t cap,
+                          uint64_t *d_n_out, void *stream);
+
 /* bc_sites_expand_dev: bitmap -> ascending position list (uint32).  *d_n_out
  * (uint64) receives the number of set bits; positions beyond `cap` are not
  * written.  d_tmp must hold ceil(n_words/1024)+1 uint32. */

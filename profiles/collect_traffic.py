@@ -14,7 +14,9 @@ through scalar loads that are counted in full (see below).
 k_first_refine reads 4-byte words (uncalibrated width: taken as counted).
 usage: python profiles/collect_traffic.py profiles/r01_rocprof_summary.json reads algo max_mm
 """
-import json, sys
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from barcoder_amd.stamp import match_source_stamp
 src, reads, algo, mm = sys.argv[1], int(float(sys.argv[2])), sys.argv[3], int(sys.argv[4])
 d = json.load(open(src))["pmc"]
 rows, total = {}, 0.0
@@ -50,6 +52,9 @@ for name, e in d.items():
     total += f * corr + add + w
 out = {"reads": reads, "algo": algo, "max_mismatch": mm, "hbm_bytes_per_pass": total, "per_kernel": rows,
        "algorithmic_bytes_per_pass": 13 * reads, "source": src,
+       # what the counters were collected on: bench.py quotes the figure only for the same kernel sources and kernel
+       "match_source_stamp": match_source_stamp(),
+       "dominant_kernel": next((k for k in rows if k.startswith("k_match")), None),
        "note": "FETCH_SIZE counts Infinity-Cache hits too; the match kernel's table misses are included as fetched bytes"}
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

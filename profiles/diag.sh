@@ -1,8 +1,11 @@
 #!/bin/bash
 # stage attribution of k_match_wq: VALU wave-instructions and kernel time with stages switched off (BC_DIAG bits:
 # 1 = no table-2 phase, 2 = no table-1 phase / item drain, 4 = no tie resolution).  Results are wrong with any bit set.
+# Needs the diag build (`make -C barcoder_amd/csrc diag` before the gpurun call): the release library has no BC_DIAG.
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+export BC_NATIVE_SO=$GRAFT_REPO_ROOT/barcoder_amd/libbarcoder_hip_diag.so
+[ -f "$BC_NATIVE_SO" ] || { echo "diag.sh: $BC_NATIVE_SO missing (make -C barcoder_amd/csrc diag)"; exit 1; }
 for d in ${DIAGS:-0 1 2 3 4 7}; do
   rm -rf gpurun_out/dg; mkdir -p gpurun_out/dg
   for pass in "SQ_INSTS_VALU SQ_INSTS_SALU" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do

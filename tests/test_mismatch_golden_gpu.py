@@ -107,3 +107,50 @@ def test_d1_counts_bound_d0_counts(gpu_device, tmp_path):
         assert all(got[b] >= c for b, c in ref.items()), s["name"]
         grew += sum(got.values()) - sum(ref.values())
     assert grew > 0  # the scenarios contain 1-mismatch decoys: some must have been picked up
+
+
+@pytest.mark.parametrize("budget", [2, 3])
+def test_reference_multi_substitution_pairs_pin_d2_d3(gpu_device, oracle, budget):
+    """d = 2 and d = 3 pinned by vectors the reference holds: the 42 (original, variant, y_pred) pairs that
+    mismatch.py:15-35 (calculate_y_pred, `recalculate` mode) scored — 22 with one substitution, 9 with two, 10 with
+    three, one identical (tests/golden/mismatch.json "pairs", from the unmodified reference).  With the variant as
+    the read and the originals in front of 5 000 decoys as the library, the HIP matcher at max_mismatch = budget
+    (wave kernel for 2, cascade incl. the pair index for 3) must return every variant within the budget to its
+    original at distance = its number of substitutions with n_best = 1, leave the others unmatched, and
+    bc_score_mismatch_dev(best guide, read) must equal the reference's y_pred bit for bit — which pins the mismatch
+    mask of a d >= 2 hit record."""
+    from barcoder_amd import DeviceLibrary, GpuMatcher, encoding as E, mismatch as M, synth as S
+    m = json.load(open(os.path.join(GOLDEN, "mismatch.json")))
+    pairs = [(o.upper(), v.upper(), y) for o, v, y in m["pairs"]]
+    k = len(pairs[0][0])
+    originals = list(dict.fromkeys(o for o, _, _ in pairs))
+    decoys = [s for s in E.unpack_kmers(S.library(5000, k), k) if s not in originals]
+    lib_s = originals + decoys
+    lib, fl = E.pack_kmers(lib_s, k)
+    assert not fl.any()
+    variants = [v for _, v, _ in pairs]
+    nsub = np.array([sum(a != b for a, b in zip(o, v)) for o, v, _ in pairs])
+    assert sorted(set(nsub.tolist())) == [0, 1, 2, 3]
+    want_idx = np.array([originals.index(o) if d <= budget else -1 for (o, _, _), d in zip(pairs, nsub)], np.int32)
+    # no decoy comes within the budget of a variant (checked, not assumed): the oracle's brute force agrees
+    ref = oracle.best_hit(lib_s, variants, budget)
+    np.testing.assert_array_equal(ref["best_idx"], want_idx)
+    reps = 64  # enough reads for the vectorised kernels (the same 42 variants over and over)
+    reads, fl = E.pack_kmers(variants * reps, k)
+    assert not fl.any()
+    dl = DeviceLibrary(lib, k, gpu_device)
+    for algo in ("seed", "brute", "seed_csr"):
+        res = GpuMatcher(dl).match(reads, None, max_mismatch=budget, algo=algo)
+        if algo == "seed":
+            assert dl.last_kernel == ("k_match_wq" if budget == 2 else "cascade3:d2+k_match_pairs")
+        np.testing.assert_array_equal(res.best_idx, np.tile(want_idx, reps), err_msg=algo)
+        hit = np.tile(want_idx >= 0, reps)
+        np.testing.assert_array_equal(res.best_dist[hit], np.tile(nsub, reps)[hit])
+        assert (res.n_best[hit] == 1).all() and (res.n_best[~hit] == 0).all() and (res.best_dist[~hit] == 255).all()
+        np.testing.assert_array_equal(res.counts[:len(originals)],
+                                      reps * np.bincount(want_idx[want_idx >= 0], minlength=len(originals)))
+    # the score of (best guide, read) = the reference's y_pred, exactly (float64)
+    sel = [i for i in range(len(pairs)) if want_idx[i] >= 0]
+    y = M.y_pred_device([lib_s[res.best_idx[i]] for i in sel], [variants[i] for i in sel], m["params"], device=gpu_device)
+    for i, got in zip(sel, y):
+        assert got == pairs[i][2] or (got is None and nsub[i] == 0), (pairs[i], got)

@@ -132,3 +132,29 @@ def test_windows_and_expand_full_size(gpu_device):
             assert topo[a:a + 20] == s and topo[a + 21:a + 23] == "GG"
         else:
             assert topo[a:a + 20] == s[::-1].translate(str.maketrans("ACGT", "TGCA")) and topo[a - 3:a - 1] == "CC"
+
+
+@pytest.mark.parametrize("pam,k", [("NGG", 20), ("NGNC", 32), ("TTTN", 23), ("G", 1), ("NNGRRT", 21), ("GGNNNNNNNCC", 9)])
+@pytest.mark.parametrize("direction", ["downstream", "upstream"])
+def test_fused_site_pipeline_equals_staged(gpu_device, plasmids, pam, k, direction):
+    """find_sites (two launches: bc_pam_sites_count_dev / _emit_dev) against the separate stages (bitmaps ->
+    position lists -> windows, dropped on the host) on lengths around the 1024-word blocks, with non-ACGT
+    characters, wrapped genomes and inputs shorter than a window."""
+    from barcoder_amd import pam as P, synth as S
+    iupac = "R" in pam
+    rng = np.random.default_rng(7)
+    long_seq = S.genome(70_000, seed=11)
+    noisy = bytearray(long_seq.encode())
+    for i in rng.choice(len(noisy), 600, replace=False):
+        noisy[i] = ord("N")
+    cases = [(plasmids[0], 0), (plasmids[1], k + len(pam) - 1), (noisy.decode(), 0), (long_seq[:32768], 0),
+             (long_seq[:32769], 5), (long_seq[:32767 + 1024 * 32], 0), (long_seq[:65], 0), ("ACGTNNGGCCGGAAGG", 0),
+             ("GG", 0), ("", 0), ("A" * 31 + "GG" + "C" * 40, 3)]
+    for seq, wrap in cases:
+        if wrap and not seq:
+            continue
+        g = P.pack_genome(seq, wrap)
+        a = P.find_sites(g, pam, k, direction, gpu_device, iupac=iupac)
+        b = P.find_sites_staged(g, pam, k, direction, gpu_device, iupac=iupac)
+        for f in ("start", "strand", "spacer", "pam_pos"):
+            np.testing.assert_array_equal(getattr(a, f), getattr(b, f), err_msg=f"{pam} {k} {direction} len {len(seq)} wrap {wrap}: {f}")
