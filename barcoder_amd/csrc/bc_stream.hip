@@ -220,8 +220,9 @@ struct Slot {  // one worker's buffers
     uint8_t* h_text = nullptr;   // pinned, 1 + CHUNK + SLACK
     hipStream_t st = nullptr;
     DevBuf text, bits, nl, tmp, packed, status, best, odd;
+    DevBuf mw, mk;               // this chunk's undocumented windows (word, key) before they join the run-wide list
     uint64_t* d_n = nullptr;     // expand count
-    uint32_t* d_nodd = nullptr;
+    uint32_t* d_nodd = nullptr;  // [0] odd windows, [1] error flag, [2..3] the chunk's miss cursor (64 bits)
     ~Slot() {
         if (h_text) (void)hipHostFree(h_text);
         if (st) (void)hipStreamDestroy(st);
@@ -325,16 +326,18 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
     T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)T, std::max<uint64_t>(n_chunks, 1)));
     const uint64_t kmask = kmer_mask(k);
 
-    // run-wide device state
-    DevBuf d_counts, d_first, m_words, m_keys, d_cursor;
+    // run-wide device state.  The list of undocumented windows (m_words / m_keys, `miss_used` entries) is touched
+    // only under grow_m: a worker collects a chunk's misses into buffers of its own, and appends them — growing the
+    // list first when it has to — once its stream has finished the chunk.  (Round 2 let every worker's kernel append
+    // to the shared list directly and grew it under the lock only: a worker that had passed its capacity check could
+    // still launch with the old pointers while another one swapped them, and its entries were lost.)
+    DevBuf d_counts, d_first, m_words, m_keys;
     int rc;
     if ((rc = d_counts.reserve((size_t)G * 4)) != BC_OK) return rc;
     if ((rc = d_first.reserve((size_t)G * 8)) != BC_OK) return rc;
-    if ((rc = d_cursor.reserve(16)) != BC_OK) return rc;
     BC_HIP(hipMemset(d_counts.p, 0, (size_t)G * 4));
     BC_HIP(hipMemset(d_first.p, 0xFF, (size_t)G * 8));
-    BC_HIP(hipMemset(d_cursor.p, 0, 16));
-    uint64_t miss_cap = span / 24 + 65536;  // grown when a file has shorter reads than that
+    uint64_t miss_cap = span / 24 + 65536, miss_used = 0;  // grown when the file holds more misses than that
     if ((rc = m_words.reserve(miss_cap * 8)) != BC_OK) return rc;
     if ((rc = m_keys.reserve(miss_cap * 8)) != BC_OK) return rc;
 
@@ -403,7 +406,7 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                 t_a = tick();
                 const uint64_t n_own = n_real + (uint64_t)virt;
                 // ---- position in the run: lines and reads in front of this chunk
-                uint64_t line_base, reads_before;
+                uint64_t line_base;
                 {
                     std::unique_lock<std::mutex> lk(order_m);
                     order_cv.wait(lk, [&] { return next_to_publish == c || first_rc.load() != BC_OK; });
@@ -412,7 +415,6 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                     lines_before += n_own;
                     const uint64_t gri0_ = g.fastq ? ((line_base + 2) >> 2) : line_base;
                     const uint64_t gri1_ = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
-                    reads_before = reads_launched;
                     reads_launched += gri1_ - gri0_;
                     ++next_to_publish;
                 }
@@ -423,23 +425,6 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                 const uint64_t gri1 = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
                 const uint64_t n_reads = gri1 - gri0;
                 if (n_own == 0 || n_reads == 0) continue;
-                {   // room for this chunk's misses in the run-wide list (every read could be one)
-                    std::lock_guard<std::mutex> lk(grow_m);
-                    if (reads_before + n_reads > miss_cap) {
-                        BC_HIP(hipDeviceSynchronize());
-                        unsigned long long used = 0;
-                        BC_HIP(hipMemcpy(&used, d_cursor.p, 8, hipMemcpyDeviceToHost));
-                        const uint64_t ncap = std::max<uint64_t>(miss_cap * 2, reads_before + n_reads + 65536);
-                        DevBuf nw, nk;
-                        if ((rc2 = nw.reserve(ncap * 8)) != BC_OK) return rc2;
-                        if ((rc2 = nk.reserve(ncap * 8)) != BC_OK) return rc2;
-                        BC_HIP(hipMemcpy(nw.p, m_words.p, used * 8, hipMemcpyDeviceToDevice));
-                        BC_HIP(hipMemcpy(nk.p, m_keys.p, used * 8, hipMemcpyDeviceToDevice));
-                        std::swap(nw.p, m_words.p); std::swap(nw.cap, m_words.cap);
-                        std::swap(nk.p, m_keys.p); std::swap(nk.cap, m_keys.cap);
-                        miss_cap = ncap;
-                    }
-                }
                 // ---- device pass
                 const uint64_t n_words = (nbytes + 31) / 32;
                 const uint64_t nl_cap = n_real + SLACK + 64;
@@ -451,8 +436,10 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                 if ((rc2 = s.status.reserve(n_reads + 64)) != BC_OK) return rc2;
                 if ((rc2 = s.best.reserve(n_reads * 4 + 64)) != BC_OK) return rc2;
                 if ((rc2 = s.odd.reserve((size_t)odd_cap * sizeof(OddRec))) != BC_OK) return rc2;
+                if ((rc2 = s.mw.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;  // every read could be a miss
+                if ((rc2 = s.mk.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;
                 BC_HIP(hipMemcpyAsync(s.text.p, s.h_text, nbytes, hipMemcpyHostToDevice, s.st));
-                BC_HIP(hipMemsetAsync(s.d_nodd, 0, 8, s.st));
+                BC_HIP(hipMemsetAsync(s.d_nodd, 0, 16, s.st));
                 hipLaunchKernelGGL(k_nl_bitmap, dim3(grid_for(n_words)), dim3(BLOCK), 0, s.st, (const uint8_t*)s.text.p, nbytes,
                                    (uint32_t*)s.bits.p, n_words);
                 if ((rc2 = bc_sites_expand_dev((const uint32_t*)s.bits.p, n_words, (uint32_t*)s.nl.p, nl_cap, s.d_n,
@@ -469,17 +456,37 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                                         algo, (int32_t*)s.best.p, nullptr, nullptr, (uint32_t*)d_counts.p,
                                         (uint64_t*)d_first.p, key0, s.st)) != BC_OK) return rc2;
                 hipLaunchKernelGGL(k_collect_misses, dim3(grid_for(n_reads)), dim3(BLOCK), 0, s.st, (const int32_t*)s.best.p,
-                                   (const uint64_t*)s.packed.p, n_reads, kmask, key0, (uint64_t*)m_words.p,
-                                   (uint64_t*)m_keys.p, (unsigned long long*)d_cursor.p);
+                                   (const uint64_t*)s.packed.p, n_reads, kmask, key0, (uint64_t*)s.mw.p,
+                                   (uint64_t*)s.mk.p, (unsigned long long*)(s.d_nodd + 2));
                 BC_HIP(hipGetLastError());
                 // ---- odd windows: their text is still in the pinned buffer
-                uint32_t fl[2] = {0, 0};
-                BC_HIP(hipMemcpyAsync(fl, s.d_nodd, 8, hipMemcpyDeviceToHost, s.st));
+                uint32_t fl[4] = {0, 0, 0, 0};
+                BC_HIP(hipMemcpyAsync(fl, s.d_nodd, 16, hipMemcpyDeviceToHost, s.st));
                 prof_us[3] += since(t_a);
                 t_a = tick();
                 BC_HIP(hipStreamSynchronize(s.st));
                 prof_us[4] += since(t_a);
                 if (fl[1]) { set_error("%s: a line longer than %llu bytes", path, (unsigned long long)SLACK); return BC_EINVAL; }
+                const uint64_t n_m = (uint64_t)fl[2] | ((uint64_t)fl[3] << 32);
+                if (n_m) {  // the chunk's misses join the run-wide list
+                    std::lock_guard<std::mutex> lk(grow_m);
+                    if (miss_used + n_m > miss_cap) {
+                        const uint64_t ncap = std::max<uint64_t>(miss_cap * 2, miss_used + n_m + 65536);
+                        DevBuf nw, nk;
+                        if ((rc2 = nw.reserve(ncap * 8)) != BC_OK) return rc2;
+                        if ((rc2 = nk.reserve(ncap * 8)) != BC_OK) return rc2;
+                        BC_HIP(hipMemcpyAsync(nw.p, m_words.p, miss_used * 8, hipMemcpyDeviceToDevice, s.st));
+                        BC_HIP(hipMemcpyAsync(nk.p, m_keys.p, miss_used * 8, hipMemcpyDeviceToDevice, s.st));
+                        BC_HIP(hipStreamSynchronize(s.st));  // before the old buffers are freed (nw / nk leave scope)
+                        std::swap(nw.p, m_words.p); std::swap(nw.cap, m_words.cap);
+                        std::swap(nk.p, m_keys.p); std::swap(nk.cap, m_keys.cap);
+                        miss_cap = ncap;
+                    }
+                    BC_HIP(hipMemcpyAsync((uint64_t*)m_words.p + miss_used, s.mw.p, n_m * 8, hipMemcpyDeviceToDevice, s.st));
+                    BC_HIP(hipMemcpyAsync((uint64_t*)m_keys.p + miss_used, s.mk.p, n_m * 8, hipMemcpyDeviceToDevice, s.st));
+                    BC_HIP(hipStreamSynchronize(s.st));  // complete before anybody else may grow (and copy) the list
+                    miss_used += n_m;
+                }
                 const uint32_t n_odd = fl[0];
                 if (n_odd > odd_cap) { set_error("%s: more than %u odd windows in one chunk", path, odd_cap); return BC_EINVAL; }
                 if (n_odd) {
@@ -529,8 +536,7 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
         }
         // undocumented: sort the (word, key) pairs by word, then one pass gives every distinct word its count and
         // smallest key
-        unsigned long long n_miss = 0;
-        BC_HIP(hipMemcpy(&n_miss, d_cursor.p, 8, hipMemcpyDeviceToHost));
+        const unsigned long long n_miss = miss_used;
         if (n_miss) {
             DevBuf w2, k2, tmp, uw, uf, uc, un;
             int rc3;

@@ -119,3 +119,36 @@ def test_stream_byte_ranges_tile_the_file(gpu_device, tmp_path):
             np.testing.assert_array_equal(part[3], whole[3])
             np.testing.assert_array_equal(part[4], whole[4])
             assert part[5] == whole[5]
+
+
+def test_undocumented_list_grows_under_concurrent_workers(gpu_device, tmp_path):
+    """Bare 20-mers, one per 21-byte line, nearly all of them absent from the library: more undocumented windows
+    than the run-wide list is first sized for (span / 24), in a file of several 16 MiB chunks taken by six worker
+    threads at once — the list must grow without losing an entry (round 2 grew it under a lock that the other
+    workers' launches did not take).  Expected table from numpy; one worker and six must agree with it."""
+    from barcoder_amd import DeviceLibrary, encoding as E, ingest as I, synth as S
+    k, n = 20, 1_800_000
+    lib = S.library(500, k)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    words = S.draw(77, np.arange(n, dtype=np.uint64), 0) & np.uint64(0x000FFFFF000FFFFF)
+    words[::1000] = lib[np.arange(words[::1000].size) % lib.size]      # a few documented reads
+    words[5::7] = words[3::7][:words[5::7].size]                       # repeated undocumented words
+    sh = np.arange(k, dtype=np.uint64)
+    codes = (((words[:, None] >> sh) & np.uint64(1)) | (((words[:, None] >> (sh + np.uint64(32))) & np.uint64(1)) << np.uint64(1))).astype(np.uint8)
+    rows = np.empty((n, k + 1), np.uint8)
+    rows[:, :k] = np.frombuffer(b"ACGT", np.uint8)[codes]
+    rows[:, k] = 10
+    path = str(tmp_path / "bare.reads")
+    rows.tofile(path)
+    assert os.path.getsize(path) == n * 21 > 2 * (16 << 20) and n > os.path.getsize(path) // 24 + 65536
+    in_lib = np.isin(words, lib)
+    uw, first, cnt = np.unique(words[~in_lib], return_index=True, return_counts=True)
+    first_keys = np.flatnonzero(~in_lib)[first]
+    for threads in (1, 6):
+        c, f = np.zeros(lib.size, np.uint64), np.full(lib.size, np.iinfo(np.uint64).max, np.uint64)
+        r = I.stream_count_file(dl.handle, path, 0, os.path.getsize(path), 0, "", "", False, 0, "auto", 0, c, f, n_threads=threads)
+        assert r.n_reads == n and int(c.sum()) == int(in_lib.sum())
+        order = np.argsort(r.u_words)
+        np.testing.assert_array_equal(r.u_words[order], uw)
+        np.testing.assert_array_equal(r.u_counts[order], cnt.astype(np.uint64))
+        np.testing.assert_array_equal(r.u_first[order], first_keys.astype(np.uint64))
