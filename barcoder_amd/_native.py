@@ -60,6 +60,11 @@ SIGNATURES = {
     "bc_stream_result_undoc": (C.c_int, [vp, vp, vp, vp]),
     "bc_stream_result_odd": (C.c_int, [vp, vp, vp, vp]),
     "bc_stream_result_free": (C.c_int, [vp]),
+    "bc_stream_count_pair": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
+                                       C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                       C.c_int, vp, vp, C.POINTER(vp)]),
+    "bc_stream_result_pair_info": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bc_stream_result_pair_odd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "bc_sample_data": (C.c_int, [C.c_char_p, C.c_char_p, vp, C.c_uint32, C.c_int, C.POINTER(vp)]),
     "bc_sample_info": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),

@@ -100,21 +100,25 @@ __global__ __launch_bounds__(BLOCK) void k_pam_scan(const uint64_t* __restrict__
     const uint64_t n_pairs = (n_words + 1) / 2;
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     const uint32_t lane = threadIdx.x & 63u;
-    // wave-uniform loop bound: every lane of a wave takes part in the exchange
-    for (uint64_t t0 = (uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u); t0 < n_pairs; t0 += stride) {
-        const uint64_t t = t0 + lane, w = 2 * t;
-        uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
+    struct Pair { uint32_t lo0, hi0, lo1, hi1, c0, c1; };
+    auto fetch = [&](uint64_t t) {
+        const uint64_t w = 2 * t;
+        Pair p{0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (w + 1 < n_words && vec) {
             const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bases) + t);
             const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(invalid) + t);
-            lo0 = b.x; hi0 = b.y; lo1 = b.z; hi1 = b.w; c0 = c.x; c1 = c.y;
+            p.lo0 = b.x; p.hi0 = b.y; p.lo1 = b.z; p.hi1 = b.w; p.c0 = c.x; p.c1 = c.y;
         } else if (w < n_words) {  // (pointers that are not 16 / 8-byte aligned, or the odd last word)
             const uint64_t b = bases[w];
-            lo0 = (uint32_t)b; hi0 = (uint32_t)(b >> 32); c0 = invalid[w];
-            if (w + 1 < n_words) { const uint64_t b1 = bases[w + 1]; lo1 = (uint32_t)b1; hi1 = (uint32_t)(b1 >> 32); c1 = invalid[w + 1]; }
+            p.lo0 = (uint32_t)b; p.hi0 = (uint32_t)(b >> 32); p.c0 = invalid[w];
+            if (w + 1 < n_words) { const uint64_t b1 = bases[w + 1]; p.lo1 = (uint32_t)b1; p.hi1 = (uint32_t)(b1 >> 32); p.c1 = invalid[w + 1]; }
         }
+        return p;
+    };
+    auto finish = [&](uint64_t t, Pair p) {
+        const uint64_t w = 2 * t;
         // the word after the pair: the next lane's first word
-        uint32_t lo2 = (uint32_t)__shfl_down((int)lo0, 1), hi2 = (uint32_t)__shfl_down((int)hi0, 1), c2 = (uint32_t)__shfl_down((int)c0, 1);
+        uint32_t lo2 = (uint32_t)__shfl_down((int)p.lo0, 1), hi2 = (uint32_t)__shfl_down((int)p.hi0, 1), c2 = (uint32_t)__shfl_down((int)p.c0, 1);
         if (lane == 63u) {
             lo2 = 0; hi2 = 0; c2 = 0xFFFFFFFFu;
             if (w + 2 < n_words) { const uint64_t b = bases[w + 2]; lo2 = (uint32_t)b; hi2 = (uint32_t)(b >> 32); c2 = invalid[w + 2]; }
@@ -122,10 +126,10 @@ __global__ __launch_bounds__(BLOCK) void k_pam_scan(const uint64_t* __restrict__
         // positions past total_len never match, whatever the caller left in the invalid bits there
         const uint32_t o0 = outside_bits(w, n_words, total_len), o1 = outside_bits(w + 1, n_words, total_len),
                        o2 = outside_bits(w + 2, n_words, total_len);
-        c0 |= o0; c1 |= o1; c2 |= o2;
+        p.c0 |= o0; p.c1 |= o1; c2 |= o2;
         uint32_t f0, r0, f1, r1;
-        pam_eval<LEN, ANY>(pp, lo0, hi0, c0, o0, lo1, hi1, c1, o1, f0, r0);
-        pam_eval<LEN, ANY>(pp, lo1, hi1, c1, o1, lo2, hi2, c2, o2, f1, r1);
+        pam_eval<LEN, ANY>(pp, p.lo0, p.hi0, p.c0, o0, p.lo1, p.hi1, p.c1, o1, f0, r0);
+        pam_eval<LEN, ANY>(pp, p.lo1, p.hi1, p.c1, o1, lo2, hi2, c2, o2, f1, r1);
         if (w + 1 < n_words && vec) {
             __builtin_nontemporal_store(u32x2{f0, f1}, reinterpret_cast<u32x2*>(out_fwd) + t);
             __builtin_nontemporal_store(u32x2{r0, r1}, reinterpret_cast<u32x2*>(out_rev) + t);
@@ -134,7 +138,14 @@ __global__ __launch_bounds__(BLOCK) void k_pam_scan(const uint64_t* __restrict__
             out_rev[w] = r0;
             if (w + 1 < n_words) { out_fwd[w + 1] = f1; out_rev[w + 1] = r1; }
         }
+    };
+    // wave-uniform loop bounds (every lane of a wave takes part in the exchange); four tiles' loads in flight per lane
+    uint64_t t0 = (uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u);
+    for (; t0 + 3 * stride < n_pairs; t0 += 4 * stride) {
+        const Pair a = fetch(t0 + lane), b = fetch(t0 + stride + lane), c = fetch(t0 + 2 * stride + lane), d = fetch(t0 + 3 * stride + lane);
+        finish(t0 + lane, a); finish(t0 + stride + lane, b); finish(t0 + 2 * stride + lane, c); finish(t0 + 3 * stride + lane, d);
     }
+    for (; t0 < n_pairs; t0 += stride) finish(t0 + lane, fetch(t0 + lane));
 }
 
 // ---- bitmap -> ascending position list: popcount, scan, expand ---------------

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -180,6 +181,28 @@ __global__ __launch_bounds__(BLOCK) void k_collect_misses(const int32_t* __restr
     }
 }
 
+// paired-end (heuristicount.py:469-518): a pair counts when both mates have their flanks, neither holds an N and
+// seq1 == rev_comp(seq2) (:506) — with both windows packed (the reverse mate's already reverse-complemented) that is
+// st1 == st2 == OK and p1 == p2; the match then runs on p1.  Pairs with an ODD window keep string semantics on the host.
+__global__ __launch_bounds__(BLOCK) void k_pair_flags(const uint64_t* __restrict__ p1, const uint8_t* __restrict__ st1,
+                                                      const uint64_t* __restrict__ p2, const uint8_t* __restrict__ st2,
+                                                      uint64_t n, uint8_t* __restrict__ flags) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += stride)
+        flags[r] = (st1[r] == BC_WIN_OK && st2[r] == BC_WIN_OK && p1[r] == p2[r]) ? 0 : 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gather_pairs(const uint64_t* __restrict__ idx, uint64_t m,
+                                                        const uint64_t* __restrict__ p1, const uint8_t* __restrict__ st1,
+                                                        const uint64_t* __restrict__ p2, const uint8_t* __restrict__ st2,
+                                                        uint64_t* __restrict__ o1, uint8_t* __restrict__ os1,
+                                                        uint64_t* __restrict__ o2, uint8_t* __restrict__ os2) {
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t r = idx[j];
+    o1[j] = p1[r]; os1[j] = st1[r]; o2[j] = p2[r]; os2[j] = st2[r];
+}
+
 int grid_for(uint64_t items) {
     uint64_t b = (items + BLOCK - 1) / BLOCK;
     return (int)std::max<uint64_t>(1, std::min<uint64_t>(b, 4096));
@@ -231,115 +254,114 @@ struct Slot {  // one worker's buffers
     }
 };
 
-}  // namespace
+struct OddOut { uint64_t key; std::string text; };
 
-struct bc_stream_result {
-    uint64_t n_reads = 0;
-    double seconds = 0;
-    // the table of undocumented windows stays on the device until the caller hands over its arrays
-    // (bc_stream_result_undoc copies straight into them: 24 bytes x 2.5e7 entries on the benchmark file)
-    int device = 0;
-    uint64_t n_undoc = 0;
-    uint64_t *d_words = nullptr, *d_counts = nullptr, *d_first = nullptr;
-    ~bc_stream_result() {
-        if (d_words || d_counts || d_first) (void)hipSetDevice(device);
-        for (void* q : {(void*)d_words, (void*)d_counts, (void*)d_first}) if (q) (void)hipFree(q);
+// run-wide list of undocumented windows (word, key): touched only under `m`.  A worker collects a chunk's misses
+// into buffers of its own and appends them — growing the list first when it has to — once its stream has finished
+// the chunk.  (Round 2 let every worker's kernel append to the shared list and grew it under a lock the launches
+// did not take: a worker past its capacity check could launch with pointers another one was swapping out.)
+struct MissList {
+    DevBuf words, keys;
+    uint64_t cap = 0, used = 0;
+    std::mutex m;
+    int reserve(uint64_t n) {
+        int rc;
+        if ((rc = words.reserve(n * 8)) != BC_OK) return rc;
+        if ((rc = keys.reserve(n * 8)) != BC_OK) return rc;
+        cap = n;
+        return BC_OK;
     }
-    std::vector<uint64_t> odd_keys, odd_off;  // odd_off: n_odd + 1 offsets into odd_text
-    std::string odd_text;
+    // append n entries from device buffers; the copies run on `st` and are complete on return
+    int append(const void* w, const void* k, uint64_t n, hipStream_t st) {
+        std::lock_guard<std::mutex> lk(m);
+        if (used + n > cap) {
+            const uint64_t ncap = std::max<uint64_t>(cap * 2, used + n + 65536);
+            DevBuf nw, nk;
+            int rc;
+            if ((rc = nw.reserve(ncap * 8)) != BC_OK) return rc;
+            if ((rc = nk.reserve(ncap * 8)) != BC_OK) return rc;
+            BC_HIP(hipMemcpyAsync(nw.p, words.p, used * 8, hipMemcpyDeviceToDevice, st));
+            BC_HIP(hipMemcpyAsync(nk.p, keys.p, used * 8, hipMemcpyDeviceToDevice, st));
+            BC_HIP(hipStreamSynchronize(st));  // before the old buffers are freed (nw / nk leave scope)
+            std::swap(nw.p, words.p); std::swap(nw.cap, words.cap);
+            std::swap(nk.p, keys.p); std::swap(nk.cap, keys.cap);
+            cap = ncap;
+        }
+        BC_HIP(hipMemcpyAsync((uint64_t*)words.p + used, w, n * 8, hipMemcpyDeviceToDevice, st));
+        BC_HIP(hipMemcpyAsync((uint64_t*)keys.p + used, k, n * 8, hipMemcpyDeviceToDevice, st));
+        BC_HIP(hipStreamSynchronize(st));  // complete before anybody else may grow (and copy) the list
+        used += n;
+        return BC_OK;
+    }
 };
 
-extern "C" {
-
-int bc_stream_result_free(bc_stream_result* r) {
-    delete r;
-    return BC_OK;
-}
-
-int bc_stream_result_info(const bc_stream_result* r, uint64_t* n_reads, uint64_t* n_undoc, uint64_t* n_odd,
-                          uint64_t* odd_bytes, double* seconds) {
-    if (!r) { set_error("bc_stream_result_info: null"); return BC_EINVAL; }
-    if (n_reads) *n_reads = r->n_reads;
-    if (n_undoc) *n_undoc = r->n_undoc;
-    if (n_odd) *n_odd = r->odd_keys.size();
-    if (odd_bytes) *odd_bytes = r->odd_text.size();
-    if (seconds) *seconds = r->seconds;
-    return BC_OK;
-}
-
-int bc_stream_result_undoc(const bc_stream_result* r, uint64_t* words, uint64_t* counts, uint64_t* first) {
-    if (!r || ((!words || !counts || !first) && r->n_undoc)) { set_error("bc_stream_result_undoc: null"); return BC_EINVAL; }
-    if (!r->n_undoc) return BC_OK;
-    BC_HIP(hipSetDevice(r->device));
-    BC_HIP(hipMemcpy(words, r->d_words, r->n_undoc * 8, hipMemcpyDeviceToHost));
-    BC_HIP(hipMemcpy(counts, r->d_counts, r->n_undoc * 8, hipMemcpyDeviceToHost));
-    BC_HIP(hipMemcpy(first, r->d_first, r->n_undoc * 8, hipMemcpyDeviceToHost));
-    return BC_OK;
-}
-
-int bc_stream_result_odd(const bc_stream_result* r, uint64_t* keys, uint64_t* off, char* text) {
-    if (!r) { set_error("bc_stream_result_odd: null"); return BC_EINVAL; }
-    std::copy(r->odd_keys.begin(), r->odd_keys.end(), keys);
-    std::copy(r->odd_off.begin(), r->odd_off.end(), off);
-    std::copy(r->odd_text.begin(), r->odd_text.end(), text);
-    return BC_OK;
-}
-
-int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uint64_t byte_end, int64_t start,
-                         const char* L, int L_len, const char* R, int R_len, int reverse, int max_mismatch, int algo,
-                         uint64_t key_base, int n_threads, uint64_t* h_counts, uint64_t* h_first_seen,
-                         bc_stream_result** out) {
-    if (!lib || !path || !out || start < 0 || L_len < 0 || R_len < 0 || L_len > 15 || R_len > 15 || (L_len && !L) ||
-        (R_len && !R)) {
-        set_error("bc_stream_count_file: bad argument (flanks are at most 15 characters)");
-        return BC_EINVAL;
+// paired-end: the windows of every read of one file, at the read's index (the pairing and the match run afterwards
+// over the whole arrays).  A chunk's kernels write under the shared side of `m` until the chunk's stream has
+// finished; growing takes the exclusive side, so nothing is in flight while the arrays move.
+struct WindowStore {
+    DevBuf packed, status;   // uint64[cap], uint8[cap]
+    uint64_t cap = 0, estimate = 0;
+    std::shared_mutex m;
+    int grow(uint64_t need) {  // caller holds the exclusive lock
+        const uint64_t ncap = std::max<uint64_t>(std::max<uint64_t>(cap * 2, need + 65536), estimate);
+        DevBuf np_, ns;
+        int rc;
+        if ((rc = np_.reserve(ncap * 8)) != BC_OK) return rc;
+        if ((rc = ns.reserve(ncap)) != BC_OK) return rc;
+        if (cap) {
+            BC_HIP(hipMemcpy(np_.p, packed.p, cap * 8, hipMemcpyDeviceToDevice));
+            BC_HIP(hipMemcpy(ns.p, status.p, cap, hipMemcpyDeviceToDevice));
+        }
+        BC_HIP(hipDeviceSynchronize());
+        std::swap(np_.p, packed.p); std::swap(np_.cap, packed.cap);
+        std::swap(ns.p, status.p); std::swap(ns.cap, status.cap);
+        cap = ncap;
+        return BC_OK;
     }
-    uint32_t G = 0; int k = 0, device = 0;
-    bc_lib_info(lib, &G, &k, &device);
-    std::string p(path);
-    auto ends = [&](const char* suf) { size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
+};
+
+struct FileJob {
+    bc_lib* lib = nullptr;
+    const char* path = nullptr;
+    uint64_t byte_begin = 0, byte_end = 0;
     Geometry g{};
-    if (ends(".fastq")) g.fastq = 1;
-    else if (ends(".reads")) g.fastq = 0;
-    else { set_error("bc_stream_count_file: an uncompressed .fastq or .reads file is needed, got %s", path); return BC_EINVAL; }
-    g.start = start; g.L_len = L_len; g.R_len = R_len; g.k = k; g.reverse = reverse ? 1 : 0;
-    memcpy(g.L, L ? L : "", (size_t)L_len);
-    memcpy(g.R, R ? R : "", (size_t)R_len);
+    int max_mismatch = 0, algo = 0, n_threads = 0;
+    uint64_t key_base = 0;
+    // match mode (store == nullptr): per-chunk match, tallies accumulate on the device, misses join `misses`
+    uint32_t* d_counts = nullptr;
+    uint64_t* d_first = nullptr;
+    MissList* misses = nullptr;
+    // store mode: windows only
+    WindowStore* store = nullptr;
+    // results
+    std::vector<OddOut> odd_all;
+    uint64_t n_reads = 0;
+};
+
+// every chunk of one file through the device (see the header of this file); returns BC_OK or the first error
+int run_file(FileJob& J) {
+    uint32_t G = 0; int k = 0, device = 0;
+    bc_lib_info(J.lib, &G, &k, &device);
+    const char* path = J.path;
+    Geometry g = J.g;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) { set_error("cannot open %s", path); return BC_EINVAL; }
     struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
     struct stat sb;
     if (fstat(fd, &sb) != 0) { set_error("cannot stat %s", path); return BC_EINVAL; }
     const uint64_t fsize = (uint64_t)sb.st_size;
-    byte_end = std::min(byte_end, fsize);
-    if (byte_begin > byte_end) byte_begin = byte_end;
-    const auto t_begin = std::chrono::steady_clock::now();
-    BC_HIP(hipSetDevice(device));
-
+    const uint64_t byte_end = std::min(J.byte_end, fsize);
+    const uint64_t byte_begin = std::min(J.byte_begin, byte_end);
     const uint64_t span = byte_end - byte_begin;
     const uint64_t n_chunks = (span + CHUNK - 1) / CHUNK;
-    int T = n_threads;
+    int T = J.n_threads;
     if (T <= 0) {  // default; BC_STREAM_THREADS overrides (tuning aid)
         const char* e = getenv("BC_STREAM_THREADS");
         T = e && atoi(e) > 0 ? atoi(e) : 8;  // measured, 4.6 GB file in the page cache: 4 / 8 / 12 / 16 threads -> 144-161 / 210 / 243 / 222 Mreads/s
     }
     T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)T, std::max<uint64_t>(n_chunks, 1)));
     const uint64_t kmask = kmer_mask(k);
-
-    // run-wide device state.  The list of undocumented windows (m_words / m_keys, `miss_used` entries) is touched
-    // only under grow_m: a worker collects a chunk's misses into buffers of its own, and appends them — growing the
-    // list first when it has to — once its stream has finished the chunk.  (Round 2 let every worker's kernel append
-    // to the shared list directly and grew it under the lock only: a worker that had passed its capacity check could
-    // still launch with the old pointers while another one swapped them, and its entries were lost.)
-    DevBuf d_counts, d_first, m_words, m_keys;
-    int rc;
-    if ((rc = d_counts.reserve((size_t)G * 4)) != BC_OK) return rc;
-    if ((rc = d_first.reserve((size_t)G * 8)) != BC_OK) return rc;
-    BC_HIP(hipMemset(d_counts.p, 0, (size_t)G * 4));
-    BC_HIP(hipMemset(d_first.p, 0xFF, (size_t)G * 8));
-    uint64_t miss_cap = span / 24 + 65536, miss_used = 0;  // grown when the file holds more misses than that
-    if ((rc = m_words.reserve(miss_cap * 8)) != BC_OK) return rc;
-    if ((rc = m_keys.reserve(miss_cap * 8)) != BC_OK) return rc;
+    WindowStore* const store = J.store;
 
     std::vector<Slot> slots((size_t)T);
     // ordered hand-over of the running line / read totals (a chunk needs the number of lines in front of it)
@@ -349,10 +371,7 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
     std::atomic<uint64_t> next_chunk{0};
     std::atomic<int> first_rc{BC_OK};
     std::string err;
-    std::mutex err_m, grow_m, odd_m;
-    bc_stream_result* res = new bc_stream_result();
-    struct OddOut { uint64_t key; std::string text; };
-    std::vector<OddOut> odd_all;
+    std::mutex err_m, odd_m;
 
     auto fail = [&](int code) {
         int expect = BC_OK;
@@ -416,6 +435,8 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                     const uint64_t gri0_ = g.fastq ? ((line_base + 2) >> 2) : line_base;
                     const uint64_t gri1_ = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
                     reads_launched += gri1_ - gri0_;
+                    if (store && c == 0)  // size the run-wide arrays from the first chunk's density (+25 %)
+                        store->estimate = (uint64_t)((double)(gri1_ - gri0_) * ((double)span / (double)std::max<uint64_t>(core_hi - core_lo, 1)) * 1.25) + 65536;
                     ++next_to_publish;
                 }
                 order_cv.notify_all();
@@ -432,12 +453,31 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                 if ((rc2 = s.bits.reserve(n_words * 4 + 64)) != BC_OK) return rc2;
                 if ((rc2 = s.nl.reserve(nl_cap * 4)) != BC_OK) return rc2;
                 if ((rc2 = s.tmp.reserve((n_words / 1024 + 2) * 4)) != BC_OK) return rc2;
-                if ((rc2 = s.packed.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;
-                if ((rc2 = s.status.reserve(n_reads + 64)) != BC_OK) return rc2;
-                if ((rc2 = s.best.reserve(n_reads * 4 + 64)) != BC_OK) return rc2;
                 if ((rc2 = s.odd.reserve((size_t)odd_cap * sizeof(OddRec))) != BC_OK) return rc2;
-                if ((rc2 = s.mw.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;  // every read could be a miss
-                if ((rc2 = s.mk.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;
+                std::shared_lock<std::shared_mutex> window_lock;
+                uint64_t* d_packed;
+                uint8_t* d_status;
+                if (store) {  // the windows go to the run-wide arrays, at the reads' own indices
+                    window_lock = std::shared_lock<std::shared_mutex>(store->m);
+                    if (gri1 > store->cap) {
+                        window_lock.unlock();
+                        {
+                            std::unique_lock<std::shared_mutex> ul(store->m);
+                            if (gri1 > store->cap && (rc2 = store->grow(gri1)) != BC_OK) return rc2;
+                        }
+                        window_lock.lock();
+                    }
+                    d_packed = (uint64_t*)store->packed.p + gri0;
+                    d_status = (uint8_t*)store->status.p + gri0;
+                } else {
+                    if ((rc2 = s.packed.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;
+                    if ((rc2 = s.status.reserve(n_reads + 64)) != BC_OK) return rc2;
+                    if ((rc2 = s.best.reserve(n_reads * 4 + 64)) != BC_OK) return rc2;
+                    if ((rc2 = s.mw.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;  // every read could be a miss
+                    if ((rc2 = s.mk.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;
+                    d_packed = (uint64_t*)s.packed.p;
+                    d_status = (uint8_t*)s.status.p;
+                }
                 BC_HIP(hipMemcpyAsync(s.text.p, s.h_text, nbytes, hipMemcpyHostToDevice, s.st));
                 BC_HIP(hipMemsetAsync(s.d_nodd, 0, 16, s.st));
                 hipLaunchKernelGGL(k_nl_bitmap, dim3(grid_for(n_words)), dim3(BLOCK), 0, s.st, (const uint8_t*)s.text.p, nbytes,
@@ -446,47 +486,31 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                                                (uint32_t*)s.tmp.p, s.st)) != BC_OK) return rc2;
                 // the device's list holds every newline of the buffer in ascending order: the owned ones come first,
                 // the slack's after them (the end of the last owned line is among those)
-                const uint64_t key0 = key_base + gri0;
+                const uint64_t key0 = J.key_base + gri0;
                 hipLaunchKernelGGL(k_lines_to_windows, dim3(grid_for(n_own)), dim3(BLOCK), 0, s.st, (const uint8_t*)s.text.p,
                                    nbytes, (const uint32_t*)s.nl.p, (const uint64_t*)s.d_n, nl_cap, n_own, virt,
-                                   hi < fsize ? 1 : 0, line_base, gri0, g, key0, (uint64_t*)s.packed.p,
-                                   (uint8_t*)s.status.p, (OddRec*)s.odd.p, odd_cap, s.d_nodd);
+                                   hi < fsize ? 1 : 0, line_base, gri0, g, key0, d_packed, d_status, (OddRec*)s.odd.p,
+                                   odd_cap, s.d_nodd);
                 BC_HIP(hipGetLastError());
-                if ((rc2 = bc_match_dev(lib, (const uint64_t*)s.packed.p, (const uint8_t*)s.status.p, n_reads, max_mismatch,
-                                        algo, (int32_t*)s.best.p, nullptr, nullptr, (uint32_t*)d_counts.p,
-                                        (uint64_t*)d_first.p, key0, s.st)) != BC_OK) return rc2;
-                hipLaunchKernelGGL(k_collect_misses, dim3(grid_for(n_reads)), dim3(BLOCK), 0, s.st, (const int32_t*)s.best.p,
-                                   (const uint64_t*)s.packed.p, n_reads, kmask, key0, (uint64_t*)s.mw.p,
-                                   (uint64_t*)s.mk.p, (unsigned long long*)(s.d_nodd + 2));
-                BC_HIP(hipGetLastError());
+                if (!store) {
+                    if ((rc2 = bc_match_dev(J.lib, d_packed, d_status, n_reads, J.max_mismatch, J.algo, (int32_t*)s.best.p,
+                                            nullptr, nullptr, J.d_counts, J.d_first, key0, s.st)) != BC_OK) return rc2;
+                    hipLaunchKernelGGL(k_collect_misses, dim3(grid_for(n_reads)), dim3(BLOCK), 0, s.st, (const int32_t*)s.best.p,
+                                       (const uint64_t*)d_packed, n_reads, kmask, key0, (uint64_t*)s.mw.p,
+                                       (uint64_t*)s.mk.p, (unsigned long long*)(s.d_nodd + 2));
+                    BC_HIP(hipGetLastError());
+                }
                 // ---- odd windows: their text is still in the pinned buffer
                 uint32_t fl[4] = {0, 0, 0, 0};
                 BC_HIP(hipMemcpyAsync(fl, s.d_nodd, 16, hipMemcpyDeviceToHost, s.st));
                 prof_us[3] += since(t_a);
                 t_a = tick();
                 BC_HIP(hipStreamSynchronize(s.st));
+                if (window_lock.owns_lock()) window_lock.unlock();  // this chunk's writes into the run-wide arrays are done
                 prof_us[4] += since(t_a);
                 if (fl[1]) { set_error("%s: a line longer than %llu bytes", path, (unsigned long long)SLACK); return BC_EINVAL; }
                 const uint64_t n_m = (uint64_t)fl[2] | ((uint64_t)fl[3] << 32);
-                if (n_m) {  // the chunk's misses join the run-wide list
-                    std::lock_guard<std::mutex> lk(grow_m);
-                    if (miss_used + n_m > miss_cap) {
-                        const uint64_t ncap = std::max<uint64_t>(miss_cap * 2, miss_used + n_m + 65536);
-                        DevBuf nw, nk;
-                        if ((rc2 = nw.reserve(ncap * 8)) != BC_OK) return rc2;
-                        if ((rc2 = nk.reserve(ncap * 8)) != BC_OK) return rc2;
-                        BC_HIP(hipMemcpyAsync(nw.p, m_words.p, miss_used * 8, hipMemcpyDeviceToDevice, s.st));
-                        BC_HIP(hipMemcpyAsync(nk.p, m_keys.p, miss_used * 8, hipMemcpyDeviceToDevice, s.st));
-                        BC_HIP(hipStreamSynchronize(s.st));  // before the old buffers are freed (nw / nk leave scope)
-                        std::swap(nw.p, m_words.p); std::swap(nw.cap, m_words.cap);
-                        std::swap(nk.p, m_keys.p); std::swap(nk.cap, m_keys.cap);
-                        miss_cap = ncap;
-                    }
-                    BC_HIP(hipMemcpyAsync((uint64_t*)m_words.p + miss_used, s.mw.p, n_m * 8, hipMemcpyDeviceToDevice, s.st));
-                    BC_HIP(hipMemcpyAsync((uint64_t*)m_keys.p + miss_used, s.mk.p, n_m * 8, hipMemcpyDeviceToDevice, s.st));
-                    BC_HIP(hipStreamSynchronize(s.st));  // complete before anybody else may grow (and copy) the list
-                    miss_used += n_m;
-                }
+                if (n_m && (rc2 = J.misses->append(s.mw.p, s.mk.p, n_m, s.st)) != BC_OK) return rc2;
                 const uint32_t n_odd = fl[0];
                 if (n_odd > odd_cap) { set_error("%s: more than %u odd windows in one chunk", path, odd_cap); return BC_EINVAL; }
                 if (n_odd) {
@@ -494,7 +518,7 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                     BC_HIP(hipMemcpy(recs.data(), s.odd.p, (size_t)n_odd * sizeof(OddRec), hipMemcpyDeviceToHost));
                     std::lock_guard<std::mutex> lk(odd_m);
                     for (const OddRec& o : recs)
-                        odd_all.push_back(OddOut{o.key, std::string((const char*)s.h_text + o.begin, o.len)});
+                        J.odd_all.push_back(OddOut{o.key, std::string((const char*)s.h_text + o.begin, o.len)});
                 }
             }
             BC_HIP(hipStreamSynchronize(s.st));
@@ -517,70 +541,217 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
                 prof_us[1] / 1e3, prof_us[2] / 1e3, prof_us[3] / 1e3, prof_us[4] / 1e3);
     if (first_rc.load() != BC_OK) {
         set_error("%s", err.c_str());
-        delete res;
         return first_rc.load();
     }
+    J.n_reads = reads_launched;
+    std::sort(J.odd_all.begin(), J.odd_all.end(), [](const OddOut& a, const OddOut& b) { return a.key < b.key; });
+    return BC_OK;
+}
+
+int file_kind(const char* path, const char* who, int* fastq) {
+    std::string p(path);
+    auto ends = [&](const char* suf) { size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
+    if (ends(".fastq")) *fastq = 1;
+    else if (ends(".reads")) *fastq = 0;
+    else { set_error("%s: an uncompressed .fastq or .reads file is needed, got %s", who, path); return BC_EINVAL; }
+    return BC_OK;
+}
+
+}  // namespace
+
+struct bc_stream_result {
+    uint64_t n_reads = 0;
+    double seconds = 0;
+    // the table of undocumented windows stays on the device until the caller hands over its arrays
+    // (bc_stream_result_undoc copies straight into them: 24 bytes x 2.5e7 entries on the benchmark file)
+    int device = 0;
+    uint64_t n_undoc = 0;
+    uint64_t *d_words = nullptr, *d_counts = nullptr, *d_first = nullptr;
+    ~bc_stream_result() {
+        if (d_words || d_counts || d_first) (void)hipSetDevice(device);
+        for (void* q : {(void*)d_words, (void*)d_counts, (void*)d_first}) if (q) (void)hipFree(q);
+    }
+    std::vector<uint64_t> odd_keys, odd_off;  // odd_off: n_odd + 1 offsets into odd_text
+    std::string odd_text;
+    // paired runs: the pairs with an odd window (see bc_stream_result_pair_odd); odd_keys / odd_text stay empty
+    std::vector<uint64_t> pair_keys, pair_p1, pair_p2, pair_off1, pair_off2;
+    std::vector<uint8_t> pair_st1, pair_st2;
+    std::string pair_text1, pair_text2;
+};
+
+namespace {
+
+// undocumented windows: sort the (word, key) pairs by word, then one pass gives every distinct word its count and
+// smallest key; the table stays on the device (ownership moves to the result)
+int group_misses(MissList& M, int device, bc_stream_result* res) {
+    const unsigned long long n_miss = M.used;
+    if (!n_miss) return BC_OK;
+    DevBuf w2, k2, tmp, uw, uf, uc, un;
+    int rc3;
+    if ((rc3 = w2.reserve(n_miss * 8)) != BC_OK) return rc3;
+    if ((rc3 = k2.reserve(n_miss * 8)) != BC_OK) return rc3;
+    if ((rc3 = uw.reserve(n_miss * 8)) != BC_OK) return rc3;
+    if ((rc3 = uf.reserve(n_miss * 8)) != BC_OK) return rc3;
+    if ((rc3 = uc.reserve(n_miss * 8)) != BC_OK) return rc3;
+    if ((rc3 = un.reserve(16)) != BC_OK) return rc3;
+    size_t tb = 0;
+    BC_HIP(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)M.words.p, (uint64_t*)w2.p, (uint64_t*)M.keys.p,
+                                     (uint64_t*)k2.p, (size_t)n_miss, 0, 64, 0));
+    if ((rc3 = tmp.reserve(tb)) != BC_OK) return rc3;
+    BC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t*)M.words.p, (uint64_t*)w2.p, (uint64_t*)M.keys.p,
+                                     (uint64_t*)k2.p, (size_t)n_miss, 0, 64, 0));
+    // every run of equal words: its smallest key, and its length (a sum of ones)
+    size_t tb2 = 0;
+    BC_HIP(rocprim::reduce_by_key(nullptr, tb2, (uint64_t*)w2.p, (uint64_t*)k2.p, (size_t)n_miss, (uint64_t*)uw.p,
+                                  (uint64_t*)uf.p, (uint64_t*)un.p, rocprim::minimum<uint64_t>(),
+                                  rocprim::equal_to<uint64_t>(), 0));
+    if ((rc3 = tmp.reserve(tb2)) != BC_OK) return rc3;
+    BC_HIP(rocprim::reduce_by_key(tmp.p, tb2, (uint64_t*)w2.p, (uint64_t*)k2.p, (size_t)n_miss, (uint64_t*)uw.p,
+                                  (uint64_t*)uf.p, (uint64_t*)un.p, rocprim::minimum<uint64_t>(),
+                                  rocprim::equal_to<uint64_t>(), 0));
+    size_t tb4 = 0;
+    auto ones_it = rocprim::make_constant_iterator<uint64_t>(1);
+    BC_HIP(rocprim::reduce_by_key(nullptr, tb4, (uint64_t*)w2.p, ones_it, (size_t)n_miss, (uint64_t*)uw.p,
+                                  (uint64_t*)uc.p, (uint64_t*)un.p, rocprim::plus<uint64_t>(),
+                                  rocprim::equal_to<uint64_t>(), 0));
+    if ((rc3 = tmp.reserve(tb4)) != BC_OK) return rc3;
+    BC_HIP(rocprim::reduce_by_key(tmp.p, tb4, (uint64_t*)w2.p, ones_it, (size_t)n_miss, (uint64_t*)uw.p,
+                                  (uint64_t*)uc.p, (uint64_t*)un.p, rocprim::plus<uint64_t>(),
+                                  rocprim::equal_to<uint64_t>(), 0));
+    BC_HIP(hipDeviceSynchronize());
+    uint64_t n_u = 0;
+    BC_HIP(hipMemcpy(&n_u, un.p, 8, hipMemcpyDeviceToHost));
+    res->device = device;
+    res->n_undoc = n_u;
+    res->d_words = (uint64_t*)uw.p; res->d_first = (uint64_t*)uf.p; res->d_counts = (uint64_t*)uc.p;
+    uw.p = nullptr; uf.p = nullptr; uc.p = nullptr;  // ownership moves to the result
+    return BC_OK;
+}
+
+int tallies_to_host(uint32_t G, const DevBuf& d_counts, const DevBuf& d_first, uint64_t* h_counts, uint64_t* h_first_seen) {
+    if (h_counts) {
+        std::vector<uint32_t> c32(G);
+        BC_HIP(hipMemcpy(c32.data(), d_counts.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < G; ++i) h_counts[i] += c32[i];
+    }
+    if (h_first_seen) {
+        std::vector<uint64_t> fs(G);
+        BC_HIP(hipMemcpy(fs.data(), d_first.p, (size_t)G * 8, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < G; ++i) h_first_seen[i] = std::min(h_first_seen[i], fs[i]);
+    }
+    return BC_OK;
+}
+
+int fill_geometry(Geometry& g, int k, int64_t start, const char* L, int L_len, const char* R, int R_len, int reverse,
+                  const char* who) {
+    if (start < 0 || L_len < 0 || R_len < 0 || L_len > 15 || R_len > 15 || (L_len && !L) || (R_len && !R)) {
+        set_error("%s: bad argument (flanks are at most 15 characters)", who);
+        return BC_EINVAL;
+    }
+    g.start = start; g.L_len = L_len; g.R_len = R_len; g.k = k; g.reverse = reverse ? 1 : 0;
+    memcpy(g.L, L ? L : "", (size_t)L_len);
+    memcpy(g.R, R ? R : "", (size_t)R_len);
+    return BC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bc_stream_result_free(bc_stream_result* r) {
+    delete r;
+    return BC_OK;
+}
+
+int bc_stream_result_info(const bc_stream_result* r, uint64_t* n_reads, uint64_t* n_undoc, uint64_t* n_odd,
+                          uint64_t* odd_bytes, double* seconds) {
+    if (!r) { set_error("bc_stream_result_info: null"); return BC_EINVAL; }
+    if (n_reads) *n_reads = r->n_reads;
+    if (n_undoc) *n_undoc = r->n_undoc;
+    if (n_odd) *n_odd = r->odd_keys.size();
+    if (odd_bytes) *odd_bytes = r->odd_text.size();
+    if (seconds) *seconds = r->seconds;
+    return BC_OK;
+}
+
+int bc_stream_result_undoc(const bc_stream_result* r, uint64_t* words, uint64_t* counts, uint64_t* first) {
+    if (!r || ((!words || !counts || !first) && r->n_undoc)) { set_error("bc_stream_result_undoc: null"); return BC_EINVAL; }
+    if (!r->n_undoc) return BC_OK;
+    BC_HIP(hipSetDevice(r->device));
+    BC_HIP(hipMemcpy(words, r->d_words, r->n_undoc * 8, hipMemcpyDeviceToHost));
+    BC_HIP(hipMemcpy(counts, r->d_counts, r->n_undoc * 8, hipMemcpyDeviceToHost));
+    BC_HIP(hipMemcpy(first, r->d_first, r->n_undoc * 8, hipMemcpyDeviceToHost));
+    return BC_OK;
+}
+
+int bc_stream_result_odd(const bc_stream_result* r, uint64_t* keys, uint64_t* off, char* text) {
+    if (!r) { set_error("bc_stream_result_odd: null"); return BC_EINVAL; }
+    std::copy(r->odd_keys.begin(), r->odd_keys.end(), keys);
+    std::copy(r->odd_off.begin(), r->odd_off.end(), off);
+    std::copy(r->odd_text.begin(), r->odd_text.end(), text);
+    return BC_OK;
+}
+
+int bc_stream_result_pair_info(const bc_stream_result* r, uint64_t* n_pairs, uint64_t* text1_bytes, uint64_t* text2_bytes) {
+    if (!r) { set_error("bc_stream_result_pair_info: null"); return BC_EINVAL; }
+    if (n_pairs) *n_pairs = r->pair_keys.size();
+    if (text1_bytes) *text1_bytes = r->pair_text1.size();
+    if (text2_bytes) *text2_bytes = r->pair_text2.size();
+    return BC_OK;
+}
+
+int bc_stream_result_pair_odd(const bc_stream_result* r, uint64_t* keys, uint64_t* p1, uint8_t* st1, uint64_t* p2,
+                              uint8_t* st2, uint64_t* off1, char* text1, uint64_t* off2, char* text2) {
+    if (!r) { set_error("bc_stream_result_pair_odd: null"); return BC_EINVAL; }
+    std::copy(r->pair_keys.begin(), r->pair_keys.end(), keys);
+    std::copy(r->pair_p1.begin(), r->pair_p1.end(), p1);
+    std::copy(r->pair_st1.begin(), r->pair_st1.end(), st1);
+    std::copy(r->pair_p2.begin(), r->pair_p2.end(), p2);
+    std::copy(r->pair_st2.begin(), r->pair_st2.end(), st2);
+    std::copy(r->pair_off1.begin(), r->pair_off1.end(), off1);
+    std::copy(r->pair_text1.begin(), r->pair_text1.end(), text1);
+    std::copy(r->pair_off2.begin(), r->pair_off2.end(), off2);
+    std::copy(r->pair_text2.begin(), r->pair_text2.end(), text2);
+    return BC_OK;
+}
+
+int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uint64_t byte_end, int64_t start,
+                         const char* L, int L_len, const char* R, int R_len, int reverse, int max_mismatch, int algo,
+                         uint64_t key_base, int n_threads, uint64_t* h_counts, uint64_t* h_first_seen,
+                         bc_stream_result** out) {
+    if (!lib || !path || !out) { set_error("bc_stream_count_file: null argument"); return BC_EINVAL; }
+    uint32_t G = 0; int k = 0, device = 0;
+    bc_lib_info(lib, &G, &k, &device);
+    FileJob J;
+    int rc;
+    if ((rc = fill_geometry(J.g, k, start, L, L_len, R, R_len, reverse, "bc_stream_count_file")) != BC_OK) return rc;
+    if ((rc = file_kind(path, "bc_stream_count_file", &J.g.fastq)) != BC_OK) return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    BC_HIP(hipSetDevice(device));
+    struct stat sb;
+    if (stat(path, &sb) != 0) { set_error("cannot open %s", path); return BC_EINVAL; }
+    const uint64_t span = std::min<uint64_t>(byte_end, (uint64_t)sb.st_size) - std::min<uint64_t>(std::min<uint64_t>(byte_begin, byte_end), (uint64_t)sb.st_size);
+    // run-wide device state
+    DevBuf d_counts, d_first;
+    MissList misses;
+    if ((rc = d_counts.reserve((size_t)G * 4)) != BC_OK) return rc;
+    if ((rc = d_first.reserve((size_t)G * 8)) != BC_OK) return rc;
+    BC_HIP(hipMemset(d_counts.p, 0, (size_t)G * 4));
+    BC_HIP(hipMemset(d_first.p, 0xFF, (size_t)G * 8));
+    if ((rc = misses.reserve(span / 24 + 65536)) != BC_OK) return rc;  // grown when the file holds more misses than that
+    J.lib = lib; J.path = path; J.byte_begin = byte_begin; J.byte_end = byte_end;
+    J.max_mismatch = max_mismatch; J.algo = algo; J.n_threads = n_threads; J.key_base = key_base;
+    J.d_counts = (uint32_t*)d_counts.p; J.d_first = (uint64_t*)d_first.p; J.misses = &misses;
+    if ((rc = run_file(J)) != BC_OK) return rc;
+    bc_stream_result* res = new bc_stream_result();
     auto finish = [&]() -> int {
         BC_HIP(hipDeviceSynchronize());
-        res->n_reads = reads_launched;
-        // documented: counts / first-seen keys
-        if (h_counts) {
-            std::vector<uint32_t> c32(G);
-            BC_HIP(hipMemcpy(c32.data(), d_counts.p, (size_t)G * 4, hipMemcpyDeviceToHost));
-            for (uint32_t i = 0; i < G; ++i) h_counts[i] += c32[i];
-        }
-        if (h_first_seen) {
-            std::vector<uint64_t> fs(G);
-            BC_HIP(hipMemcpy(fs.data(), d_first.p, (size_t)G * 8, hipMemcpyDeviceToHost));
-            for (uint32_t i = 0; i < G; ++i) h_first_seen[i] = std::min(h_first_seen[i], fs[i]);
-        }
-        // undocumented: sort the (word, key) pairs by word, then one pass gives every distinct word its count and
-        // smallest key
-        const unsigned long long n_miss = miss_used;
-        if (n_miss) {
-            DevBuf w2, k2, tmp, uw, uf, uc, un;
-            int rc3;
-            if ((rc3 = w2.reserve(n_miss * 8)) != BC_OK) return rc3;
-            if ((rc3 = k2.reserve(n_miss * 8)) != BC_OK) return rc3;
-            if ((rc3 = uw.reserve(n_miss * 8)) != BC_OK) return rc3;
-            if ((rc3 = uf.reserve(n_miss * 8)) != BC_OK) return rc3;
-            if ((rc3 = uc.reserve(n_miss * 8)) != BC_OK) return rc3;
-            if ((rc3 = un.reserve(16)) != BC_OK) return rc3;
-            size_t tb = 0;
-            BC_HIP(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)m_words.p, (uint64_t*)w2.p, (uint64_t*)m_keys.p,
-                                             (uint64_t*)k2.p, (size_t)n_miss, 0, 64, 0));
-            if ((rc3 = tmp.reserve(tb)) != BC_OK) return rc3;
-            BC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t*)m_words.p, (uint64_t*)w2.p, (uint64_t*)m_keys.p,
-                                             (uint64_t*)k2.p, (size_t)n_miss, 0, 64, 0));
-            // every run of equal words: its smallest key, and its length (a sum of ones)
-            size_t tb2 = 0;
-            BC_HIP(rocprim::reduce_by_key(nullptr, tb2, (uint64_t*)w2.p, (uint64_t*)k2.p, (size_t)n_miss, (uint64_t*)uw.p,
-                                          (uint64_t*)uf.p, (uint64_t*)un.p, rocprim::minimum<uint64_t>(),
-                                          rocprim::equal_to<uint64_t>(), 0));
-            if ((rc3 = tmp.reserve(tb2)) != BC_OK) return rc3;
-            BC_HIP(rocprim::reduce_by_key(tmp.p, tb2, (uint64_t*)w2.p, (uint64_t*)k2.p, (size_t)n_miss, (uint64_t*)uw.p,
-                                          (uint64_t*)uf.p, (uint64_t*)un.p, rocprim::minimum<uint64_t>(),
-                                          rocprim::equal_to<uint64_t>(), 0));
-            size_t tb4 = 0;
-            auto ones_it = rocprim::make_constant_iterator<uint64_t>(1);
-            BC_HIP(rocprim::reduce_by_key(nullptr, tb4, (uint64_t*)w2.p, ones_it, (size_t)n_miss, (uint64_t*)uw.p,
-                                          (uint64_t*)uc.p, (uint64_t*)un.p, rocprim::plus<uint64_t>(),
-                                          rocprim::equal_to<uint64_t>(), 0));
-            if ((rc3 = tmp.reserve(tb4)) != BC_OK) return rc3;
-            BC_HIP(rocprim::reduce_by_key(tmp.p, tb4, (uint64_t*)w2.p, ones_it, (size_t)n_miss, (uint64_t*)uw.p,
-                                          (uint64_t*)uc.p, (uint64_t*)un.p, rocprim::plus<uint64_t>(),
-                                          rocprim::equal_to<uint64_t>(), 0));
-            BC_HIP(hipDeviceSynchronize());
-            uint64_t n_u = 0;
-            BC_HIP(hipMemcpy(&n_u, un.p, 8, hipMemcpyDeviceToHost));
-            res->device = device;
-            res->n_undoc = n_u;
-            res->d_words = (uint64_t*)uw.p; res->d_first = (uint64_t*)uf.p; res->d_counts = (uint64_t*)uc.p;
-            uw.p = nullptr; uf.p = nullptr; uc.p = nullptr;  // ownership moves to the result
-        }
-        std::sort(odd_all.begin(), odd_all.end(), [](const OddOut& a, const OddOut& b) { return a.key < b.key; });
+        res->n_reads = J.n_reads;
+        int rc3 = tallies_to_host(G, d_counts, d_first, h_counts, h_first_seen);
+        if (rc3 != BC_OK) return rc3;
+        if ((rc3 = group_misses(misses, device, res)) != BC_OK) return rc3;
         res->odd_off.push_back(0);
-        for (const OddOut& o : odd_all) {
+        for (const OddOut& o : J.odd_all) {
             res->odd_keys.push_back(o.key);
             res->odd_text += o.text;
             res->odd_off.push_back(res->odd_text.size());
@@ -588,6 +759,117 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
         return BC_OK;
     };
     rc = finish();
+    if (rc != BC_OK) { delete res; return rc; }
+    res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    *out = res;
+    return BC_OK;
+}
+
+// Paired-end form (heuristicount.py:469-518): both uncompressed files go through the device one after the other,
+// each leaving its windows {packed, status} at the read's index in HBM (18 bytes per pair in all); then one pass pairs
+// them (st1 == st2 == OK and p1 == p2, the reverse mate's window being reverse-complemented as it is packed),
+// the matcher runs once over all pairs, and the unmatched flank-valid pairs are grouped as for a single file.
+// path_fwd is the file whose reads carry the barcode in library orientation (the reference's reads1 AFTER its
+// need_swap exchange, :444-447), path_rev the other one.  Files with different numbers of reads fail like the
+// reference's process_paired_end (:483-486).
+int bc_stream_count_pair(bc_lib* lib, const char* path_fwd, const char* path_rev, int64_t start_fwd, const char* L_fwd,
+                         int L_fwd_len, const char* R_fwd, int R_fwd_len, int64_t start_rev, const char* L_rev,
+                         int L_rev_len, const char* R_rev, int R_rev_len, int max_mismatch, int algo, uint64_t key_base,
+                         int n_threads, uint64_t* h_counts, uint64_t* h_first_seen, bc_stream_result** out) {
+    if (!lib || !path_fwd || !path_rev || !out) { set_error("bc_stream_count_pair: null argument"); return BC_EINVAL; }
+    uint32_t G = 0; int k = 0, device = 0;
+    bc_lib_info(lib, &G, &k, &device);
+    const auto t_begin = std::chrono::steady_clock::now();
+    BC_HIP(hipSetDevice(device));
+    WindowStore W[2];
+    FileJob J[2];
+    int rc;
+    if ((rc = fill_geometry(J[0].g, k, start_fwd, L_fwd, L_fwd_len, R_fwd, R_fwd_len, 0, "bc_stream_count_pair")) != BC_OK) return rc;
+    if ((rc = fill_geometry(J[1].g, k, start_rev, L_rev, L_rev_len, R_rev, R_rev_len, 1, "bc_stream_count_pair")) != BC_OK) return rc;
+    const char* paths[2] = {path_fwd, path_rev};
+    for (int f = 0; f < 2; ++f) {
+        if ((rc = file_kind(paths[f], "bc_stream_count_pair", &J[f].g.fastq)) != BC_OK) return rc;
+        J[f].lib = lib; J[f].path = paths[f]; J[f].byte_begin = 0; J[f].byte_end = ~0ull;
+        J[f].n_threads = n_threads; J[f].key_base = key_base; J[f].store = &W[f];
+        if ((rc = run_file(J[f])) != BC_OK) return rc;
+    }
+    if (J[0].n_reads != J[1].n_reads) {
+        set_error("Length of reads1 and reads2 must be the same for paired-end data.");  // heuristicount.py:484-486
+        return BC_EINVAL;
+    }
+    const uint64_t n = J[0].n_reads;
+    bc_stream_result* res = new bc_stream_result();
+    auto body = [&]() -> int {
+        res->n_reads = n;
+        res->pair_off1.push_back(0);
+        res->pair_off2.push_back(0);
+        if (n == 0) return BC_OK;
+        const uint64_t *p1 = (const uint64_t*)W[0].packed.p, *p2 = (const uint64_t*)W[1].packed.p;
+        const uint8_t *s1 = (const uint8_t*)W[0].status.p, *s2 = (const uint8_t*)W[1].status.p;
+        // pairs with an odd window: both mates' windows back to the host (a packed mate is rebuilt from its word there)
+        std::vector<uint64_t> keys;
+        {
+            size_t a = 0, b = 0;
+            const auto &A = J[0].odd_all, &B = J[1].odd_all;
+            while (a < A.size() || b < B.size()) {
+                const uint64_t ka = a < A.size() ? A[a].key : ~0ull, kb = b < B.size() ? B[b].key : ~0ull;
+                const uint64_t kk = std::min(ka, kb);
+                keys.push_back(kk);
+                res->pair_text1 += (ka == kk) ? A[a].text : std::string();
+                res->pair_text2 += (kb == kk) ? B[b].text : std::string();
+                res->pair_off1.push_back(res->pair_text1.size());
+                res->pair_off2.push_back(res->pair_text2.size());
+                if (ka == kk) ++a;
+                if (kb == kk) ++b;
+            }
+        }
+        const uint64_t m = keys.size();
+        if (m) {
+            DevBuf d_idx, o1, o2, os1, os2;
+            int rc3;
+            std::vector<uint64_t> idx(m);
+            for (uint64_t j = 0; j < m; ++j) idx[j] = keys[j] - key_base;
+            if ((rc3 = d_idx.reserve(m * 8)) != BC_OK || (rc3 = o1.reserve(m * 8)) != BC_OK || (rc3 = o2.reserve(m * 8)) != BC_OK ||
+                (rc3 = os1.reserve(m)) != BC_OK || (rc3 = os2.reserve(m)) != BC_OK) return rc3;
+            BC_HIP(hipMemcpy(d_idx.p, idx.data(), m * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_gather_pairs, dim3((unsigned)((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, (const uint64_t*)d_idx.p, m,
+                               p1, s1, p2, s2, (uint64_t*)o1.p, (uint8_t*)os1.p, (uint64_t*)o2.p, (uint8_t*)os2.p);
+            BC_HIP(hipGetLastError());
+            res->pair_keys = keys;
+            res->pair_p1.resize(m); res->pair_p2.resize(m); res->pair_st1.resize(m); res->pair_st2.resize(m);
+            BC_HIP(hipMemcpy(res->pair_p1.data(), o1.p, m * 8, hipMemcpyDeviceToHost));
+            BC_HIP(hipMemcpy(res->pair_p2.data(), o2.p, m * 8, hipMemcpyDeviceToHost));
+            BC_HIP(hipMemcpy(res->pair_st1.data(), os1.p, m, hipMemcpyDeviceToHost));
+            BC_HIP(hipMemcpy(res->pair_st2.data(), os2.p, m, hipMemcpyDeviceToHost));
+        }
+        // pair, match, collect
+        DevBuf d_counts, d_first, flags, best, d_cursor;
+        MissList misses;
+        int rc3;
+        if ((rc3 = d_counts.reserve((size_t)G * 4)) != BC_OK) return rc3;
+        if ((rc3 = d_first.reserve((size_t)G * 8)) != BC_OK) return rc3;
+        if ((rc3 = flags.reserve(n + 64)) != BC_OK) return rc3;
+        if ((rc3 = best.reserve(n * 4 + 64)) != BC_OK) return rc3;
+        if ((rc3 = d_cursor.reserve(16)) != BC_OK) return rc3;
+        BC_HIP(hipMemset(d_counts.p, 0, (size_t)G * 4));
+        BC_HIP(hipMemset(d_first.p, 0xFF, (size_t)G * 8));
+        BC_HIP(hipMemset(d_cursor.p, 0, 16));
+        hipLaunchKernelGGL(k_pair_flags, dim3(grid_for(n)), dim3(BLOCK), 0, 0, p1, s1, p2, s2, n, (uint8_t*)flags.p);
+        BC_HIP(hipGetLastError());
+        if ((rc3 = bc_match_dev(lib, p1, (const uint8_t*)flags.p, n, max_mismatch, algo, (int32_t*)best.p, nullptr, nullptr,
+                                (uint32_t*)d_counts.p, (uint64_t*)d_first.p, key_base, nullptr)) != BC_OK) return rc3;
+        BC_HIP(hipDeviceSynchronize());
+        if ((rc3 = misses.reserve(n)) != BC_OK) return rc3;  // every pair could be a miss
+        hipLaunchKernelGGL(k_collect_misses, dim3(grid_for(n)), dim3(BLOCK), 0, 0, (const int32_t*)best.p, p1, n, kmer_mask(k),
+                           key_base, (uint64_t*)misses.words.p, (uint64_t*)misses.keys.p, (unsigned long long*)d_cursor.p);
+        BC_HIP(hipGetLastError());
+        unsigned long long used = 0;
+        BC_HIP(hipMemcpy(&used, d_cursor.p, 8, hipMemcpyDeviceToHost));
+        misses.used = used;
+        if ((rc3 = tallies_to_host(G, d_counts, d_first, h_counts, h_first_seen)) != BC_OK) return rc3;
+        return group_misses(misses, device, res);
+    };
+    rc = body();
     if (rc != BC_OK) { delete res; return rc; }
     res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     *out = res;

@@ -628,6 +628,11 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     device_ingest = (not is_paired and not file1.endswith((".gz", ".zst")) and (plan == "bytes" or world == 1)
                      and (bc_start2 if need_swap else bc_start1) is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                      and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
+    # paired-end: two uncompressed files, one process (ranks keep the strided host plan: every rank would need the
+    # mates' byte ranges, i.e. a line index of both files)
+    device_pairs = (is_paired and world == 1 and not file1.endswith((".gz", ".zst")) and not file2.endswith((".gz", ".zst"))
+                    and bc_start1 is not None and bc_start2 is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
+                    and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     undoc_tables, odd_events = [], []
     n_mine = [0]
     t_bulk = [0.0]
@@ -643,6 +648,32 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
         counts = np.zeros(G + 1, np.uint64)  # last element: reads seen by this rank
         first_seen = np.full(G + 1, np.iinfo(np.uint64).max, np.uint64)
         t0 = _time.perf_counter()
+        if device_pairs:
+            # both mate files through the device (bc_stream_count_pair); the file whose reads carry the barcode in
+            # library orientation is reads1 after the reference's swap (heuristicount.py:444-447)
+            from .ingest import stream_count_pair
+            s1, s2, Lf, Rf, Lr, Rr = cc.geom
+            p_fwd, p_rev = (file2, file1) if need_swap else (file1, file2)
+            c64, f64 = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
+            sr = stream_count_pair(cc.lib.handle, p_fwd, p_rev, s1, Lf, Rf, s2, Lr, Rr, max_mismatch, cc.algo, 0, c64, f64)
+            counts[:G], first_seen[:G] = c64, f64
+            undoc_tables.append((sr.u_words, sr.u_counts, sr.u_first))
+            for key, w1p, st1, w2p, st2, t1, t2 in sr.odd:  # string semantics (ChunkCounter.match_buffers)
+                if st1 == N.WIN_SKIP or st2 == N.WIN_SKIP:
+                    continue
+                w1 = t1[s1:s1 + len(Lf) + bc_len + len(Rf)] if st1 == N.WIN_ODD else \
+                    Lf + unpack_kmers(np.array([w1p], np.uint64), bc_len)[0] + Rf
+                w2 = t2[s2:s2 + len(Lr) + bc_len + len(Rr)] if st2 == N.WIN_ODD else \
+                    Lr + rev_comp(unpack_kmers(np.array([w2p], np.uint64), bc_len)[0]) + Rr
+                q1, q2 = w1[len(Lf):len(w1) - len(Rf)], w2[len(Lr):len(w2) - len(Rr)]
+                has = w1.startswith(Lf) and w1.endswith(Rf) and w2.startswith(Lr) and w2.endswith(Rr)
+                if q1 != rev_comp(q2) or not has:
+                    continue
+                odd_events.append((key, q1 if (w1 in cc.fwd_set and w2 in cc.rev_set) else q1 + "*"))
+            n_mine[0] = sr.n_reads
+            counts[G] = sr.n_reads
+            t_bulk[0] = _time.perf_counter() - t0
+            return counts, first_seen
         if device_ingest:
             # single uncompressed file: raw bytes -> HBM, everything per read on the device (bc_stream_count_file).
             # Nominal byte cuts become record-aligned ranges; the key of a read = range start + its ordinal.

@@ -148,3 +148,43 @@ def stream_count_file(lib_handle, path: str, byte_begin: int, byte_end: int, sta
         return StreamResult(int(n.value), float(sec.value), uw, uc, uf, odd)
     finally:
         lib.bc_stream_result_free(h)
+
+
+def stream_count_pair(lib_handle, path_fwd: str, path_rev: str, start_fwd: int, L_fwd: str, R_fwd: str, start_rev: int,
+                      L_rev: str, R_rev: str, max_mismatch: int, algo: str, key_base: int, counts: np.ndarray,
+                      first_seen: np.ndarray, n_threads: int = 0) -> StreamResult:
+    """The device path for two uncompressed mate files (bc_stream_count_pair).  `odd` of the result holds, per pair
+    with an odd window, (key, p1, st1, p2, st2, text1, text2): the packed word / status of each mate and the stripped
+    text of each odd mate ('' for a packed one)."""
+    lib = N.load()
+    h = N.vp()
+    enc = [x.encode("ascii") for x in (L_fwd, R_fwd, L_rev, R_rev)]
+    N.check(lib.bc_stream_count_pair(lib_handle, path_fwd.encode(), path_rev.encode(), int(start_fwd), enc[0], len(enc[0]),
+                                     enc[1], len(enc[1]), int(start_rev), enc[2], len(enc[2]), enc[3], len(enc[3]),
+                                     int(max_mismatch), N.ALGOS[algo], int(key_base), int(n_threads), N.ptr(counts),
+                                     N.ptr(first_seen), C.byref(h)))
+    try:
+        n, nu, no, ob, sec = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
+        N.check(lib.bc_stream_result_info(h, C.byref(n), C.byref(nu), C.byref(no), C.byref(ob), C.byref(sec)))
+        uw, uc, uf = (np.empty(nu.value, np.uint64) for _ in range(3))
+        if nu.value:
+            N.check(lib.bc_stream_result_undoc(h, N.ptr(uw), N.ptr(uc), N.ptr(uf)))
+        m, b1, b2 = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(lib.bc_stream_result_pair_info(h, C.byref(m), C.byref(b1), C.byref(b2)))
+        odd = []
+        if m.value:
+            mm = m.value
+            keys, p1, p2 = (np.empty(mm, np.uint64) for _ in range(3))
+            st1, st2 = np.empty(mm, np.uint8), np.empty(mm, np.uint8)
+            off1, off2 = np.empty(mm + 1, np.uint64), np.empty(mm + 1, np.uint64)
+            t1, t2 = np.empty(max(b1.value, 1), np.uint8), np.empty(max(b2.value, 1), np.uint8)
+            N.check(lib.bc_stream_result_pair_odd(h, N.ptr(keys), N.ptr(p1), N.ptr(st1), N.ptr(p2), N.ptr(st2), N.ptr(off1),
+                                                  N.ptr(t1), N.ptr(off2), N.ptr(t2)))
+            r1, r2 = t1.tobytes(), t2.tobytes()
+            o1, o2 = off1.astype(np.int64), off2.astype(np.int64)
+            odd = [(int(keys[i]), int(p1[i]), int(st1[i]), int(p2[i]), int(st2[i]),
+                    r1[o1[i]:o1[i + 1]].decode("ascii", errors="replace"), r2[o2[i]:o2[i + 1]].decode("ascii", errors="replace"))
+                   for i in range(mm)]
+        return StreamResult(int(n.value), float(sec.value), uw, uc, uf, odd)
+    finally:
+        lib.bc_stream_result_free(h)

@@ -158,6 +158,32 @@ int bc_stream_result_odd(const bc_stream_result *r, uint64_t *keys, uint64_t *of
                          char *text);
 int bc_stream_result_free(bc_stream_result *r);
 
+/* bc_stream_count_pair: the paired-end form (heuristicount.py:469-518, reached from
+ * :540-554).  Both UNCOMPRESSED files go through the device one after the other,
+ * each leaving {packed window, status} per read in HBM; then the pairs are formed
+ * (neither mate holds an N, both show their flanks, seq1 == rev_comp(seq2), :489-507),
+ * matched once over the whole run (documented: both windows in the library,
+ * :509-515; undocumented: flanks only, :517-518) and tallied.  path_fwd = the file
+ * whose reads carry the barcode in library orientation — reads1 AFTER the
+ * reference's need_swap exchange (:444-447) — with geometry (start_fwd, L_fwd,
+ * R_fwd); path_rev the other file, geometry (start_rev, L_rev, R_rev), windows
+ * reverse-complemented.  Key of pair i = key_base + i.  Files with different
+ * numbers of reads fail with BC_EINVAL and the reference's message (:484-486).
+ * Pairs with an odd window (flanks present, window short or not pure ACGT) come
+ * back through bc_stream_result_pair_*: per pair its key, both mates' packed word
+ * and status, and the stripped text of each odd mate (empty for a packed one). */
+int bc_stream_count_pair(bc_lib *lib, const char *path_fwd, const char *path_rev,
+                         int64_t start_fwd, const char *L_fwd, int L_fwd_len, const char *R_fwd,
+                         int R_fwd_len, int64_t start_rev, const char *L_rev, int L_rev_len,
+                         const char *R_rev, int R_rev_len, int max_mismatch, int algo,
+                         uint64_t key_base, int n_threads, uint64_t *h_counts,
+                         uint64_t *h_first_seen, bc_stream_result **out);
+int bc_stream_result_pair_info(const bc_stream_result *r, uint64_t *n_pairs, uint64_t *text1_bytes,
+                               uint64_t *text2_bytes);
+int bc_stream_result_pair_odd(const bc_stream_result *r, uint64_t *keys, uint64_t *p1, uint8_t *st1,
+                              uint64_t *p2, uint8_t *st2, uint64_t *off1 /* n_pairs + 1 */,
+                              char *text1, uint64_t *off2 /* n_pairs + 1 */, char *text2);
+
 /* ---- sampling (host) --------------------------------------------------------
  * bc_sample_data: orientation / barcode offset discovery on the first chunks of
  * the reads file(s), heuristicount.py:156-379 (sample_data).  `barcodes` = G

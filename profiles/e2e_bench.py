@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end timing of barcoder_amd.heuristicount.count_barcodes on a synthetic
 .reads file (5 nt + CCGGATTCAG + 20-mer + GTTTTAGAGC, the layout of BASELINE.md
-section 2).  usage: python profiles/e2e_bench.py [n_reads] [n_guides]"""
+section 2).  usage: python profiles/e2e_bench.py [n_reads] [n_guides] [paired]
+`paired` adds a mate file (3 nt + the reverse complement of flank + 20-mer + flank) and counts the pairs."""
 import os, sys, time, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +10,7 @@ from barcoder_amd import encoding as E, synth as S, heuristicount as H
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
+PAIRED = len(sys.argv) > 3 and sys.argv[3] == "paired"
 d = tempfile.mkdtemp(prefix="bc_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 lib = S.library(G, 20)
 labels = E.unpack_kmers(lib, 20)
@@ -19,6 +21,8 @@ t0 = time.perf_counter()
 rd = os.path.join(d, "reads.reads")
 CH = 2_000_000
 lut = np.frombuffer(b"ACGT", np.uint8)
+rd2 = os.path.join(d, "mates.reads")
+f2 = open(rd2, "wb") if PAIRED else None
 with open(rd, "wb") as f:
     for a in range(0, n, CH):
         m = min(CH, n - a)
@@ -34,15 +38,25 @@ with open(rd, "wb") as f:
         row[:, 35:45] = np.frombuffer(b"GTTTTAGAGC", np.uint8)
         row[:, 45] = 10
         f.write(row.tobytes())
+        if f2 is not None:  # the mate: 3 nt, then the reverse complement of flank + barcode + flank
+            comp = np.zeros(256, np.uint8)
+            comp[list(b"ACGT")] = list(b"TGCA")
+            mate = np.empty((m, 44), np.uint8)
+            mate[:, :3] = pre[:, :3]
+            mate[:, 3:43] = comp[row[:, 5:45][:, ::-1]]
+            mate[:, 43] = 10
+            f2.write(mate.tobytes())
+if f2 is not None:
+    f2.close()
 print(f"generated {n} reads ({os.path.getsize(rd) / 1e6:.0f} MB) in {time.perf_counter() - t0:.1f} s", file=sys.stderr)
 t0 = time.perf_counter()
-r = H.count_barcodes(fa, rd)
+r = H.count_barcodes(fa, rd, rd2 if PAIRED else None)
 dt = time.perf_counter() - t0
 print({"reads": n, "guides": G, "seconds": round(dt, 2), "Mreads_per_s": round(n / dt / 1e6, 2),
        "documented_reads": sum(r["doc"].values()), "undocumented_reads": r["undoc"].total(),
        "offset": r["bc_start1"], "flanks": r["flanks_fwd"]})
 
-print({"bulk_pass": "device ingest (bc_stream_count_file)" if r["shard_plan"] == "stride" and os.environ.get("BC_DEVICE_INGEST", "1") != "0" else "host front half",
+print({"bulk_pass": ("device ingest (bc_stream_count_pair)" if PAIRED else "device ingest (bc_stream_count_file)") if r["shard_plan"] == "stride" and os.environ.get("BC_DEVICE_INGEST", "1") != "0" else "host front half",
        "bulk_Mreads_per_s": round(r["bulk_mreads_per_s"], 1), "bulk_GB_per_s_of_file": round(r["bulk_mreads_per_s"] * 46e6 / 1e9, 2),
        "undocumented_barcodes": len(r["undoc"]), "seconds": {k_: round(v, 2) for k_, v in r["seconds"].items()}})
 t0 = time.perf_counter()

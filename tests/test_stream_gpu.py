@@ -152,3 +152,90 @@ def test_undocumented_list_grows_under_concurrent_workers(gpu_device, tmp_path):
         np.testing.assert_array_equal(r.u_words[order], uw)
         np.testing.assert_array_equal(r.u_counts[order], cnt.astype(np.uint64))
         np.testing.assert_array_equal(r.u_first[order], first_keys.astype(np.uint64))
+
+
+def _make_pair_files(tmp_path, n, k, fastq, rng, lib_s, swapped):
+    """Mates: read 1 carries L + barcode + R, read 2 the reverse complement of that stretch; with N reads, mates that
+    disagree, short reads, odd characters (in one mate, or mirrored in both so that the pair still agrees), blank
+    lines.  swapped: the files change roles (file 1 holds the reverse mates)."""
+    from barcoder_amd.heuristicount import rev_comp
+    r1, r2 = [], []
+    for i in range(n):
+        bc = lib_s[int(rng.integers(0, len(lib_s)))]
+        if rng.random() < 0.10:
+            bc = "".join(rng.choice(list("ACGT"), size=k))
+        mid = L_FLANK + bc + R_FLANK
+        a = "".join(rng.choice(list("ACGT"), size=5)) + mid + "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 9))))
+        b = "".join(rng.choice(list("ACGT"), size=3)) + rev_comp(mid) + "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 7))))
+        v = rng.random()
+        if v < 0.01:
+            p = int(rng.integers(0, len(a)))
+            a = a[:p] + "N" + a[p + 1:]
+        elif v < 0.02:
+            p = int(rng.integers(0, len(b)))
+            b = b[:p] + "N" + b[p + 1:]
+        elif v < 0.04:   # mates disagree
+            other = lib_s[int(rng.integers(0, len(lib_s)))]
+            b = b[:3] + rev_comp(L_FLANK + other + R_FLANK) + b[3 + len(mid):]
+        elif v < 0.05:
+            a = a[:int(rng.integers(0, len(a)))]
+        elif v < 0.06:   # odd character inside one mate's window
+            p = 15 + int(rng.integers(0, k))
+            a = a[:p] + "a" + a[p + 1:]
+        elif v < 0.07:   # the same odd character mirrored in both mates: the pair still agrees (undocumented, as a string)
+            j = int(rng.integers(0, k))
+            a = a[:15 + j] + "a" + a[15 + j + 1:]
+            q = 3 + len(R_FLANK) + (k - 1 - j)
+            b = b[:q] + "a" + b[q + 1:]
+        elif v < 0.075:
+            b = ""
+        elif v < 0.085:
+            a, b = "  " + a + "\t", b + "  "
+        r1.append(a)
+        r2.append(b)
+    if swapped:
+        r1, r2 = r2, r1
+    paths = []
+    for name, reads in (("m1", r1), ("m2", r2)):
+        path = tmp_path / (name + (".fastq" if fastq else ".reads"))
+        with open(path, "w", newline="") as f:
+            for i, r in enumerate(reads):
+                f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" if fastq else r + "\n")
+        paths.append(str(path))
+    return paths
+
+
+@pytest.mark.parametrize("fastq,swapped,k", [(False, False, 20), (True, True, 20), (False, True, 32)])
+def test_paired_device_ingest_equals_host_front_half(gpu_device, tmp_path, monkeypatch, fastq, swapped, k):
+    """bc_stream_count_pair (both mate files through the device, pairing and one match over the whole run) against
+    the host front half of the same job (bc_reader_* + bc_pack_windows per chunk, itself pinned by the reference's
+    paired golden vectors): documented counts in first-seen order, undocumented table, odd pairs, totals."""
+    from barcoder_amd import encoding as E, heuristicount as H, synth as S
+    rng = np.random.default_rng(23 + k + fastq)
+    lib = S.library(3000, k)
+    lib_s = E.unpack_kmers(lib, k)
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">g{i}\n{s}\n" for i, s in enumerate(lib_s)))
+    n = 260_000 if fastq else 520_000            # more than one 16 MiB chunk per file
+    f1, f2 = _make_pair_files(tmp_path, n, k, fastq, rng, lib_s, swapped)
+    assert os.path.getsize(f1) > 17 << 20
+    for mm in (0, 1):
+        monkeypatch.setenv("BC_DEVICE_INGEST", "1")
+        dev = H.count_barcodes(str(fa), f1, f2, device=gpu_device, max_mismatch=mm)
+        monkeypatch.setenv("BC_DEVICE_INGEST", "0")
+        host = H.count_barcodes(str(fa), f1, f2, device=gpu_device, max_mismatch=mm, chunk_reads=100_003)
+        assert dev["total_reads"] == host["total_reads"] == n
+        assert dev["need_swap"] == host["need_swap"] == swapped
+        assert list(dev["doc"].items()) == list(host["doc"].items())
+        assert sum(dev["doc"].values()) > 0.6 * n
+        assert dict(dev["undoc"].items()) == dict(host["undoc"].items())
+        assert [k_ for k_, _ in dev["undoc"].items()] == [k_ for k_, _ in host["undoc"].items()]
+        assert dev["undoc"].extra == host["undoc"].extra and len(dev["undoc"].extra) > 0   # the mirrored odd pairs
+    # mate files of different lengths: the reference's error (heuristicount.py:484-486), raised as ValueError
+    short = tmp_path / ("short" + (".fastq" if fastq else ".reads"))
+    with open(f2) as f, open(short, "w") as g:
+        lines = f.readlines()
+        g.writelines(lines[:len(lines) - (8 if fastq else 2)])
+    monkeypatch.setenv("BC_DEVICE_INGEST", "1")
+    with pytest.raises(ValueError, match="Length of reads1 and reads2 must be the same"):
+        H.count_barcodes(str(fa), f1, str(short), device=gpu_device)
