@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <deque>
+#include <list>
 #include <mutex>
 #include <vector>
 
@@ -146,14 +146,11 @@ struct TallyWs {
     uint32_t* ovf_count = nullptr; // self-resetting (k_first_refine)
     uint32_t* first_tile = nullptr;  // [G], 0xFFFFFFFF between launches
     uint64_t tiles_cap = 0;
-    // d = 3 cascade: the reads the d <= 2 pass left without a hit, compacted, and their results before the scatter
+    // d = 3 cascade: the reads the d <= 2 pass left without a hit, compacted (their results are written in place)
     uint64_t casc_cap = 0;
     uint32_t* c_idx = nullptr;     // [casc_cap] position of the read in the launch
     uint64_t* c_reads = nullptr;   // [casc_cap]
-    int32_t* c_best = nullptr;     // [casc_cap]
-    uint8_t* c_dist = nullptr;     // [casc_cap]
-    uint8_t* c_nb = nullptr;       // [casc_cap]
-    uint32_t* c_count = nullptr;   // [4]
+    uint32_t* c_count = nullptr;   // [4] how many: read by the second stage on the device, never by the host
 };
 
 }  // namespace bc
@@ -183,7 +180,7 @@ struct bc_lib {
     bool pairs_tried = false;                  // under ws_mutex
     std::vector<uint2> fast_stage[4];          // library creation only: regions of SlabParams::fast before upload
     bc::Knobs knobs;
-    std::deque<bc::TallyWs> ws;    // tally workspaces by stream (deque: pointers stay valid as it grows)
+    std::list<bc::TallyWs> ws;     // tally / cascade workspaces by stream (list: pointers stay valid as entries come and go)
     std::mutex ws_mutex;
     std::atomic<const char*> last_kernel{""};  // name of the match kernel launched last (bc_lib_last_kernel)
     void* host_slots = nullptr;    // HostSlot[3]: staging of bc_match_host, kept between calls

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict
                                                       const uint32_t* __restrict__ s32,
                                                       const uint64_t* __restrict__ guides, int k,
                                                       int log_slots, uint64_t kmask, MatchOut o) {
-    __shared__ __attribute__((aligned(16))) uint16_t p_stage[VEC == 4 ? (BLOCK / 64) * PART_MAX_NR * PART_CAP : 8];
+    __shared__ __attribute__((aligned(16))) uint16_t p_stage[VEC == 4 ? (BLOCK / 64) * PART_SLOTS : 8];
     __shared__ uint32_t p_cnt[VEC == 4 ? (BLOCK / 64) * PART_MAX_NR : 1];
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     const uint64_t ngroups = n / VEC;
@@ -100,8 +100,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict
             }
             if (o.part.rec) {
                 const uint32_t w = threadIdx.x >> 6;
-                part_emit(o.part, (uint32_t)((g0 * VEC) >> 8), idx, lane, p_stage + w * (PART_MAX_NR * PART_CAP),
-                          p_cnt + w * PART_MAX_NR);
+                part_emit(o.part, (uint32_t)((g0 * VEC) >> 8), idx, lane, p_stage + w * PART_SLOTS, p_cnt + w * PART_MAX_NR);
             }
         } else {
             if (active) emit(o, g, idx[0], idx[0] >= 0 ? 0u : (uint32_t)BC_DIST_NONE, idx[0] >= 0 ? 1u : 0u);
@@ -913,10 +912,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         for (int j = 0; j < 4; ++j)
             if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
         if (o.part.rec) {
-            // the lists are dead (every lane has its results in registers): q_key becomes the record staging area
-            // (256 dwords), the item stack the range counters
+            // the lists are dead (every lane has its results in registers): q_read becomes the record staging area
+            // (2 KiB = PART_SLOTS two-byte slots), the item stack the range counters
+            static_assert(sizeof(q_read) >= PART_SLOTS * sizeof(uint16_t) && WL_CAP >= PART_MAX_NR, "record staging");
             wave_lds_sync();
-            part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_key), wl);
+            part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_read), wl);
         }
     }
     phase_mark(3);
@@ -1016,10 +1016,11 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_part(PartOut P, const int32
     const uint32_t width = min(P.R, G - lo);
     for (uint32_t j = threadIdx.x; j < width; j += HIST_BLOCK) { cnt[j] = 0; ft[j] = 0xFFFFFFFFu; }
     __syncthreads();
-    // records: 8 lanes per tile line (16 B each), tiles of this slice
+    // records: a tile's line is 8, 4 or 2 pieces of 16 bytes (64, 32 or 16 records), tiles of this slice
     const uint64_t per = ((uint64_t)P.n_tiles + slices - 1) / slices;
     const uint64_t t0 = (uint64_t)slice * per, t1 = min((uint64_t)P.n_tiles, t0 + per);
-    const u32x4* pv = reinterpret_cast<const u32x4*>(P.rec + (size_t)range * P.n_tiles * PART_CAP);
+    const uint32_t pc_log2 = P.cap_log2 - 3u;  // log2 of the pieces per line
+    const u32x4* pv = reinterpret_cast<const u32x4*>(P.rec + (((size_t)range * P.n_tiles) << P.cap_log2));
     auto take = [&](const u32x4& v, uint32_t tile) {
         const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1034,17 +1035,17 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_part(PartOut P, const int32
             }
         }
     };
-    const uint64_t q0 = t0 * 8, q1 = t1 * 8;  // 16-byte pieces
+    const uint64_t q0 = t0 << pc_log2, q1 = t1 << pc_log2;  // 16-byte pieces
     uint64_t q = q0 + threadIdx.x;
     for (; q + 3 * HIST_BLOCK < q1; q += 4 * HIST_BLOCK) {  // four loads in flight
         const u32x4 v0 = __builtin_nontemporal_load(pv + q), v1 = __builtin_nontemporal_load(pv + q + HIST_BLOCK);
         const u32x4 v2 = __builtin_nontemporal_load(pv + q + 2 * HIST_BLOCK), v3 = __builtin_nontemporal_load(pv + q + 3 * HIST_BLOCK);
-        take(v0, (uint32_t)(q >> 3));
-        take(v1, (uint32_t)((q + HIST_BLOCK) >> 3));
-        take(v2, (uint32_t)((q + 2 * HIST_BLOCK) >> 3));
-        take(v3, (uint32_t)((q + 3 * HIST_BLOCK) >> 3));
+        take(v0, (uint32_t)(q >> pc_log2));
+        take(v1, (uint32_t)((q + HIST_BLOCK) >> pc_log2));
+        take(v2, (uint32_t)((q + 2 * HIST_BLOCK) >> pc_log2));
+        take(v3, (uint32_t)((q + 3 * HIST_BLOCK) >> pc_log2));
     }
-    for (; q < q1; q += HIST_BLOCK) take(__builtin_nontemporal_load(pv + q), (uint32_t)(q >> 3));
+    for (; q < q1; q += HIST_BLOCK) take(__builtin_nontemporal_load(pv + q), (uint32_t)(q >> pc_log2));
     // tiles whose records did not fit (overflow flag): straight from best_idx
     auto take_idx = [&](int32_t v, uint32_t tile) {
         const uint32_t g = (uint32_t)v - lo;  // negative sentinels wrap far above width
@@ -1582,6 +1583,43 @@ int build_hash(bc_lib* lib) {
 }
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// 16-byte reads / results and 4-byte distance / tie words: what the vectorised kernels need
+bool vector_io_ok(const uint64_t* d_reads, const MatchOut& o, uint64_t n) {
+    return aligned16(d_reads) && aligned16(o.best_idx) && n >= 4 && (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
+           (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
+}
+
+// does the wave matcher (k_match_wq) take a launch with this budget?  nq01 / nq2: 16-byte pieces per lane of a
+// table-0/1 and of a table-2 slab
+bool wave_kernel_serves(const bc_lib* lib, int max_mm, int algo, bool vec_ok, int* nq01_out, int* nq2_out) {
+    if (max_mm < 1 || max_mm >= MAX_SEG) return false;
+    const SlabParams& hp = lib->slab[max_mm];
+    const int nseg = hp.nseg;
+    const bool wide = lib->slab_wide[max_mm];
+    // table-0/1 slabs of 64 bytes (8 narrow entries) or 128 bytes (16 narrow entries: buckets above 16 guides; or
+    // 8 wide entries): one or two 16-byte pieces per lane
+    const int nq01 = (int)(((wide ? 16u : 8u) << hp.t[0].log2S) / 64u);
+    bool wave_ok = algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && vec_ok && !lib->knobs.single_slab &&
+                   lib->knobs.lane && (nseg == 2 || nseg == 3) && hp.t[0].log2S == hp.t[1].log2S &&
+                   (nq01 == 1 || nq01 == 2) && !lib->h_nn.empty();
+    for (int t = 0; t < nseg && wave_ok; ++t) wave_ok = hp.t[t].empty < (1u << 22);  // slab numbers travel in 22-bit item fields
+    // narrow 128-byte slabs: measured against the quad kernels, 1e8 reads, d <= 2: 5e5 20-mers (30 per bucket) 14.7 vs
+    // 13.1 G reads/s, 1e6 (61 per bucket) 6.1 vs 7.1, 2e4 12-mers (rest of 8 bases: ties everywhere) 9.6 vs 11.0
+    if (wave_ok && !wide && nq01 == 2 && (lib->k < 16 || (double)lib->G / (double)(1u << (2 * hp.t[0].slen)) > 40.0)) wave_ok = false;
+    const int nq2 = nseg == 3 ? (int)(((wide ? 16u : 8u) << hp.t[2].log2S) / 64u) : nq01;  // pieces per lane, table 2
+    if (wave_ok && nseg == 3 && (nq2 > 4 || (nq01 == 2 && nq2 < 2))) wave_ok = false;
+    *nq01_out = nq01; *nq2_out = nq2;
+    return wave_ok;
+}
+
+// does the kernel a launch will run write tally records (PartOut)?  k_match_hash and k_match_wq do
+bool kernel_writes_records(const bc_lib* lib, const uint64_t* d_reads, const MatchOut& o, uint64_t n, int max_mm, int algo) {
+    const bool vec_ok = vector_io_ok(d_reads, o, n);
+    if (algo == BC_ALGO_HASH) return vec_ok && max_mm == 0;
+    int a, b;
+    return wave_kernel_serves(lib, max_mm, algo, vec_ok, &a, &b);
+}
 int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
                         int max_mm, int algo, const MatchOut& o, hipStream_t st, bool* part_done, uint64_t* tail_begin);
 
@@ -1622,19 +1660,45 @@ int launch_hist(bc_lib* lib, const MatchOut& o, uint64_t n, hipStream_t st) {
 // return by position), searched by the d = 3 kernels, and scattered back.
 constexpr uint64_t COLLECT_CHUNK = 16384;  // reads per workgroup: one global append per chunk (a shared counter takes
                                            // ~90 appends per microsecond on this part: one per wave cost 17 ms per 1e8 reads)
+// One sweep: a thread holds its 64 results (sixteen 16-byte loads, all in flight) in registers, the block turns the
+// per-thread miss counts into offsets and makes ONE append for the chunk, then every thread writes its misses from
+// the registers.  (Round 2 swept the chunk twice with 4-byte loads, one dependent load per iteration: 0.40 ms per
+// 1e8 reads against the 0.07 ms the bytes take.)
 __global__ __launch_bounds__(BLOCK) void k_collect_missed(const int32_t* __restrict__ best_idx, const uint64_t* __restrict__ reads,
                                                          uint64_t n, uint32_t* __restrict__ idx, uint64_t* __restrict__ out_reads,
                                                          uint32_t* __restrict__ count) {
     __shared__ uint32_t w_cnt[BLOCK / 64];
     __shared__ uint32_t w_base[BLOCK / 64];
-    const uint64_t c0 = (uint64_t)blockIdx.x * COLLECT_CHUNK, c1 = min(n, c0 + COLLECT_CHUNK);
+    constexpr int PER = (int)(COLLECT_CHUNK / BLOCK / 4);  // 16-byte loads per thread
+    const uint64_t c0 = (uint64_t)blockIdx.x * COLLECT_CHUNK;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t mine = 0;  // misses this wave has met (wave-uniform)
-    for (uint64_t b = c0; b < c1; b += BLOCK) {
-        const uint64_t i = b + threadIdx.x;
-        mine += (uint32_t)__popcll(__ballot(i < c1 && best_idx[i] == BC_IDX_MISS));
+    const u32x4* pv = reinterpret_cast<const u32x4*>(best_idx);  // (the cascade requires a 16-byte aligned best_idx)
+    u32x4 v[PER];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint64_t i = c0 + ((uint64_t)q * BLOCK + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            v[q] = pv[i >> 2];
+        } else {  // ragged end: element by element, past the end = a hit (never collected)
+            uint32_t e[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[c] = (i + c < n) ? (uint32_t)best_idx[i + c] : 0u;
+            v[q] = u32x4{e[0], e[1], e[2], e[3]};
+        }
     }
-    if (lane == 0) w_cnt[wv] = mine;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        mine += (v[q].x == (uint32_t)BC_IDX_MISS) + (v[q].y == (uint32_t)BC_IDX_MISS) + (v[q].z == (uint32_t)BC_IDX_MISS) +
+                (v[q].w == (uint32_t)BC_IDX_MISS);
+    // exclusive scan of `mine` over the block
+    uint32_t x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63u) w_cnt[wv] = x;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
@@ -1643,48 +1707,38 @@ __global__ __launch_bounds__(BLOCK) void k_collect_missed(const int32_t* __restr
         for (int w = 0; w < BLOCK / 64; ++w) w_base[w] += base;
     }
     __syncthreads();
-    uint32_t at = w_base[wv];
-    for (uint64_t b = c0; b < c1; b += BLOCK) {  // second sweep of the chunk's results (L2-resident)
-        const uint64_t i = b + threadIdx.x;
-        const bool miss = i < c1 && best_idx[i] == BC_IDX_MISS;
-        const unsigned long long m = __ballot(miss);
-        if (miss) {
-            const uint32_t pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            idx[pos] = (uint32_t)(i);
-            out_reads[pos] = reads[i];
-        }
-        at += (uint32_t)__popcll(m);
+    uint32_t at = w_base[wv] + x - mine;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint64_t i = c0 + ((uint64_t)q * BLOCK + threadIdx.x) * 4;
+        const uint32_t e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (e[c] == (uint32_t)BC_IDX_MISS) {
+                idx[at] = (uint32_t)(i + c);
+                out_reads[at] = reads[i + c];
+                ++at;
+            }
     }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_scatter_results(const uint32_t* __restrict__ idx, uint32_t nm, const int32_t* __restrict__ c_best,
-                                                          const uint8_t* __restrict__ c_dist, const uint8_t* __restrict__ c_nb,
-                                                          int32_t* __restrict__ best_idx, uint8_t* __restrict__ best_dist,
-                                                          uint8_t* __restrict__ n_best) {
-    const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= nm) return;
-    const uint32_t i = idx[j];
-    best_idx[i] = c_best[j];
-    if (best_dist) best_dist[i] = c_dist[j];
-    if (n_best) n_best[i] = c_nb[j];
 }
 
 // ---- tally records: geometry and per-stream workspace -------------------------------------------------------
 // ranges: as few as the LDS allows (HIST_R guides each), equal sizes; range(g) = umulhi(g, magic) must be exact
 bool part_geometry(uint32_t G, PartOut& P) {
     uint32_t nr = (G + HIST_R - 1) / HIST_R;
-    // one or two ranges: sweeping best_idx costs no more.  Above eight the lines are mostly empty (256 reads over nr
-    // ranges) and writing + reading them costs what the sweeps cost (measured, 25 ranges: 1.13 vs 1.07 ms per 1e8 reads)
+    // one or two ranges: sweeping best_idx costs no more
     if (nr < 3 || nr > (uint32_t)PART_MAX_NR) return false;
-    // a line holds 64 records: with three or four ranges a tile's 256 results overflow it as a rule (77 / 58 hits per
-    // range at a 90 % hit rate) and every tile falls back to best_idx (measured at 6e4 / 8e4 guides: 7.2 / 4.7 ms per
-    // pass instead of 1.2): at least five ranges, i.e. at most 51 expected hits per line
+    // a line must hold well more than the hits it expects (256 results x 90 % over nr ranges): with three or four
+    // ranges and 64-record lines a tile overflows as a rule (77 / 58 hits per range) and falls back to best_idx
+    // (measured at 6e4 / 8e4 guides: 7.2 / 4.7 ms per pass instead of 1.2): at least five ranges (<= 51 expected in 64);
+    // 17..32 ranges take 32-record lines (<= 13.6 expected), 33..64 take 16-record lines (<= 7 expected)
     nr = std::max(nr, 5u);
     const uint32_t R = (G + nr - 1) / nr;
     const uint32_t magic = (uint32_t)((0x100000000ull + R - 1) / R);
     for (uint32_t g = 0; g < G; ++g)
         if ((uint32_t)(((uint64_t)g * magic) >> 32) != g / R) return false;
     P.nr = nr; P.R = R; P.magic = magic;
+    P.cap_log2 = nr <= 16u ? 6u : nr <= 32u ? 5u : 4u;
     return true;
 }
 
@@ -1693,7 +1747,10 @@ static int stream_workspace(bc_lib* lib, hipStream_t st, TallyWs** out) {  // ca
     TallyWs* w = nullptr;
     for (auto& e : lib->ws) if (e.stream == (void*)st) w = &e;
     if (!w) {
-        if (lib->ws.size() >= 64) { set_error("bc_match: more than 64 streams share one library"); return BC_EINVAL; }
+        if (lib->ws.size() >= 1024) {  // (a caller that rotates streams releases them: bc_lib_release_stream)
+            set_error("bc_match: more than 1024 streams hold a workspace on one library (bc_lib_release_stream frees one)");
+            return BC_EINVAL;
+        }
         lib->ws.emplace_back();
         w = &lib->ws.back();
         w->stream = (void*)st;
@@ -1715,20 +1772,17 @@ int cascade_workspace(bc_lib* lib, hipStream_t st, uint64_t n, TallyWs** out) {
     if (!w->c_count) BC_HIP(hipMalloc((void**)&w->c_count, 16));
     if (n > w->casc_cap) {
         BC_HIP(hipStreamSynchronize(st));
-        for (void* p : {(void*)w->c_idx, (void*)w->c_reads, (void*)w->c_best, (void*)w->c_dist, (void*)w->c_nb}) if (p) (void)hipFree(p);
-        w->c_idx = nullptr; w->c_reads = nullptr; w->c_best = nullptr; w->c_dist = nullptr; w->c_nb = nullptr; w->casc_cap = 0;
+        for (void* p : {(void*)w->c_idx, (void*)w->c_reads}) if (p) (void)hipFree(p);
+        w->c_idx = nullptr; w->c_reads = nullptr; w->casc_cap = 0;
         BC_HIP(hipMalloc((void**)&w->c_idx, (size_t)n * 4));
         BC_HIP(hipMalloc((void**)&w->c_reads, (size_t)n * 8));
-        BC_HIP(hipMalloc((void**)&w->c_best, (size_t)n * 4));
-        BC_HIP(hipMalloc((void**)&w->c_dist, (size_t)n));
-        BC_HIP(hipMalloc((void**)&w->c_nb, (size_t)n));
         w->casc_cap = n;
     }
     *out = w;
     return BC_OK;
 }
 
-int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, TallyWs** out) {
+int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, uint32_t cap_log2, TallyWs** out) {
     std::lock_guard<std::mutex> g(lib->ws_mutex);
     TallyWs* w = nullptr;
     int rc = stream_workspace(lib, st, &w);
@@ -1738,7 +1792,7 @@ int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, 
         if (w->rec) (void)hipFree(w->rec);
         if (w->ovf_list) (void)hipFree(w->ovf_list);
         w->rec = nullptr; w->ovf_list = nullptr; w->tiles_cap = 0;
-        BC_HIP(hipMalloc((void**)&w->rec, (size_t)n_tiles * nr * PART_CAP * sizeof(uint16_t)));
+        BC_HIP(hipMalloc((void**)&w->rec, (((size_t)n_tiles * nr) << cap_log2) * sizeof(uint16_t)));
         BC_HIP(hipMalloc((void**)&w->ovf_list, (size_t)n_tiles * 4));
         w->tiles_cap = n_tiles;
     }
@@ -1770,12 +1824,11 @@ int ensure_pair_index(bc_lib* lib) {
     return rc;
 }
 
-// max_mismatch = 3 as a cascade (see k_collect_missed).  One host synchronisation per launch: the number of reads left
-// for the second stage sizes its grid.
+// max_mismatch = 3 as a cascade (see k_collect_missed).  Fully asynchronous: the number of reads left for the second
+// stage stays on the device (k_match_pairs_quad reads it and strides over the list), results land in place.
 int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o_in, hipStream_t st) {
-    const uint64_t CH = 1ull << 27;  // reads per round: bounds the workspace (18 bytes per read)
+    const uint64_t CH = 1ull << 27;  // reads per round: bounds the workspace (12 bytes per read)
     const bool want_tally = o_in.counts || o_in.first_seen;
-    const char* second = nullptr;
     for (uint64_t a = 0; a < n; a += CH) {
         const uint64_t m = std::min(CH, n - a);
         MatchOut o = o_in;
@@ -1796,23 +1849,8 @@ int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags
         hipLaunchKernelGGL(k_collect_missed, dim3((unsigned)blocks), dim3(BLOCK), 0, st, o.best_idx, d_reads + a, m, w->c_idx,
                            w->c_reads, w->c_count);
         BC_HIP(hipGetLastError());
-        uint32_t nm = 0;
-        BC_HIP(hipMemcpyAsync(&nm, w->c_count, 4, hipMemcpyDeviceToHost, st));
-        BC_HIP(hipStreamSynchronize(st));
-        if (nm) {
-            MatchOut o2{w->c_best, o.best_dist ? w->c_dist : nullptr, o.n_best ? w->c_nb : nullptr, nullptr, nullptr, 0, PartOut{}};
-            if (lib->d_pairs) {
-                rc = launch_pairs(lib, 3, w->c_reads, nullptr, nm, o2, st);
-                if (rc == BC_OK) note_kernel(lib, "k_match_pairs");
-            } else {
-                rc = launch_match_kernel(lib, w->c_reads, nullptr, nm, 3, BC_ALGO_SEED, o2, st, &pd, &tb);
-            }
-            if (rc != BC_OK) return rc;
-            second = lib->last_kernel.load(std::memory_order_relaxed);
-            hipLaunchKernelGGL(k_scatter_results, dim3((nm + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, w->c_idx, nm, w->c_best,
-                               w->c_dist, w->c_nb, o.best_idx, o.best_dist, o.n_best);
-            BC_HIP(hipGetLastError());
-        }
+        rc = launch_pairs_list(lib, 3, w->c_reads, w->c_idx, w->c_count, m, o.best_idx, o.best_dist, o.n_best, st);
+        if (rc != BC_OK) return rc;
         if (want_tally) {
             MatchOut t = o;
             t.counts = o_in.counts; t.first_seen = o_in.first_seen;
@@ -1820,14 +1858,7 @@ int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags
             if (rc != BC_OK) return rc;
         }
     }
-    // which kernels ran: the d <= 2 pass, then (if any read was left) the d = 3 kernel
-    const char* name = "cascade3:d2";
-    if (second) {
-        name = !strcmp(second, "k_match_pairs") ? "cascade3:d2+k_match_pairs"
-             : !strcmp(second, "k_match_fused") ? "cascade3:d2+k_match_fused"
-             : !strcmp(second, "k_match_slab") ? "cascade3:d2+k_match_slab" : "cascade3:d2+k_match_seed";
-    }
-    note_kernel(lib, name);
+    note_kernel(lib, "cascade3:d2+k_match_pairs");
     return BC_OK;
 }
 
@@ -1854,7 +1885,10 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     const bool want_tally = o_in.counts || o_in.first_seen;
     // libraries of more than 36 ranges (7.4e5 guides): one sweep of best_idx per range (0.05 ms each per 1e8 reads) costs
     // more than device-scope atomics on counters that spread (1.6 - 2.2 ms per 1e8 reads at 5e5 - 3e6 guides)
-    const bool sweeps_pay = (lib->G + HIST_R - 1) / HIST_R <= 36u;
+    // (records serve up to PART_MAX_NR = 64 ranges — 1.3e6 guides — when the kernel that runs writes them)
+    const uint32_t n_ranges = (lib->G + HIST_R - 1) / HIST_R;
+    const bool sweeps_pay = n_ranges <= 36u || (n_ranges <= (uint32_t)PART_MAX_NR && tally_mode != 2 &&
+                                                kernel_writes_records(lib, d_reads, o_in, n, max_mm, algo));
     const bool use_lds = want_tally && aligned16(o_in.best_idx) &&
                          (tally_mode >= 2 || (tally_mode == 0 && n >= 4ull * lib->G && sweeps_pay));
     const uint64_t CH = 1ull << 31;  // reads per launch: 32-bit tile numbers and offsets stay far from wrapping
@@ -1871,7 +1905,7 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
             o.counts = nullptr; o.first_seen = nullptr;
             if (tally_mode != 2 && part_geometry(lib->G, o.part)) {
                 o.part.n_tiles = (uint32_t)((m + 255) >> 8);
-                int rc = tally_workspace(lib, st, o.part.n_tiles, o.part.nr, &w);
+                int rc = tally_workspace(lib, st, o.part.n_tiles, o.part.nr, o.part.cap_log2, &w);
                 if (rc != BC_OK) return rc;
                 o.part.rec = w->rec; o.part.ovf_flag = w->ovf_list;
             }
@@ -1947,21 +1981,9 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
         const SlabParams& hp = lib->slab[max_mm];
         const int nseg = hp.nseg;
         const bool wide = lib->slab_wide[max_mm];
-        const bool vec_ok = aligned16(d_reads) && aligned16(o.best_idx) && n >= 4 &&
-                            (!o.best_dist || (((uintptr_t)o.best_dist) & 3u) == 0) &&
-                            (!o.n_best || (((uintptr_t)o.n_best) & 3u) == 0);
-        // table-0/1 slabs of 64 bytes (8 narrow entries) or 128 bytes (16 narrow entries: buckets above 16 guides; or
-        // 8 wide entries): one or two 16-byte pieces per lane
-        const int nq01 = (int)(((wide ? 16u : 8u) << hp.t[0].log2S) / 64u);
-        bool wave_ok = algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && max_mm >= 1 && vec_ok && !lib->knobs.single_slab &&
-                       lib->knobs.lane && (nseg == 2 || nseg == 3) && hp.t[0].log2S == hp.t[1].log2S &&
-                       (nq01 == 1 || nq01 == 2) && !lib->h_nn.empty();
-        for (int t = 0; t < nseg && wave_ok; ++t) wave_ok = hp.t[t].empty < (1u << 22);  // slab numbers travel in 22-bit item fields
-        // narrow 128-byte slabs: measured against the quad kernels, 1e8 reads, d <= 2: 5e5 20-mers (30 per bucket) 14.7 vs
-        // 13.1 G reads/s, 1e6 (61 per bucket) 6.1 vs 7.1, 2e4 12-mers (rest of 8 bases: ties everywhere) 9.6 vs 11.0
-        if (wave_ok && !wide && nq01 == 2 && (lib->k < 16 || (double)lib->G / (double)(1u << (2 * hp.t[0].slen)) > 40.0)) wave_ok = false;
-        const int nq2 = nseg == 3 ? (int)(((wide ? 16u : 8u) << hp.t[2].log2S) / 64u) : nq01;  // pieces per lane, table 2
-        if (wave_ok && nseg == 3 && (nq2 > 4 || (nq01 == 2 && nq2 < 2))) wave_ok = false;
+        const bool vec_ok = vector_io_ok(d_reads, o, n);
+        int nq01 = 1, nq2 = 1;
+        const bool wave_ok = wave_kernel_serves(lib, max_mm, algo, vec_ok, &nq01, &nq2);
         if (algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && (!wide || wave_ok)) {
             const SlabParams* dp = lib->d_slab[max_mm];
             if (max_mm >= 1 && vec_ok && !lib->knobs.single_slab) {
@@ -2263,7 +2285,7 @@ int bc_lib_destroy(bc_lib* lib) {
     for (void* p : lib->owned) (void)hipFree(p);
     for (auto& w : lib->ws)
         for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile, (void*)w.c_idx, (void*)w.c_reads,
-                        (void*)w.c_best, (void*)w.c_dist, (void*)w.c_nb, (void*)w.c_count}) if (p) (void)hipFree(p);
+                        (void*)w.c_count}) if (p) (void)hipFree(p);
     if (lib->host_slots) {
         HostSlot* hs = (HostSlot*)lib->host_slots;
         for (int w = 0; w < 3; ++w) {
@@ -2273,6 +2295,21 @@ int bc_lib_destroy(bc_lib* lib) {
         delete[] hs;
     }
     delete lib;
+    return BC_OK;
+}
+
+int bc_lib_release_stream(bc_lib* lib, void* stream) {
+    if (!lib) { set_error("bc_lib_release_stream: null"); return BC_EINVAL; }
+    std::lock_guard<std::mutex> g(lib->ws_mutex);
+    for (auto it = lib->ws.begin(); it != lib->ws.end(); ++it) {
+        if (it->stream != stream) continue;
+        BC_HIP(hipSetDevice(lib->device));
+        BC_HIP(hipStreamSynchronize((hipStream_t)stream));  // nothing of this stream may still use the buffers
+        for (void* p : {(void*)it->rec, (void*)it->ovf_list, (void*)it->ovf_count, (void*)it->first_tile, (void*)it->c_idx,
+                        (void*)it->c_reads, (void*)it->c_count}) if (p) (void)hipFree(p);
+        lib->ws.erase(it);
+        break;
+    }
     return BC_OK;
 }
 
@@ -2541,6 +2578,7 @@ int bc_multi_gpu_match(bc_multi* m, const uint64_t* h_reads, const uint8_t* h_fl
                                        first_index_base + a);
                 if (rc != BC_OK) return rc;
             }
+            // (null stream: match_host_chunks has synchronised the device, so every slot stream's tallies are in d_c)
             hipLaunchKernelGGL(k_widen_counts, dim3((G + 255) / 256), dim3(256), 0, 0, (const uint32_t*)d_c[i].p,
                                (uint64_t*)d_c64[i].p, G);
             BC_HIP(hipGetLastError());
@@ -2563,13 +2601,16 @@ int bc_multi_gpu_match(bc_multi* m, const uint64_t* h_reads, const uint8_t* h_fl
     if (!m->comms.empty()) {
         // one all-reduce of each vector over RCCL / xGMI; every device ends with the job-wide result
         int r = g_rccl.GroupStart();
-        for (int i = 0; i < P && r == 0; ++i) {
-            BC_HIP(hipSetDevice(m->devices[i]));
+        hipError_t dev_err = hipSuccess;
+        for (int i = 0; i < P && r == 0 && dev_err == hipSuccess; ++i) {
+            dev_err = hipSetDevice(m->devices[i]);  // (no return inside the group: it must always be closed)
+            if (dev_err != hipSuccess) break;
             r = g_rccl.AllReduce(d_c64[i].p, d_c64[i].p, G, NCCL_UINT64, NCCL_SUM, m->comms[i], 0);
             if (r == 0) r = g_rccl.AllReduce(d_fs[i].p, d_fs[i].p, G, NCCL_UINT64, NCCL_MIN, m->comms[i], 0);
         }
         const int r2 = g_rccl.GroupEnd();
         if (r == 0) r = r2;
+        if (dev_err != hipSuccess) { set_error("bc_multi_gpu_match: hipSetDevice: %s", hipGetErrorString(dev_err)); return BC_EHIP; }
         if (r != 0) { set_error("ncclAllReduce: %s", g_rccl.GetErrorString(r)); return BC_EHIP; }
         for (int i = 0; i < P; ++i) {
             BC_HIP(hipSetDevice(m->devices[i]));

@@ -9,15 +9,18 @@
 namespace bc {
 
 // Tally records (K5', see k_hist_part): while a tile of 256 results is still on chip, the matcher writes, for each
-// of the NR guide ranges the tally kernel owns in LDS, one 128-byte line of up to 64 two-byte records (guide index
-// inside the range, 0xFFFF = empty) to rec[range][tile][64].  The tally then streams every range's records ONCE
-// (2.5 B per read in all at NR = 5) instead of sweeping best_idx once per range (4 B per read and range).
-// A tile with more than 64 hits in one range writes empty lines and raises its overflow flag; the tally takes such
-// tiles from best_idx.
-constexpr int PART_CAP = 64;        // records per range and tile: one 128-byte line
-constexpr int PART_MAX_NR = 8;      // ranges the staging area of a wave holds (512 two-byte records)
+// of the NR guide ranges the tally kernel owns in LDS, one line of up to `cap` two-byte records (guide index inside
+// the range, 0xFFFF = empty) to rec[range][tile][cap].  The tally then streams every range's records ONCE instead of
+// sweeping best_idx once per range (4 B per read and range).  The line shrinks as the ranges multiply — a tile's 256
+// results spread over more lines — so that the records stay a few bytes per read: 64 records (128 B) up to 16
+// ranges, 32 up to 32 ranges, 16 up to 64 ranges (1.3e6 guides): 2.5 B per read at five ranges, 8 at 16, 4 at 32,
+// 8 at 64.  A tile with more hits in one range than a line holds writes empty lines and raises its overflow flag;
+// the tally takes such tiles from best_idx.  (Round 2 had one line size, 64, and records for 5..8 ranges only:
+// libraries of 1.7e5 ... 1e6 guides fell back to one sweep of best_idx per range, 0.4 ... 2.3 ms per 1e8 reads.)
+constexpr int PART_MAX_NR = 64;      // ranges
+constexpr int PART_SLOTS = 1024;     // two-byte slots of a wave's staging area (2 KiB): nr * cap <= PART_SLOTS
 struct PartOut {
-    uint16_t* rec;        // [nr][n_tiles][PART_CAP]; NULL = no records wanted
+    uint16_t* rec;        // [nr][n_tiles][cap]; NULL = no records wanted
     uint32_t* ovf_flag;   // [n_tiles] 1: the tile's records did not fit (its lines are empty), 0: they did; written for
                           // every tile (no shared append counter: one took ~90 appends per microsecond, 4 ms when every
                           // tile overflowed)
@@ -25,6 +28,7 @@ struct PartOut {
     uint32_t nr;          // ranges
     uint32_t R;           // guides per range (<= HIST_R)
     uint32_t magic;       // range of guide g = umulhi(g, magic) (exact for g < G, checked on the host)
+    uint32_t cap_log2;    // log2 of the records per line: 6, 5 or 4
 };
 
 struct MatchOut {
@@ -47,6 +51,8 @@ int launch_quad_slab(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uin
 int build_pair_index(bc_lib* lib);
 int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o,
                  hipStream_t st);
+int launch_pairs_list(bc_lib* lib, int max_mm, const uint64_t* c_reads, const uint32_t* c_idx, const uint32_t* c_count,
+                      uint64_t n_max, int32_t* best_idx, uint8_t* best_dist, uint8_t* n_best, hipStream_t st);
 
 }  // namespace bc
 
@@ -63,12 +69,16 @@ __device__ __forceinline__ void load_reads4(const uint64_t* p, uint64_t (&r)[4])
     r[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); r[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
 }
 
-// One wave, one tile of 256 consecutive results (4 per lane): stage the tally records in LDS (stage: PART_MAX_NR *
-// PART_CAP two-byte slots, cnt: PART_MAX_NR counters; both private to the wave) and store them as whole lines.
+// One wave, one tile of 256 consecutive results (4 per lane): stage the tally records in LDS (stage: PART_SLOTS
+// two-byte slots, cnt: PART_MAX_NR counters; both private to the wave) and store them as whole lines.
 __device__ __forceinline__ void part_emit(const PartOut& P, uint32_t tile, const int32_t (&idx)[4], uint32_t lane,
                                           uint16_t* stage, uint32_t* cnt) {
-    // empty staging area: 512 slots = 256 dwords, four per lane; counters
-    reinterpret_cast<uint4*>(stage)[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    const uint32_t cap = 1u << P.cap_log2, used = P.nr << P.cap_log2;  // slots in use (<= PART_SLOTS)
+    // empty staging area: 16 slots (32 bytes) per lane and step; counters
+    for (uint32_t b = lane * 16u; b < used; b += 64u * 16u) {
+        reinterpret_cast<uint4*>(stage + b)[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        reinterpret_cast<uint4*>(stage + b)[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
     if (lane < (uint32_t)PART_MAX_NR) cnt[lane] = 0u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -77,24 +87,23 @@ __device__ __forceinline__ void part_emit(const PartOut& P, uint32_t tile, const
             const uint32_t g = (uint32_t)idx[j];
             const uint32_t p = __umulhi(g, P.magic);
             const uint32_t slot = atomicAdd(&cnt[p], 1u);
-            if (slot < (uint32_t)PART_CAP) stage[p * PART_CAP + slot] = (uint16_t)(g - p * P.R);
+            if (slot < cap) stage[(p << P.cap_log2) + slot] = (uint16_t)(g - p * P.R);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const uint32_t c = lane < P.nr ? cnt[lane] : 0u;
-    const bool ovf = __ballot(c > (uint32_t)PART_CAP) != 0ull;
+    const bool ovf = __ballot(c > cap) != 0ull;
     if (lane == 0) P.ovf_flag[tile] = ovf ? 1u : 0u;
-    // lines out: lane l stores dword (l & 31) of range r + (l >> 5): two ranges (256 staged bytes, read in lane
-    // order) per store instruction; the upper half-wave's line lies one range stride (< 2^31 bytes) further on
+    // lines out, one dword per lane and step: dword d of the staging area belongs to range d / (cap / 2); a range's
+    // lines lie one stride (< 2^31 bytes) apart, a tile's line at tile * cap * 2 bytes inside it
     const uint32_t* sw = reinterpret_cast<const uint32_t*>(stage);
-    const uint32_t stride = P.n_tiles * (uint32_t)(PART_CAP * sizeof(uint16_t));  // bytes between two ranges' lines of a tile
-    const uint32_t lane_off = (lane & 31u) * 4u + (lane >> 5) * stride;
-    const char* line0 = reinterpret_cast<const char*>(P.rec) + (size_t)tile * (PART_CAP * sizeof(uint16_t));
-    for (uint32_t r = 0; r < P.nr; r += 2) {
-        if (r + (lane >> 5) < P.nr) {
-            const uint32_t v = ovf ? 0xFFFFFFFFu : sw[r * (PART_CAP / 2) + lane];
-            __builtin_nontemporal_store(v, (uint32_t*)(line0 + (size_t)r * stride + lane_off));
-        }
+    const uint32_t stride = P.n_tiles << (P.cap_log2 + 1u);  // bytes between two ranges' lines of a tile
+    const uint32_t dw_log2 = P.cap_log2 - 1u;                // dwords per line
+    char* line0 = reinterpret_cast<char*>(P.rec) + ((size_t)tile << (P.cap_log2 + 1u));
+    for (uint32_t d = lane; d < (used >> 1); d += 64u) {
+        const uint32_t r = d >> dw_log2, within = d & ((1u << dw_log2) - 1u);
+        const uint32_t v = ovf ? 0xFFFFFFFFu : sw[d];
+        __builtin_nontemporal_store(v, (uint32_t*)(line0 + (size_t)r * stride + within * 4u));
     }
 }
 

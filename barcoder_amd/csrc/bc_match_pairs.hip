@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "bc_match_dev.h"
@@ -94,6 +95,93 @@ __global__ __launch_bounds__(BLOCK) void k_match_pairs(const PairParams* __restr
     else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0u);
 }
 
+// Second stage of the d = 3 cascade, one DPP quad per read.  The reads the d <= 2 pass left without a hit sit
+// compacted in c_reads with their positions in c_idx; their number is a DEVICE value (*c_count), read here, so the
+// host neither waits for it nor sizes the grid by it: the grid is capped and strides over the list.  Lane s of a quad
+// fetches quarter s of a 64-byte slab (one vector-L1 access per slab where the lane-per-read form made four), all ten
+// tables' primary slabs are requested before any is looked at (ten requests in flight per read), chains are followed
+// afterwards.  Results go straight to best_idx / best_dist / n_best at the read's position: no intermediate result
+// arrays, no scatter pass.
+typedef const u32x4 __attribute__((address_space(1)))* pq_t;
+__device__ __forceinline__ uint4 pairs_load16(const uint2* slabs, uint32_t slab, int s) {
+    const u32x4 t = *(pq_t)(uintptr_t)(reinterpret_cast<const char*>(slabs) + ((size_t)slab << 6) + (size_t)s * 16u);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+struct PairBest { uint32_t mind, cnt, bidx; };
+__device__ __forceinline__ void pairs_scan(const PairTable& T, const uint4& w, uint32_t rest, uint32_t max_mm, PairBest& b) {
+    const uint32_t er[2] = {w.x, w.z}, eg[2] = {w.y, w.w};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t x = rest ^ er[e];
+        const uint32_t mm = (x | (x >> 16)) & 0xFFFFu;
+        const uint32_t d = (uint32_t)__popc(mm);
+        // counted here only if this table's pair is the first pair of the guide's clean pieces (see k_match_pairs);
+        // link / empty slots carry an index word >= SLAB_LINK
+        bool ok = eg[e] < SLAB_LINK && d <= max_mm && (mm & T.must_clean) == 0u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ok = ok && (c >= (int)T.n_other || (mm & T.other[c]) != 0u);
+        if (ok) {
+            if (d < b.mind) { b.mind = d; b.cnt = 1u; b.bidx = eg[e]; }
+            else if (d == b.mind) { ++b.cnt; b.bidx = min(b.bidx, eg[e]); }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_match_pairs_quad(const PairParams* __restrict__ ppp, const uint64_t* __restrict__ c_reads,
+                                                           const uint32_t* __restrict__ c_idx, const uint32_t* __restrict__ c_count,
+                                                           uint64_t kmask, int max_mm_, int32_t* __restrict__ best_idx,
+                                                           uint8_t* __restrict__ best_dist, uint8_t* __restrict__ n_best) {
+    const PairParams& pp = *ppp;
+    const uint32_t n = *c_count;
+    const uint32_t max_mm = (uint32_t)max_mm_;
+    const int s = (int)(threadIdx.x & 3u);
+    const uint32_t q_per_grid = gridDim.x * (BLOCK / 4);
+    // wave-uniform bound: every lane of a wave keeps taking part in the quad exchanges
+    for (uint32_t j0 = blockIdx.x * (BLOCK / 4) + ((threadIdx.x & ~63u) >> 2); j0 < n; j0 += q_per_grid) {
+        const uint32_t j = j0 + ((threadIdx.x & 63u) >> 2);
+        const bool act = j < n;
+        const uint64_t r = act ? (c_reads[j] & kmask) : 0ull;
+        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
+        uint4 w[10];
+        uint32_t rest[10];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const PairTable& T = pp.t[t];
+            rest[t] = pair_rest_plane(T, rlo) | (pair_rest_plane(T, rhi) << 16);
+            w[t] = pairs_load16(T.slabs, act ? pair_bucket(T, rlo, rhi) : 0u, s);
+        }
+        PairBest b{0xFFu, 0u, 0xFFFFFFFFu};
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const PairTable& T = pp.t[t];
+            pairs_scan(T, w[t], rest[t], max_mm, b);
+            // lane 3's second entry is the link-or-empty slot
+            uint32_t lw = quad_perm<0xFF>(w[t].w), lz = quad_perm<0xFF>(w[t].z);
+            uint32_t nxt = (act && lw == SLAB_LINK) ? lz : 0u;
+            while (nxt) {  // quad-uniform
+                const uint4 v = pairs_load16(T.slabs, nxt, s);
+                pairs_scan(T, v, rest[t], max_mm, b);
+                lw = quad_perm<0xFF>(v.w); lz = quad_perm<0xFF>(v.z);
+                nxt = (lw == SLAB_LINK) ? lz : 0u;
+            }
+        }
+        // quad reduction: smallest distance; among those the tie count summed and the lowest index
+        uint32_t md = min(b.mind, quad_perm<0xB1>(b.mind));
+        md = min(md, quad_perm<0x4E>(md));
+        uint32_t c = b.mind == md ? b.cnt : 0u, g = b.mind == md ? b.bidx : 0xFFFFFFFFu;
+        c += quad_perm<0xB1>(c); c += quad_perm<0x4E>(c);
+        g = min(g, quad_perm<0xB1>(g)); g = min(g, quad_perm<0x4E>(g));
+        if (act && s == 0) {
+            const uint32_t i = c_idx[j];
+            const bool hit = md <= max_mm;
+            best_idx[i] = hit ? (int32_t)(g & SLAB_GIDX_MASK) : BC_IDX_MISS;
+            if (best_dist) best_dist[i] = hit ? (uint8_t)md : (uint8_t)BC_DIST_NONE;
+            if (n_best) n_best[i] = hit ? (uint8_t)(c > 255u ? 255u : c) : (uint8_t)0;
+        }
+    }
+}
+
 template <typename T>
 int upload(bc_lib* lib, const std::vector<T>& h, T** d) {
     void* p = nullptr;
@@ -120,61 +208,77 @@ int build_pair_index(bc_lib* lib) {
     while (want < 9 && ((double)lib->G / (double)(1ull << (2 * want))) > 8.0) ++want;
     want = std::max(want, k - 16);
     if (want > 9) return BC_OK;
+    // the ten tables are independent: one host thread each (50 ms single-threaded at 1e5 guides)
+    struct Built { PairTable T{}; std::vector<uint2> slabs; bool ok = false; };
+    Built built[10];
+    int pa[10], pb[10], nt = 0;
+    for (int a = 0; a < 5; ++a)
+        for (int b = a + 1; b < 5; ++b) { pa[nt] = a; pb[nt] = b; ++nt; }
+    auto build_one = [&](int t) {
+        const int a = pa[t], b = pb[t];
+        PairTable T{};
+        const int la = std::min(p_len[a], (want + 1) / 2 + std::max(0, (want / 2) - p_len[b]));
+        const int lb = std::min(p_len[b], want - la);
+        if (la < 1 || lb < 1 || k - la - lb > 16) return;
+        T.a_start = (uint32_t)p_start[a]; T.a_len = (uint32_t)la;
+        T.b_start = (uint32_t)p_start[b]; T.b_len = (uint32_t)lb;
+        auto rest_mask = [&](int start, int len) {  // bases [start, start + len) in rest coordinates
+            const uint32_t m = len >= 32 ? 0xFFFFFFFFu : (((1u << len) - 1u) << start);
+            return pair_rest_plane(T, m);
+        };
+        T.must_clean = rest_mask(p_start[a] + la, p_len[a] - la) | rest_mask(p_start[b] + lb, p_len[b] - lb);
+        T.n_other = 0;
+        for (int c = 0; c < b; ++c)
+            if (c != a) T.other[T.n_other++] = rest_mask(p_start[c], p_len[c]);
+        // slabs of 7 entries + link, bucket = slab number, overflow slabs appended
+        const uint32_t nb = 1u << (2 * (la + lb));
+        std::vector<uint32_t> cnt(nb + 1, 0u);
+        std::vector<uint32_t> bucket_of(lib->G);
+        for (uint32_t g = 0; g < lib->G; ++g) {
+            const uint64_t v = lib->h_guides[g];
+            bucket_of[g] = pair_bucket(T, (uint32_t)v, (uint32_t)(v >> 32));
+            ++cnt[bucket_of[g] + 1];
+        }
+        for (uint32_t i = 0; i < nb; ++i) cnt[i + 1] += cnt[i];
+        std::vector<uint32_t> order(lib->G), fill(cnt.begin(), cnt.end() - 1);
+        for (uint32_t g = 0; g < lib->G; ++g) order[fill[bucket_of[g]]++] = g;  // ascending guide index inside a bucket
+        std::vector<uint2>& slabs = built[t].slabs;
+        slabs.assign((size_t)nb * 8, make_uint2(0u, SLAB_EMPTY));
+        for (uint32_t bkt = 0; bkt < nb; ++bkt) {
+            size_t cur = bkt;
+            uint32_t pos = 0;
+            for (uint32_t j = cnt[bkt]; j < cnt[bkt + 1]; ++j) {
+                if (pos == 7) {
+                    const size_t nxt = slabs.size() / 8;
+                    slabs.resize(slabs.size() + 8, make_uint2(0u, SLAB_EMPTY));
+                    slabs[cur * 8 + 7] = make_uint2((uint32_t)nxt, SLAB_LINK);
+                    cur = nxt;
+                    pos = 0;
+                }
+                const uint32_t g = order[j];
+                const uint64_t v = lib->h_guides[g];
+                slabs[cur * 8 + pos++] =
+                    make_uint2(pair_rest_plane(T, (uint32_t)v) | (pair_rest_plane(T, (uint32_t)(v >> 32)) << 16), g);
+            }
+        }
+        if ((slabs.size() / 8) >> 31) return;
+        built[t].T = T;
+        built[t].ok = true;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < 10; ++t) th.emplace_back(build_one, t);
+        for (auto& x : th) x.join();
+    }
     PairParams pp{};
     pp.ntab = 0;
-    for (int a = 0; a < 5; ++a) {
-        for (int b = a + 1; b < 5; ++b) {
-            PairTable T{};
-            const int la = std::min(p_len[a], (want + 1) / 2 + std::max(0, (want / 2) - p_len[b]));
-            const int lb = std::min(p_len[b], want - la);
-            if (la < 1 || lb < 1 || k - la - lb > 16) return BC_OK;
-            T.a_start = (uint32_t)p_start[a]; T.a_len = (uint32_t)la;
-            T.b_start = (uint32_t)p_start[b]; T.b_len = (uint32_t)lb;
-            auto rest_mask = [&](int start, int len) {  // bases [start, start + len) in rest coordinates
-                const uint32_t m = len >= 32 ? 0xFFFFFFFFu : (((1u << len) - 1u) << start);
-                return pair_rest_plane(T, m);
-            };
-            T.must_clean = rest_mask(p_start[a] + la, p_len[a] - la) | rest_mask(p_start[b] + lb, p_len[b] - lb);
-            T.n_other = 0;
-            for (int c = 0; c < b; ++c)
-                if (c != a) T.other[T.n_other++] = rest_mask(p_start[c], p_len[c]);
-            // slabs of 7 entries + link, bucket = slab number, overflow slabs appended
-            const uint32_t nb = 1u << (2 * (la + lb));
-            std::vector<uint32_t> cnt(nb + 1, 0u);
-            std::vector<uint32_t> bucket_of(lib->G);
-            for (uint32_t g = 0; g < lib->G; ++g) {
-                const uint64_t v = lib->h_guides[g];
-                bucket_of[g] = pair_bucket(T, (uint32_t)v, (uint32_t)(v >> 32));
-                ++cnt[bucket_of[g] + 1];
-            }
-            for (uint32_t i = 0; i < nb; ++i) cnt[i + 1] += cnt[i];
-            std::vector<uint32_t> order(lib->G), fill(cnt.begin(), cnt.end() - 1);
-            for (uint32_t g = 0; g < lib->G; ++g) order[fill[bucket_of[g]]++] = g;  // ascending guide index inside a bucket
-            std::vector<uint2> slabs((size_t)nb * 8, make_uint2(0u, SLAB_EMPTY));
-            for (uint32_t bkt = 0; bkt < nb; ++bkt) {
-                size_t cur = bkt;
-                uint32_t pos = 0;
-                for (uint32_t j = cnt[bkt]; j < cnt[bkt + 1]; ++j) {
-                    if (pos == 7) {
-                        const size_t nxt = slabs.size() / 8;
-                        slabs.resize(slabs.size() + 8, make_uint2(0u, SLAB_EMPTY));
-                        slabs[cur * 8 + 7] = make_uint2((uint32_t)nxt, SLAB_LINK);
-                        cur = nxt;
-                        pos = 0;
-                    }
-                    const uint32_t g = order[j];
-                    const uint64_t v = lib->h_guides[g];
-                    slabs[cur * 8 + pos++] =
-                        make_uint2(pair_rest_plane(T, (uint32_t)v) | (pair_rest_plane(T, (uint32_t)(v >> 32)) << 16), g);
-                }
-            }
-            if ((slabs.size() / 8) >> 31) return BC_OK;
-            uint2* d_slabs;
-            int rc = upload(lib, slabs, &d_slabs);
-            if (rc != BC_OK) return rc;
-            T.slabs = d_slabs;
-            pp.t[pp.ntab++] = T;
-        }
+    for (int t = 0; t < 10; ++t) {
+        if (!built[t].ok) return BC_OK;  // a geometry the 8-byte entries cannot hold: the four-segment index stays
+        uint2* d_slabs;
+        int rc = upload(lib, built[t].slabs, &d_slabs);
+        if (rc != BC_OK) return rc;
+        built[t].T.slabs = d_slabs;
+        pp.t[pp.ntab++] = built[t].T;
     }
     std::vector<PairParams> one(1, pp);
     PairParams* d_pp;
@@ -192,6 +296,19 @@ int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t
     if (blocks >> 31) { set_error("bc_match: launch too large"); return BC_EINVAL; }
     hipLaunchKernelGGL(k_match_pairs, dim3((unsigned)blocks), dim3(BLOCK), 0, st, lib->d_pairs, d_reads, d_flags, n, lib->k,
                        lib->kmask, max_mm, o);
+    BC_HIP(hipGetLastError());
+    return BC_OK;
+}
+
+// second stage of the cascade over a device-side list (see k_match_pairs_quad): asynchronous, no host-visible count
+int launch_pairs_list(bc_lib* lib, int max_mm, const uint64_t* c_reads, const uint32_t* c_idx, const uint32_t* c_count,
+                      uint64_t n_max, int32_t* best_idx, uint8_t* best_dist, uint8_t* n_best, hipStream_t st) {
+    if (!lib->d_pairs) { set_error("bc_match: no pair index for k = %d", lib->k); return BC_EINVAL; }
+    if (n_max == 0) return BC_OK;
+    const uint64_t want = (n_max + (BLOCK / 4) - 1) / (BLOCK / 4);
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, 8192));  // 32 blocks per CU; the rest by stride
+    hipLaunchKernelGGL(k_match_pairs_quad, dim3(grid), dim3(BLOCK), 0, st, lib->d_pairs, c_reads, c_idx, c_count, lib->kmask,
+                       max_mm, best_idx, best_dist, n_best);
     BC_HIP(hipGetLastError());
     return BC_OK;
 }

@@ -86,9 +86,10 @@ __device__ __forceinline__ uint32_t outside_bits(uint64_t w, uint64_t n_words, u
 
 // mask bit 4 (BC_PAM_ANY_CHAR): the pattern position also accepts a character that is not ACGT — the '.' that
 // targets.py:224 (pam_matches) writes for N, as opposed to the [ATCG] of PAMProcessor.py:31 / design_guides.py:26.
-// One lane = two consecutive words (64 positions): one 16-byte load of bases, one 8-byte load of the invalid bits,
-// 8-byte stores; the word after the pair comes from the next lane (ds_bpermute), only the wave's last lane loads it.
-// Round 2's form (one word per lane, every word loaded twice, 8-byte loads, run-time pattern loop) reached 3.8 TB/s.
+// One lane = four consecutive words (128 positions): every access is a 16-byte vector access (two loads of bases,
+// one of the invalid bits, one store per bitmap); the word after the four comes from the next lane (ds_bpermute),
+// only the wave's last lane loads it.  Round 2's form (one word per lane, every word loaded twice, 8-byte loads,
+// run-time pattern loop) reached 3.8 TB/s at 3.1e9 bp; two words per lane with 8-byte stores 4.4-5.0.
 template <int LEN, bool ANY>
 __global__ __launch_bounds__(BLOCK) void k_pam_scan(const uint64_t* __restrict__ bases,
                                                     const uint32_t* __restrict__ invalid,
@@ -96,56 +97,64 @@ __global__ __launch_bounds__(BLOCK) void k_pam_scan(const uint64_t* __restrict__
                                                     uint32_t* __restrict__ out_fwd,
                                                     uint32_t* __restrict__ out_rev, bool vec) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const uint64_t n_pairs = (n_words + 1) / 2;
+    const uint64_t n_quads = (n_words + 3) / 4;
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     const uint32_t lane = threadIdx.x & 63u;
-    struct Pair { uint32_t lo0, hi0, lo1, hi1, c0, c1; };
+    struct Quad { uint32_t lo[4], hi[4], c[4]; };
     auto fetch = [&](uint64_t t) {
-        const uint64_t w = 2 * t;
-        Pair p{0, 0, 0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (w + 1 < n_words && vec) {
-            const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bases) + t);
-            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(invalid) + t);
-            p.lo0 = b.x; p.hi0 = b.y; p.lo1 = b.z; p.hi1 = b.w; p.c0 = c.x; p.c1 = c.y;
-        } else if (w < n_words) {  // (pointers that are not 16 / 8-byte aligned, or the odd last word)
-            const uint64_t b = bases[w];
-            p.lo0 = (uint32_t)b; p.hi0 = (uint32_t)(b >> 32); p.c0 = invalid[w];
-            if (w + 1 < n_words) { const uint64_t b1 = bases[w + 1]; p.lo1 = (uint32_t)b1; p.hi1 = (uint32_t)(b1 >> 32); p.c1 = invalid[w + 1]; }
+        const uint64_t w = 4 * t;
+        Quad q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { q.lo[j] = 0; q.hi[j] = 0; q.c[j] = 0xFFFFFFFFu; }
+        if (w + 3 < n_words && vec) {
+            const u32x4 b0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bases) + 2 * t);
+            const u32x4 b1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(bases) + 2 * t + 1);
+            const u32x4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(invalid) + t);
+            q.lo[0] = b0.x; q.hi[0] = b0.y; q.lo[1] = b0.z; q.hi[1] = b0.w;
+            q.lo[2] = b1.x; q.hi[2] = b1.y; q.lo[3] = b1.z; q.hi[3] = b1.w;
+            q.c[0] = c.x; q.c[1] = c.y; q.c[2] = c.z; q.c[3] = c.w;
+        } else {  // (pointers that are not 16-byte aligned, or the ragged last quad)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w + j < n_words) { const uint64_t b = bases[w + j]; q.lo[j] = (uint32_t)b; q.hi[j] = (uint32_t)(b >> 32); q.c[j] = invalid[w + j]; }
         }
-        return p;
+        return q;
     };
-    auto finish = [&](uint64_t t, Pair p) {
-        const uint64_t w = 2 * t;
-        // the word after the pair: the next lane's first word
-        uint32_t lo2 = (uint32_t)__shfl_down((int)p.lo0, 1), hi2 = (uint32_t)__shfl_down((int)p.hi0, 1), c2 = (uint32_t)__shfl_down((int)p.c0, 1);
+    auto finish = [&](uint64_t t, Quad q) {
+        const uint64_t w = 4 * t;
+        // the word after the four: the next lane's first word
+        uint32_t lo4 = (uint32_t)__shfl_down((int)q.lo[0], 1), hi4 = (uint32_t)__shfl_down((int)q.hi[0], 1), c4 = (uint32_t)__shfl_down((int)q.c[0], 1);
         if (lane == 63u) {
-            lo2 = 0; hi2 = 0; c2 = 0xFFFFFFFFu;
-            if (w + 2 < n_words) { const uint64_t b = bases[w + 2]; lo2 = (uint32_t)b; hi2 = (uint32_t)(b >> 32); c2 = invalid[w + 2]; }
+            lo4 = 0; hi4 = 0; c4 = 0xFFFFFFFFu;
+            if (w + 4 < n_words) { const uint64_t b = bases[w + 4]; lo4 = (uint32_t)b; hi4 = (uint32_t)(b >> 32); c4 = invalid[w + 4]; }
         }
         // positions past total_len never match, whatever the caller left in the invalid bits there
-        const uint32_t o0 = outside_bits(w, n_words, total_len), o1 = outside_bits(w + 1, n_words, total_len),
-                       o2 = outside_bits(w + 2, n_words, total_len);
-        p.c0 |= o0; p.c1 |= o1; c2 |= o2;
-        uint32_t f0, r0, f1, r1;
-        pam_eval<LEN, ANY>(pp, p.lo0, p.hi0, p.c0, o0, p.lo1, p.hi1, p.c1, o1, f0, r0);
-        pam_eval<LEN, ANY>(pp, p.lo1, p.hi1, p.c1, o1, lo2, hi2, c2, o2, f1, r1);
-        if (w + 1 < n_words && vec) {
-            __builtin_nontemporal_store(u32x2{f0, f1}, reinterpret_cast<u32x2*>(out_fwd) + t);
-            __builtin_nontemporal_store(u32x2{r0, r1}, reinterpret_cast<u32x2*>(out_rev) + t);
-        } else if (w < n_words) {
-            out_fwd[w] = f0;
-            out_rev[w] = r0;
-            if (w + 1 < n_words) { out_fwd[w + 1] = f1; out_rev[w + 1] = r1; }
+        uint32_t o[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) o[j] = outside_bits(w + j, n_words, total_len);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q.c[j] |= o[j];
+        c4 |= o[4];
+        uint32_t f[4], r[4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pam_eval<LEN, ANY>(pp, q.lo[j], q.hi[j], q.c[j], o[j], q.lo[j + 1], q.hi[j + 1], q.c[j + 1], o[j + 1], f[j], r[j]);
+        pam_eval<LEN, ANY>(pp, q.lo[3], q.hi[3], q.c[3], o[3], lo4, hi4, c4, o[4], f[3], r[3]);
+        if (w + 3 < n_words && vec) {
+            __builtin_nontemporal_store(u32x4{f[0], f[1], f[2], f[3]}, reinterpret_cast<u32x4*>(out_fwd) + t);
+            __builtin_nontemporal_store(u32x4{r[0], r[1], r[2], r[3]}, reinterpret_cast<u32x4*>(out_rev) + t);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w + j < n_words) { out_fwd[w + j] = f[j]; out_rev[w + j] = r[j]; }
         }
     };
-    // wave-uniform loop bounds (every lane of a wave takes part in the exchange); four tiles' loads in flight per lane
+    // wave-uniform loop bounds (every lane of a wave takes part in the exchange); two tiles' loads in flight per lane
     uint64_t t0 = (uint64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u);
-    for (; t0 + 3 * stride < n_pairs; t0 += 4 * stride) {
-        const Pair a = fetch(t0 + lane), b = fetch(t0 + stride + lane), c = fetch(t0 + 2 * stride + lane), d = fetch(t0 + 3 * stride + lane);
-        finish(t0 + lane, a); finish(t0 + stride + lane, b); finish(t0 + 2 * stride + lane, c); finish(t0 + 3 * stride + lane, d);
+    for (; t0 + stride < n_quads; t0 += 2 * stride) {
+        const Quad a = fetch(t0 + lane), b = fetch(t0 + stride + lane);
+        finish(t0 + lane, a); finish(t0 + stride + lane, b);
     }
-    for (; t0 < n_pairs; t0 += stride) finish(t0 + lane, fetch(t0 + lane));
+    for (; t0 < n_quads; t0 += stride) finish(t0 + lane, fetch(t0 + lane));
 }
 
 // ---- bitmap -> ascending position list: popcount, scan, expand ---------------
@@ -454,10 +463,10 @@ bool pam_has_any(const PamParams& pp) {
 // pattern lengths 2..8 are compiled with the position loop unrolled; others take the run-time loop
 int launch_pam_scan(const uint64_t* d_bases, const uint32_t* d_invalid, uint64_t total_len, uint64_t n_words,
                     const PamParams& pp, uint32_t* d_fwd, uint32_t* d_rev, hipStream_t st) {
-    const bool vec = (((uintptr_t)d_bases) & 15u) == 0 && (((uintptr_t)d_invalid) & 7u) == 0 &&
-                     (((uintptr_t)d_fwd) & 7u) == 0 && (((uintptr_t)d_rev) & 7u) == 0;
+    const bool vec = (((uintptr_t)d_bases) & 15u) == 0 && (((uintptr_t)d_invalid) & 15u) == 0 &&
+                     (((uintptr_t)d_fwd) & 15u) == 0 && (((uintptr_t)d_rev) & 15u) == 0;
     const bool any = pam_has_any(pp);
-    const int grid = grid_for((n_words + 1) / 2);
+    const int grid = grid_for((n_words + 3) / 4);
 #define BC_PAM_LAUNCH(LEN_)                                                                                            \
     do {                                                                                                               \
         if (any) hipLaunchKernelGGL((k_pam_scan<LEN_, true>), dim3(grid), dim3(BLOCK), 0, st, d_bases, d_invalid,       \

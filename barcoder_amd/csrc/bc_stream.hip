@@ -522,7 +522,7 @@ int run_file(FileJob& J) {
                 }
             }
             BC_HIP(hipStreamSynchronize(s.st));
-            return BC_OK;
+            return bc_lib_release_stream(J.lib, s.st);  // the stream dies with the slot: its workspace on the library goes first
         };
         const int code = body();
         if (code != BC_OK) fail(code);

@@ -237,7 +237,39 @@ def count_sharded(n_total: int, match_shard, n_guides: int, rank: int, world: in
     else:
         counts = np.zeros(n_guides, np.uint64)
         first_seen = np.full(n_guides, U64_MAX, np.uint64)
-    return reduce_counts(counts, first_seen, device=device, async_op=async_op and not isinstance(counts, np.ndarray))
+    if async_op and isinstance(counts, np.ndarray):  # numpy results (an empty shard) reduce synchronously:
+        c, f = reduce_counts(counts, first_seen, device=device)  # the caller still gets the three values it asked for
+        return c, f, Pending()
+    return reduce_counts(counts, first_seen, device=device, async_op=async_op)
+
+
+def gather_tables(arrays, device=None):
+    """Every rank's tuple of equally long uint64 arrays (an undocumented table: words, counts, first keys) as a list of
+    tuples on every rank: one size exchange, then one all_gather of a padded int64 tensor per array — on the device
+    for RCCL, on the host for gloo — instead of pickling hundreds of MB through all_gather_object."""
+    import torch
+    import torch.distributed as dist
+    arrays = tuple(np.ascontiguousarray(a, np.uint64) for a in arrays)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [arrays]
+    world = dist.get_world_size()
+    dev = "cpu"
+    if device is not None and _group_backend() == "nccl":
+        dev = torch.device("cuda", device) if isinstance(device, int) else device
+    n = arrays[0].size
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
+    sizes = [int(t.item()) for t in sizes]
+    cap = max(max(sizes), 1)
+    cols = []
+    for a in arrays:
+        mine = torch.zeros(cap, dtype=torch.int64, device=dev)
+        if n:
+            mine[:n] = torch.from_numpy(a.view(np.int64)).to(dev)
+        parts = [torch.empty(cap, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        cols.append([p[:m].cpu().numpy().view(np.uint64) for p, m in zip(parts, sizes)])
+    return [tuple(col[r] for col in cols) for r in range(world)]
 
 
 def shutdown():

@@ -737,10 +737,9 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     total_reads = int(counts[G])
     counts, first_seen = counts[:G], first_seen[:G]
     mine_u = merge_undocumented(undoc_tables)
-    if world > 1:  # variable-length leftovers: undocumented windows and odd (string) events of every rank
-        parts = D.gather_objects((mine_u, odd_events))
-        mine_u = merge_undocumented([p[0] for p in parts])
-        odd_events = [e for p in parts for e in p[1]]
+    if world > 1:  # variable-length leftovers: undocumented windows (padded tensors) and the few odd string events
+        mine_u = merge_undocumented(D.gather_tables(mine_u, device=device))
+        odd_events = [e for part in D.gather_objects(odd_events) for e in part]
     uw, uc, uf = mine_u
     # documented: first-seen order (heuristicount.py:876-877 prints Counter insertion order)
     doc_events = [(int(f), cc.labels[g], int(c)) for g, c, f in
@@ -798,15 +797,17 @@ def main(args, device: int = 0, rank: int = 0, world: int = 1):
                            max_mismatch=getattr(args, "mismatches", 0), rank=rank, world=world,
                            chunk_reads=getattr(args, "chunk_reads", 1 << 20))
         if rank != 0:
-            return
+            return True
         for line in summary_lines(r, args.fasta_file):
             print(line, file=sys.stderr)
         for barcode, count in r["doc"].items():
             print("\t".join([barcode, str(count)]))
+        return True
     except ValueError as ve:
         log.error("%s", ve)
     except Exception as e:  # noqa: BLE001 - mirrors the reference
         log.error("An unexpected error occurred: %s", e)
+    return False  # (the reference's main returns None either way; the multi-rank launcher needs to know)
 
 
 def _cli():
@@ -836,12 +837,15 @@ def _cli():
             rank, world, local = D.init_from_env()
             if rank != 0:
                 logging.getLogger().setLevel(logging.WARNING)
-            try:
-                with contextlib.redirect_stdout(buf):
-                    main(a, device=local, rank=rank, world=world)
-            finally:
-                D.barrier()
-                D.shutdown()
+            with contextlib.redirect_stdout(buf):
+                ok = main(a, device=local, rank=rank, world=world)
+            if not ok and world > 1:
+                # this rank failed (its error is logged): the others may be waiting in a collective it will never
+                # join — leave without the barrier, non-zero, and launch_workers / torchrun ends the peers
+                sys.stderr.flush()
+                os._exit(1)
+            D.barrier()
+            D.shutdown()
         sys.stdout.write(buf.getvalue())
         sys.stdout.flush()
     else:

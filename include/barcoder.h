@@ -211,6 +211,10 @@ int bc_lib_create(const uint64_t *h_guides, uint32_t n_guides, int k, int device
                   bc_lib **out);
 int bc_lib_destroy(bc_lib *lib);
 int bc_lib_info(const bc_lib *lib, uint32_t *n_guides, int *k, int *device);
+/* A library keeps a small workspace (tally records, d = 3 cascade lists) per stream
+ * that launches on it.  A caller that creates and destroys streams releases a
+ * stream's workspace before destroying the stream (waits for the stream). */
+int bc_lib_release_stream(bc_lib *lib, void *stream);
 /* name of the match kernel the last bc_match_* call on this library launched
  * ("k_match_wq", "k_match_hash", "cascade3:d2+k_match_pairs", "k_match_seed", ...): lets a test assert
  * which path a (k, max_mismatch, library size) combination takes. */
@@ -238,11 +242,14 @@ const char *bc_lib_last_kernel(const bc_lib *lib);
  *                  initialises to UINT64_MAX); gives heuristicount.py:876-877's
  *                  first-seen output order
  *
- * Asynchronous on `stream`, with one exception: max_mismatch = 3 runs as a
- * cascade (the <= 2-mismatch pass over every read, then a pair-of-pieces index
- * for the reads it left, 8 <= k <= 25) and synchronises `stream` once per launch —
- * the second stage is sized by a device-side count.  0 <= max_mismatch < k;
- * the seed algorithms take max_mismatch <= 3.
+ * Asynchronous on `stream` for every budget.  max_mismatch = 3 runs as a cascade
+ * (the <= 2-mismatch pass over every read — kernel k_match_wq — then the
+ * pair-of-pieces index, k_match_pairs_quad, for the reads it left, 8 <= k <= 25):
+ * the number of reads the second stage takes stays on the device, which strides
+ * over the compacted list; the host never waits for it.  (The first launch on a
+ * stream, or one larger than every earlier launch on it, allocates its workspace
+ * and waits for the stream once.)  0 <= max_mismatch < k; the seed algorithms
+ * take max_mismatch <= 3.
  */
 int bc_match_dev(bc_lib *lib, const uint64_t *d_reads, const uint8_t *d_flags, uint64_t n,
                  int max_mismatch, int algo,

@@ -52,6 +52,16 @@ def _worker(rank, world, port, n_total, G, out_dir):
     pend.wait()
     assert np.array_equal(tc.numpy(), np.asarray(counts).astype(np.int64))
     assert np.array_equal(tf.numpy(), np.asarray(first).astype(np.int64))
+    # async_op on numpy results (what an empty shard yields): still three values, nothing pending
+    ac, af, ap = D.count_sharded(n_total, match_shard, G, r, w, async_op=True)
+    assert ap.works == [] and np.array_equal(np.asarray(ac), np.asarray(counts)) and np.array_equal(np.asarray(af), np.asarray(first))
+    # undocumented tables of unequal lengths (one of them empty): padded tensors, every rank sees every rank's table
+    mine = tuple(np.arange(rank * 5, dtype=np.uint64) + np.uint64(j << 60) for j in range(3))
+    got = D.gather_tables(mine)
+    assert len(got) == world
+    for rr in range(world):
+        for j in range(3):
+            assert np.array_equal(got[rr][j], np.arange(rr * 5, dtype=np.uint64) + np.uint64(j << 60))
     np.save(os.path.join(out_dir, f"counts_{rank}.npy"), counts)
     np.save(os.path.join(out_dir, f"first_{rank}.npy"), first)
     dist.barrier()
