@@ -146,11 +146,6 @@ struct TallyWs {
     uint32_t* ovf_count = nullptr; // self-resetting (k_first_refine)
     uint32_t* first_tile = nullptr;  // [G], 0xFFFFFFFF between launches
     uint64_t tiles_cap = 0;
-    // d = 3 cascade: the reads the d <= 2 pass left without a hit, compacted (their results are written in place)
-    uint64_t casc_cap = 0;
-    uint32_t* c_idx = nullptr;     // [casc_cap] position of the read in the launch
-    uint64_t* c_reads = nullptr;   // [casc_cap]
-    uint32_t* c_count = nullptr;   // [4] how many: read by the second stage on the device, never by the host
 };
 
 }  // namespace bc
@@ -180,6 +175,9 @@ struct bc_lib {
     bool pairs_tried = false;                  // under ws_mutex
     std::vector<uint2> fast_stage[4];          // library creation only: regions of SlabParams::fast before upload
     bc::Knobs knobs;
+    // geometry of the record tally (ranges, records per line), fixed by the library size: computed once at creation
+    uint32_t part_nr = 0, part_R = 0, part_magic = 0, part_cap_log2 = 0;
+    bool part_ok = false;
     std::list<bc::TallyWs> ws;     // tally / cascade workspaces by stream (list: pointers stay valid as entries come and go)
     std::mutex ws_mutex;
     std::atomic<const char*> last_kernel{""};  // name of the match kernel launched last (bc_lib_last_kernel)

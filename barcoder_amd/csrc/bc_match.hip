@@ -1656,75 +1656,12 @@ int launch_hist(bc_lib* lib, const MatchOut& o, uint64_t n, hipStream_t st) {
 // ---- d = 3 cascade ---------------------------------------------------------------------------------------------
 // A guide within two substitutions, once found, is the best hit whatever the budget; only reads the d <= 2 pass left
 // without a hit need the 3-mismatch search, whose four 5-base seeds put ~G/1024 guides in every bucket (9.4 G reads/s
-// over all reads at 1e5 guides against 75 for d <= 2).  The missed reads are compacted (order irrelevant: results
-// return by position), searched by the d = 3 kernels, and scattered back.
-constexpr uint64_t COLLECT_CHUNK = 16384;  // reads per workgroup: one global append per chunk (a shared counter takes
-                                           // ~90 appends per microsecond on this part: one per wave cost 17 ms per 1e8 reads)
-// One sweep: a thread holds its 64 results (sixteen 16-byte loads, all in flight) in registers, the block turns the
-// per-thread miss counts into offsets and makes ONE append for the chunk, then every thread writes its misses from
-// the registers.  (Round 2 swept the chunk twice with 4-byte loads, one dependent load per iteration: 0.40 ms per
-// 1e8 reads against the 0.07 ms the bytes take.)
-__global__ __launch_bounds__(BLOCK) void k_collect_missed(const int32_t* __restrict__ best_idx, const uint64_t* __restrict__ reads,
-                                                         uint64_t n, uint32_t* __restrict__ idx, uint64_t* __restrict__ out_reads,
-                                                         uint32_t* __restrict__ count) {
-    __shared__ uint32_t w_cnt[BLOCK / 64];
-    __shared__ uint32_t w_base[BLOCK / 64];
-    constexpr int PER = (int)(COLLECT_CHUNK / BLOCK / 4);  // 16-byte loads per thread
-    const uint64_t c0 = (uint64_t)blockIdx.x * COLLECT_CHUNK;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const u32x4* pv = reinterpret_cast<const u32x4*>(best_idx);  // (the cascade requires a 16-byte aligned best_idx)
-    u32x4 v[PER];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const uint64_t i = c0 + ((uint64_t)q * BLOCK + threadIdx.x) * 4;
-        if (i + 3 < n) {
-            v[q] = pv[i >> 2];
-        } else {  // ragged end: element by element, past the end = a hit (never collected)
-            uint32_t e[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) e[c] = (i + c < n) ? (uint32_t)best_idx[i + c] : 0u;
-            v[q] = u32x4{e[0], e[1], e[2], e[3]};
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < PER; ++q)
-        mine += (v[q].x == (uint32_t)BC_IDX_MISS) + (v[q].y == (uint32_t)BC_IDX_MISS) + (v[q].z == (uint32_t)BC_IDX_MISS) +
-                (v[q].w == (uint32_t)BC_IDX_MISS);
-    // exclusive scan of `mine` over the block
-    uint32_t x = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)x, d);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    if (lane == 63u) w_cnt[wv] = x;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) { w_base[w] = tot; tot += w_cnt[w]; }
-        const uint32_t base = tot ? atomicAdd(count, tot) : 0u;
-        for (int w = 0; w < BLOCK / 64; ++w) w_base[w] += base;
-    }
-    __syncthreads();
-    uint32_t at = w_base[wv] + x - mine;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const uint64_t i = c0 + ((uint64_t)q * BLOCK + threadIdx.x) * 4;
-        const uint32_t e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (e[c] == (uint32_t)BC_IDX_MISS) {
-                idx[at] = (uint32_t)(i + c);
-                out_reads[at] = reads[i + c];
-                ++at;
-            }
-    }
-}
+// over all reads at 1e5 guides against 75 for d <= 2).  The second stage (k_cascade_stage2, bc_match_pairs.hip) finds
+// those reads in best_idx itself and writes its results in place: launch_cascade3 below.
 
 // ---- tally records: geometry and per-stream workspace -------------------------------------------------------
 // ranges: as few as the LDS allows (HIST_R guides each), equal sizes; range(g) = umulhi(g, magic) must be exact
-bool part_geometry(uint32_t G, PartOut& P) {
+bool part_geometry_compute(uint32_t G, PartOut& P) {
     uint32_t nr = (G + HIST_R - 1) / HIST_R;
     // one or two ranges: sweeping best_idx costs no more
     if (nr < 3 || nr > (uint32_t)PART_MAX_NR) return false;
@@ -1733,12 +1670,26 @@ bool part_geometry(uint32_t G, PartOut& P) {
     // (measured at 6e4 / 8e4 guides: 7.2 / 4.7 ms per pass instead of 1.2): at least five ranges (<= 51 expected in 64);
     // 17..32 ranges take 32-record lines (<= 13.6 expected), 33..64 take 16-record lines (<= 7 expected)
     nr = std::max(nr, 5u);
-    const uint32_t R = (G + nr - 1) / nr;
-    const uint32_t magic = (uint32_t)((0x100000000ull + R - 1) / R);
-    for (uint32_t g = 0; g < G; ++g)
-        if ((uint32_t)(((uint64_t)g * magic) >> 32) != g / R) return false;
+    uint32_t R = (G + nr - 1) / nr;
+    uint32_t magic = (uint32_t)((0x100000000ull + R - 1) / R);
+    bool exact = nr <= 8u;  // (beyond ~1.6e5 guides the 32-bit reciprocal of an arbitrary R stops being exact)
+    for (uint32_t g = 0; g < G && exact; ++g) exact = (uint32_t)(((uint64_t)g * magic) >> 32) == g / R;
+    if (!exact) {  // ranges of 2^14 guides: range = g >> 14 = umulhi(g, 2^18), exact for every g
+        R = 16384u;
+        magic = 1u << 18;
+        nr = (G + R - 1) / R;
+        if (nr > (uint32_t)PART_MAX_NR) return false;
+    }
     P.nr = nr; P.R = R; P.magic = magic;
-    P.cap_log2 = nr <= 16u ? 6u : nr <= 32u ? 5u : 4u;
+    // records per line: a line must hold well more than the 230 / nr hits it expects (Poisson tails: 64 for up to 14
+    // ranges, 32 — expecting at most 15.4 — up to 32, 16 — at most 7 — up to 64)
+    P.cap_log2 = nr <= 14u ? 6u : nr <= 32u ? 5u : 4u;
+    return (nr << P.cap_log2) <= (uint32_t)PART_SLOTS;
+}
+
+bool part_geometry(const bc_lib* lib, PartOut& P) {  // the library's cached geometry (bc_lib_create)
+    if (!lib->part_ok) return false;
+    P.nr = lib->part_nr; P.R = lib->part_R; P.magic = lib->part_magic; P.cap_log2 = lib->part_cap_log2;
     return true;
 }
 
@@ -1758,25 +1709,6 @@ static int stream_workspace(bc_lib* lib, hipStream_t st, TallyWs** out) {  // ca
         BC_HIP(hipMalloc((void**)&w->ovf_count, 16));
         BC_HIP(hipMemset(w->first_tile, 0xFF, (size_t)lib->G * 4));
         BC_HIP(hipMemset(w->ovf_count, 0, 16));
-    }
-    *out = w;
-    return BC_OK;
-}
-
-// buffers of the d = 3 cascade for launches of up to n reads on this stream
-int cascade_workspace(bc_lib* lib, hipStream_t st, uint64_t n, TallyWs** out) {
-    std::lock_guard<std::mutex> g(lib->ws_mutex);
-    TallyWs* w = nullptr;
-    int rc = stream_workspace(lib, st, &w);
-    if (rc != BC_OK) return rc;
-    if (!w->c_count) BC_HIP(hipMalloc((void**)&w->c_count, 16));
-    if (n > w->casc_cap) {
-        BC_HIP(hipStreamSynchronize(st));
-        for (void* p : {(void*)w->c_idx, (void*)w->c_reads}) if (p) (void)hipFree(p);
-        w->c_idx = nullptr; w->c_reads = nullptr; w->casc_cap = 0;
-        BC_HIP(hipMalloc((void**)&w->c_idx, (size_t)n * 4));
-        BC_HIP(hipMalloc((void**)&w->c_reads, (size_t)n * 8));
-        w->casc_cap = n;
     }
     *out = w;
     return BC_OK;
@@ -1824,11 +1756,14 @@ int ensure_pair_index(bc_lib* lib) {
     return rc;
 }
 
-// max_mismatch = 3 as a cascade (see k_collect_missed).  Fully asynchronous: the number of reads left for the second
-// stage stays on the device (k_match_pairs_quad reads it and strides over the list), results land in place.
+int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
+                 int max_mm, int algo, const MatchOut& o_in, hipStream_t st);
+
+// max_mismatch = 3 as a cascade.  Fully asynchronous, no workspace: the complete d <= 2 pass (results + its tally,
+// from the wave matcher's records) runs first; the second stage then walks best_idx, takes the reads still marked
+// BC_IDX_MISS through the pair index, writes their results in place and tallies its hits with device atomics.
 int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o_in, hipStream_t st) {
-    const uint64_t CH = 1ull << 27;  // reads per round: bounds the workspace (12 bytes per read)
-    const bool want_tally = o_in.counts || o_in.first_seen;
+    const uint64_t CH = 1ull << 31;  // positions travel as 32-bit values inside the second stage
     for (uint64_t a = 0; a < n; a += CH) {
         const uint64_t m = std::min(CH, n - a);
         MatchOut o = o_in;
@@ -1836,27 +1771,11 @@ int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags
         if (o.best_dist) o.best_dist += a;
         if (o.n_best) o.n_best += a;
         o.base += a;
-        o.counts = nullptr; o.first_seen = nullptr; o.part = PartOut{};
-        TallyWs* w = nullptr;
-        int rc = cascade_workspace(lib, st, m, &w);
+        o.part = PartOut{};
+        int rc = launch_match(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, 2, BC_ALGO_SEED, o, st);
         if (rc != BC_OK) return rc;
-        bool pd = false;
-        uint64_t tb = m;
-        rc = launch_match_kernel(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, 2, BC_ALGO_SEED, o, st, &pd, &tb);
+        rc = launch_cascade_stage2(lib, 3, d_reads + a, m, o, st);
         if (rc != BC_OK) return rc;
-        BC_HIP(hipMemsetAsync(w->c_count, 0, 4, st));
-        const uint64_t blocks = (m + COLLECT_CHUNK - 1) / COLLECT_CHUNK;
-        hipLaunchKernelGGL(k_collect_missed, dim3((unsigned)blocks), dim3(BLOCK), 0, st, o.best_idx, d_reads + a, m, w->c_idx,
-                           w->c_reads, w->c_count);
-        BC_HIP(hipGetLastError());
-        rc = launch_pairs_list(lib, 3, w->c_reads, w->c_idx, w->c_count, m, o.best_idx, o.best_dist, o.n_best, st);
-        if (rc != BC_OK) return rc;
-        if (want_tally) {
-            MatchOut t = o;
-            t.counts = o_in.counts; t.first_seen = o_in.first_seen;
-            rc = launch_hist(lib, t, m, st);
-            if (rc != BC_OK) return rc;
-        }
     }
     note_kernel(lib, "cascade3:d2+k_match_pairs");
     return BC_OK;
@@ -1887,7 +1806,8 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     // more than device-scope atomics on counters that spread (1.6 - 2.2 ms per 1e8 reads at 5e5 - 3e6 guides)
     // (records serve up to PART_MAX_NR = 64 ranges — 1.3e6 guides — when the kernel that runs writes them)
     const uint32_t n_ranges = (lib->G + HIST_R - 1) / HIST_R;
-    const bool sweeps_pay = n_ranges <= 36u || (n_ranges <= (uint32_t)PART_MAX_NR && tally_mode != 2 &&
+    PartOut probe{};
+    const bool sweeps_pay = n_ranges <= 36u || (tally_mode != 2 && part_geometry(lib, probe) &&
                                                 kernel_writes_records(lib, d_reads, o_in, n, max_mm, algo));
     const bool use_lds = want_tally && aligned16(o_in.best_idx) &&
                          (tally_mode >= 2 || (tally_mode == 0 && n >= 4ull * lib->G && sweeps_pay));
@@ -1903,7 +1823,7 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
         TallyWs* w = nullptr;
         if (use_lds) {
             o.counts = nullptr; o.first_seen = nullptr;
-            if (tally_mode != 2 && part_geometry(lib->G, o.part)) {
+            if (tally_mode != 2 && part_geometry(lib, o.part)) {
                 o.part.n_tiles = (uint32_t)((m + 255) >> 8);
                 int rc = tally_workspace(lib, st, o.part.n_tiles, o.part.nr, o.part.cap_log2, &w);
                 if (rc != BC_OK) return rc;
@@ -2267,6 +2187,11 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.host_pin = env_int("BC_HOST_PIN", 1);
     lib->knobs.cascade = env_int("BC_CASCADE", 1);
     lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));
+    {
+        PartOut pg{};
+        lib->part_ok = part_geometry_compute(n_guides, pg);
+        lib->part_nr = pg.nr; lib->part_R = pg.R; lib->part_magic = pg.magic; lib->part_cap_log2 = pg.cap_log2;
+    }
     lib->h_guides.assign(h_guides, h_guides + n_guides);
     int rc = dev_upload(lib, lib->h_guides, &lib->d_guides);
     if (rc == BC_OK) rc = compute_nn(lib);
@@ -2284,8 +2209,7 @@ int bc_lib_destroy(bc_lib* lib) {
     (void)hipDeviceSynchronize();
     for (void* p : lib->owned) (void)hipFree(p);
     for (auto& w : lib->ws)
-        for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile, (void*)w.c_idx, (void*)w.c_reads,
-                        (void*)w.c_count}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile}) if (p) (void)hipFree(p);
     if (lib->host_slots) {
         HostSlot* hs = (HostSlot*)lib->host_slots;
         for (int w = 0; w < 3; ++w) {
@@ -2305,8 +2229,7 @@ int bc_lib_release_stream(bc_lib* lib, void* stream) {
         if (it->stream != stream) continue;
         BC_HIP(hipSetDevice(lib->device));
         BC_HIP(hipStreamSynchronize((hipStream_t)stream));  // nothing of this stream may still use the buffers
-        for (void* p : {(void*)it->rec, (void*)it->ovf_list, (void*)it->ovf_count, (void*)it->first_tile, (void*)it->c_idx,
-                        (void*)it->c_reads, (void*)it->c_count}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)it->rec, (void*)it->ovf_list, (void*)it->ovf_count, (void*)it->first_tile}) if (p) (void)hipFree(p);
         lib->ws.erase(it);
         break;
     }

@@ -51,8 +51,7 @@ int launch_quad_slab(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uin
 int build_pair_index(bc_lib* lib);
 int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o,
                  hipStream_t st);
-int launch_pairs_list(bc_lib* lib, int max_mm, const uint64_t* c_reads, const uint32_t* c_idx, const uint32_t* c_count,
-                      uint64_t n_max, int32_t* best_idx, uint8_t* best_dist, uint8_t* n_best, hipStream_t st);
+int launch_cascade_stage2(bc_lib* lib, int max_mm, const uint64_t* d_reads, uint64_t n, const MatchOut& o, hipStream_t st);
 
 }  // namespace bc
 

@@ -50,20 +50,11 @@ namespace {
 
 using namespace bc;
 
-__global__ __launch_bounds__(BLOCK) void k_match_pairs(const PairParams* __restrict__ ppp, const uint64_t* __restrict__ reads,
-                                                      const uint8_t* __restrict__ flags, uint64_t n, int k, uint64_t kmask,
-                                                      int max_mm, MatchOut o) {
-    const PairParams& pp = *ppp;
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    uint64_t r = reads[i];
-    if (read_skipped(r, flags, i, k)) {
-        emit(o, i, BC_IDX_SKIP, BC_DIST_NONE, 0u);
-        return;
-    }
-    r &= kmask;
-    const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
-    uint32_t mind = 0xFFu, cnt = 0u, bidx = 0xFFFFFFFFu;
+// one read through the ten tables (lane = read): best distance, tie count, lowest index.  Exact for any read and
+// any budget <= 3 (see the header of this file).
+struct PairBest { uint32_t mind, cnt, bidx; };
+__device__ __forceinline__ PairBest pairs_lookup(const PairParams& pp, uint32_t rlo, uint32_t rhi, uint32_t max_mm) {
+    PairBest b{0xFFu, 0u, 0xFFFFFFFFu};
     for (int t = 0; t < pp.ntab; ++t) {
         const PairTable& T = pp.t[t];
         const uint32_t rest = pair_rest_plane(T, rlo) | (pair_rest_plane(T, rhi) << 16);
@@ -80,106 +71,120 @@ __global__ __launch_bounds__(BLOCK) void k_match_pairs(const PairParams* __restr
                 const uint32_t d = (uint32_t)__popc(mm);
                 // counted here only if this table's pair is the first pair of the guide's clean pieces: what is left
                 // of pieces a and b is clean, every earlier piece is dirty
-                bool ok = eg[e] < SLAB_LINK && d <= (uint32_t)max_mm && (mm & T.must_clean) == 0u;
+                bool ok = eg[e] < SLAB_LINK && d <= max_mm && (mm & T.must_clean) == 0u;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) ok = ok && (c >= (int)T.n_other || (mm & T.other[c]) != 0u);
                 if (ok) {
-                    if (d < mind) { mind = d; cnt = 1u; bidx = eg[e]; }
-                    else if (d == mind) { ++cnt; bidx = min(bidx, eg[e]); }
+                    if (d < b.mind) { b.mind = d; b.cnt = 1u; b.bidx = eg[e]; }
+                    else if (d == b.mind) { ++b.cnt; b.bidx = min(b.bidx, eg[e]); }
                 }
             }
             slab = (w3.w == SLAB_LINK) ? w3.z : 0xFFFFFFFFu;  // the last slot: link or empty
         }
     }
-    if (mind <= (uint32_t)max_mm) emit(o, i, (int32_t)(bidx & SLAB_GIDX_MASK), mind, cnt > 255u ? 255u : cnt);
-    else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0u);
+    return b;
 }
 
-// Second stage of the d = 3 cascade, one DPP quad per read.  The reads the d <= 2 pass left without a hit sit
-// compacted in c_reads with their positions in c_idx; their number is a DEVICE value (*c_count), read here, so the
-// host neither waits for it nor sizes the grid by it: the grid is capped and strides over the list.  Lane s of a quad
-// fetches quarter s of a 64-byte slab (one vector-L1 access per slab where the lane-per-read form made four), all ten
-// tables' primary slabs are requested before any is looked at (ten requests in flight per read), chains are followed
-// afterwards.  Results go straight to best_idx / best_dist / n_best at the read's position: no intermediate result
-// arrays, no scatter pass.
-typedef const u32x4 __attribute__((address_space(1)))* pq_t;
-__device__ __forceinline__ uint4 pairs_load16(const uint2* slabs, uint32_t slab, int s) {
-    const u32x4 t = *(pq_t)(uintptr_t)(reinterpret_cast<const char*>(slabs) + ((size_t)slab << 6) + (size_t)s * 16u);
-    return make_uint4(t.x, t.y, t.z, t.w);
-}
-
-struct PairBest { uint32_t mind, cnt, bidx; };
-__device__ __forceinline__ void pairs_scan(const PairTable& T, const uint4& w, uint32_t rest, uint32_t max_mm, PairBest& b) {
-    const uint32_t er[2] = {w.x, w.z}, eg[2] = {w.y, w.w};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const uint32_t x = rest ^ er[e];
-        const uint32_t mm = (x | (x >> 16)) & 0xFFFFu;
-        const uint32_t d = (uint32_t)__popc(mm);
-        // counted here only if this table's pair is the first pair of the guide's clean pieces (see k_match_pairs);
-        // link / empty slots carry an index word >= SLAB_LINK
-        bool ok = eg[e] < SLAB_LINK && d <= max_mm && (mm & T.must_clean) == 0u;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ok = ok && (c >= (int)T.n_other || (mm & T.other[c]) != 0u);
-        if (ok) {
-            if (d < b.mind) { b.mind = d; b.cnt = 1u; b.bidx = eg[e]; }
-            else if (d == b.mind) { ++b.cnt; b.bidx = min(b.bidx, eg[e]); }
-        }
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_match_pairs_quad(const PairParams* __restrict__ ppp, const uint64_t* __restrict__ c_reads,
-                                                           const uint32_t* __restrict__ c_idx, const uint32_t* __restrict__ c_count,
-                                                           uint64_t kmask, int max_mm_, int32_t* __restrict__ best_idx,
-                                                           uint8_t* __restrict__ best_dist, uint8_t* __restrict__ n_best) {
+// Second stage of the d = 3 cascade, fused with the search for its input: a workgroup walks its share of best_idx in
+// sub-chunks of 4 096 results (sixteen per thread, 16-byte loads), queues the positions the d <= 2 pass left as
+// BC_IDX_MISS in LDS, and whenever 256 are queued every thread takes one through the pair index and writes the
+// result IN PLACE; hits are tallied with device atomics (5 % of the benchmark's reads).  No compacted copy of the
+// missed reads, no device-side count for the host to wait for, no scatter pass: the launch is asynchronous and needs
+// no workspace.  (Round 2: k_collect_missed 0.40 ms + k_match_pairs 1.49 ms + k_scatter_results 0.26 ms per 1e8
+// reads and a host synchronisation in between.  A quad-per-read form of the lookup — one vector-L1 access per
+// slab — measured 1.84 ms: the stage is bound by 64-byte requests into 13 MB of tables that the L2 does not hold,
+// ~80 G requests/s, not by L1 accesses.)
+constexpr int ST2_SUB = 4096;
+__global__ __launch_bounds__(BLOCK) void k_cascade_stage2(const PairParams* __restrict__ ppp, const uint64_t* __restrict__ reads,
+                                                         uint64_t n, uint64_t kmask, int max_mm_, int32_t* __restrict__ best_idx,
+                                                         uint8_t* __restrict__ best_dist, uint8_t* __restrict__ n_best,
+                                                         uint32_t* __restrict__ counts, uint64_t* __restrict__ first_seen,
+                                                         uint64_t base) {
+    __shared__ uint32_t q_pos[ST2_SUB + BLOCK];
+    __shared__ uint32_t w_sum[BLOCK / 64];
     const PairParams& pp = *ppp;
-    const uint32_t n = *c_count;
     const uint32_t max_mm = (uint32_t)max_mm_;
-    const int s = (int)(threadIdx.x & 3u);
-    const uint32_t q_per_grid = gridDim.x * (BLOCK / 4);
-    // wave-uniform bound: every lane of a wave keeps taking part in the quad exchanges
-    for (uint32_t j0 = blockIdx.x * (BLOCK / 4) + ((threadIdx.x & ~63u) >> 2); j0 < n; j0 += q_per_grid) {
-        const uint32_t j = j0 + ((threadIdx.x & 63u) >> 2);
-        const bool act = j < n;
-        const uint64_t r = act ? (c_reads[j] & kmask) : 0ull;
-        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
-        uint4 w[10];
-        uint32_t rest[10];
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            const PairTable& T = pp.t[t];
-            rest[t] = pair_rest_plane(T, rlo) | (pair_rest_plane(T, rhi) << 16);
-            w[t] = pairs_load16(T.slabs, act ? pair_bucket(T, rlo, rhi) : 0u, s);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32x4* pv = reinterpret_cast<const u32x4*>(best_idx);  // (16-byte aligned: the cascade's precondition)
+    uint32_t qn = 0;  // queued positions (uniform over the block)
+    auto serve = [&](uint32_t first, uint32_t count) {  // queue entries [first, first + count), one per thread
+        if (threadIdx.x < count) {
+            const uint32_t i = q_pos[first + threadIdx.x];
+            const uint64_t r = reads[i] & kmask;
+            const PairBest b = pairs_lookup(pp, (uint32_t)r, (uint32_t)(r >> 32), max_mm);
+            if (b.mind <= max_mm) {
+                const uint32_t g = b.bidx & SLAB_GIDX_MASK;
+                best_idx[i] = (int32_t)g;
+                if (best_dist) best_dist[i] = (uint8_t)b.mind;
+                if (n_best) n_best[i] = (uint8_t)(b.cnt > 255u ? 255u : b.cnt);
+                if (counts) atomicAdd(&counts[g], 1u);
+                if (first_seen) {
+                    const unsigned long long v = base + i;
+                    if (v < first_seen[g]) atomicMin((unsigned long long*)&first_seen[g], v);
+                }
+            }  // else: the BC_IDX_MISS / BC_DIST_NONE / 0 the first stage wrote stay
         }
-        PairBest b{0xFFu, 0u, 0xFFFFFFFFu};
+    };
+    const uint64_t n_sub = (n + ST2_SUB - 1) / ST2_SUB;
+    for (uint64_t sc = blockIdx.x; sc < n_sub; sc += gridDim.x) {
+        const uint64_t c0 = sc * ST2_SUB;
+        uint32_t mine = 0, pos[16];
 #pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            const PairTable& T = pp.t[t];
-            pairs_scan(T, w[t], rest[t], max_mm, b);
-            // lane 3's second entry is the link-or-empty slot
-            uint32_t lw = quad_perm<0xFF>(w[t].w), lz = quad_perm<0xFF>(w[t].z);
-            uint32_t nxt = (act && lw == SLAB_LINK) ? lz : 0u;
-            while (nxt) {  // quad-uniform
-                const uint4 v = pairs_load16(T.slabs, nxt, s);
-                pairs_scan(T, v, rest[t], max_mm, b);
-                lw = quad_perm<0xFF>(v.w); lz = quad_perm<0xFF>(v.z);
-                nxt = (lw == SLAB_LINK) ? lz : 0u;
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t i = c0 + ((uint64_t)q * BLOCK + threadIdx.x) * 4;
+            uint32_t e[4] = {0u, 0u, 0u, 0u};
+            if (i + 3 < n) {
+                const u32x4 v = pv[i >> 2];
+                e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e[c] = (i + c < n) ? (uint32_t)best_idx[i + c] : 0u;
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (e[c] == (uint32_t)BC_IDX_MISS) pos[mine++] = (uint32_t)(i + c);
         }
-        // quad reduction: smallest distance; among those the tie count summed and the lowest index
-        uint32_t md = min(b.mind, quad_perm<0xB1>(b.mind));
-        md = min(md, quad_perm<0x4E>(md));
-        uint32_t c = b.mind == md ? b.cnt : 0u, g = b.mind == md ? b.bidx : 0xFFFFFFFFu;
-        c += quad_perm<0xB1>(c); c += quad_perm<0x4E>(c);
-        g = min(g, quad_perm<0xB1>(g)); g = min(g, quad_perm<0x4E>(g));
-        if (act && s == 0) {
-            const uint32_t i = c_idx[j];
-            const bool hit = md <= max_mm;
-            best_idx[i] = hit ? (int32_t)(g & SLAB_GIDX_MASK) : BC_IDX_MISS;
-            if (best_dist) best_dist[i] = hit ? (uint8_t)md : (uint8_t)BC_DIST_NONE;
-            if (n_best) n_best[i] = hit ? (uint8_t)(c > 255u ? 255u : c) : (uint8_t)0;
+        // exclusive scan of `mine` over the block
+        uint32_t x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        __syncthreads();  // (the previous round's serve() has read the queue)
+        if (lane == 63u) w_sum[wv] = x;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) { before += (uint32_t)w < wv ? w_sum[w] : 0u; total += w_sum[w]; }
+        uint32_t at = qn + before + x - mine;
+        for (uint32_t j = 0; j < mine; ++j) q_pos[at + j] = pos[j];
+        qn += total;
+        __syncthreads();
+        while (qn >= (uint32_t)BLOCK) {  // full rounds only: every lane busy
+            serve(qn - BLOCK, BLOCK);
+            qn -= BLOCK;
         }
     }
+    __syncthreads();
+    if (qn) serve(0, qn);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_match_pairs(const PairParams* __restrict__ ppp, const uint64_t* __restrict__ reads,
+                                                      const uint8_t* __restrict__ flags, uint64_t n, int k, uint64_t kmask,
+                                                      int max_mm, MatchOut o) {
+    const PairParams& pp = *ppp;
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t r = reads[i];
+    if (read_skipped(r, flags, i, k)) {
+        emit(o, i, BC_IDX_SKIP, BC_DIST_NONE, 0u);
+        return;
+    }
+    r &= kmask;
+    const PairBest b = pairs_lookup(pp, (uint32_t)r, (uint32_t)(r >> 32), (uint32_t)max_mm);
+    if (b.mind <= (uint32_t)max_mm) emit(o, i, (int32_t)(b.bidx & SLAB_GIDX_MASK), b.mind, b.cnt > 255u ? 255u : b.cnt);
+    else emit(o, i, BC_IDX_MISS, BC_DIST_NONE, 0u);
 }
 
 template <typename T>
@@ -300,15 +305,14 @@ int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t
     return BC_OK;
 }
 
-// second stage of the cascade over a device-side list (see k_match_pairs_quad): asynchronous, no host-visible count
-int launch_pairs_list(bc_lib* lib, int max_mm, const uint64_t* c_reads, const uint32_t* c_idx, const uint32_t* c_count,
-                      uint64_t n_max, int32_t* best_idx, uint8_t* best_dist, uint8_t* n_best, hipStream_t st) {
+// second stage of the cascade, in place over the first stage's results (see k_cascade_stage2): asynchronous
+int launch_cascade_stage2(bc_lib* lib, int max_mm, const uint64_t* d_reads, uint64_t n, const MatchOut& o, hipStream_t st) {
     if (!lib->d_pairs) { set_error("bc_match: no pair index for k = %d", lib->k); return BC_EINVAL; }
-    if (n_max == 0) return BC_OK;
-    const uint64_t want = (n_max + (BLOCK / 4) - 1) / (BLOCK / 4);
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, 8192));  // 32 blocks per CU; the rest by stride
-    hipLaunchKernelGGL(k_match_pairs_quad, dim3(grid), dim3(BLOCK), 0, st, lib->d_pairs, c_reads, c_idx, c_count, lib->kmask,
-                       max_mm, best_idx, best_dist, n_best);
+    if (n == 0) return BC_OK;
+    const uint64_t n_sub = (n + ST2_SUB - 1) / ST2_SUB;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_sub, 2048));  // 8 workgroups per CU
+    hipLaunchKernelGGL(k_cascade_stage2, dim3(grid), dim3(BLOCK), 0, st, lib->d_pairs, d_reads, n, lib->kmask, max_mm, o.best_idx,
+                       o.best_dist, o.n_best, o.counts, o.first_seen, o.base);
     BC_HIP(hipGetLastError());
     return BC_OK;
 }

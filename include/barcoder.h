@@ -243,13 +243,14 @@ const char *bc_lib_last_kernel(const bc_lib *lib);
  *                  first-seen output order
  *
  * Asynchronous on `stream` for every budget.  max_mismatch = 3 runs as a cascade
- * (the <= 2-mismatch pass over every read — kernel k_match_wq — then the
- * pair-of-pieces index, k_match_pairs_quad, for the reads it left, 8 <= k <= 25):
- * the number of reads the second stage takes stays on the device, which strides
- * over the compacted list; the host never waits for it.  (The first launch on a
- * stream, or one larger than every earlier launch on it, allocates its workspace
- * and waits for the stream once.)  0 <= max_mismatch < k; the seed algorithms
- * take max_mismatch <= 3.
+ * (8 <= k <= 25): the whole <= 2-mismatch pass over every read (kernel
+ * k_match_wq, tally included), then k_cascade_stage2, which finds the reads still
+ * marked BC_IDX_MISS in d_best_idx itself, takes them through the pair-of-pieces
+ * index and writes their results in place — no compacted copy, no device-side
+ * count the host would wait for.  (The first launch with a tally on a stream, or
+ * one larger than every earlier launch on it, allocates the record workspace and
+ * waits for the stream once.)  0 <= max_mismatch < k; the seed algorithms take
+ * max_mismatch <= 3.
  */
 int bc_match_dev(bc_lib *lib, const uint64_t *d_reads, const uint8_t *d_flags, uint64_t n,
                  int max_mismatch, int algo,

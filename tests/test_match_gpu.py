@@ -496,7 +496,7 @@ def test_record_tally_many_ranges(gpu_device, G, d, algo):
     dl = DeviceLibrary(lib, k, gpu_device)
     res = GpuMatcher(dl).match(reads, None, max_mismatch=d, algo=algo, first_index=7)
     hit = res.best_idx >= 0
-    assert 0.85 * n < hit.sum() < 0.95 * n
+    assert 0.75 * n < hit.sum() < 0.95 * n
     if d == 0:  # exact: the answer is known without the oracle
         order = np.argsort(lib)
         pos = np.searchsorted(lib[order], reads)
