@@ -36,6 +36,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -2193,10 +2194,25 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
         lib->part_nr = pg.nr; lib->part_R = pg.R; lib->part_magic = pg.magic; lib->part_cap_log2 = pg.cap_log2;
     }
     lib->h_guides.assign(h_guides, h_guides + n_guides);
+    const bool prof = env_int("BC_LIB_PROF", 0) != 0;  // tuning aid: phase times of this call on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t0 = now();
     int rc = dev_upload(lib, lib->h_guides, &lib->d_guides);
     if (rc == BC_OK) rc = compute_nn(lib);
+    const double t_nn = ms_since(t0);
+    t0 = now();
     if (rc == BC_OK) rc = build_hash(lib);
-    for (int d = 0; d < MAX_SEG && rc == BC_OK; ++d) rc = build_seed_index(lib, d);
+    const double t_hash = ms_since(t0);
+    double t_seed[MAX_SEG] = {0, 0, 0, 0};
+    for (int d = 0; d < MAX_SEG && rc == BC_OK; ++d) {
+        t0 = now();
+        rc = build_seed_index(lib, d);
+        t_seed[d] = ms_since(t0);
+    }
+    if (prof)
+        fprintf(stderr, "bc_lib_create: G=%u k=%d  neighbours %.1f ms, hash table %.1f ms, seed indices d=0..3 %.1f / %.1f / %.1f / %.1f ms\n",
+                n_guides, k, t_nn, t_hash, t_seed[0], t_seed[1], t_seed[2], t_seed[3]);
     // (the pair index of the 3-mismatch matcher is built on first use: ensure_pair_index)
     if (rc != BC_OK) { bc_lib_destroy(lib); return rc; }
     *out = lib;

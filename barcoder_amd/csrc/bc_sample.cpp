@@ -10,12 +10,16 @@
 // records the first mate's k-mer for both mates, Counter ties resolve to the
 // first inserted key).  The Python mirror in barcoder_amd/heuristicount.py is
 // the golden-tested statement of the same rules; tests compare the two.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -213,22 +217,6 @@ struct Roll {
     }
 };
 
-std::string revcomp_str(std::string_view s) {
-    std::string o(s.size(), 'N');
-    for (size_t i = 0; i < s.size(); ++i) {
-        char c = s[s.size() - 1 - i];
-        switch (c) {
-            case 'A': c = 'T'; break;
-            case 'T': c = 'A'; break;
-            case 'C': c = 'G'; break;
-            case 'G': c = 'C'; break;
-            default: break;
-        }
-        o[i] = c;
-    }
-    return o;
-}
-
 }  // namespace
 
 struct bc_sample {
@@ -243,28 +231,42 @@ extern "C" {
 int bc_sample_data(const char* file1, const char* file2, const char* barcodes, uint32_t G, int k, bc_sample** out) {
     if (!file1 || !barcodes || !out || G == 0 || k < 1) { set_error("bc_sample_data: bad argument"); return BC_EINVAL; }
     const bool paired = file2 && *file2;
-    std::vector<std::string> fwd_store(G), rev_store(G);
-    StrSet fwd(G, false), rev(G, false);
+    // the library and its reverse complements as two contiguous blobs (no per-entry allocation), the sets hold views
+    std::vector<char> rev_blob((size_t)G * k);
+    auto fwd_at = [&](uint32_t g) { return std::string_view(barcodes + (size_t)g * k, (size_t)k); };
+    auto rev_at = [&](uint32_t g) { return std::string_view(rev_blob.data() + (size_t)g * k, (size_t)k); };
     for (uint32_t g = 0; g < G; ++g) {
-        fwd_store[g].assign(barcodes + (size_t)g * k, k);
-        rev_store[g] = revcomp_str(fwd_store[g]);
+        const char* src = barcodes + (size_t)g * k;
+        char* dst = rev_blob.data() + (size_t)g * k;
+        for (int j = 0; j < k; ++j) {
+            char c = src[k - 1 - j];
+            switch (c) {
+                case 'A': c = 'T'; break;
+                case 'T': c = 'A'; break;
+                case 'C': c = 'G'; break;
+                case 'G': c = 'C'; break;
+                default: break;
+            }
+            dst[j] = c;
+        }
     }
-    for (uint32_t g = 0; g < G; ++g) { fwd.insert(fwd_store[g]); rev.insert(rev_store[g]); }
+    StrSet fwd(G, false), rev(G, false);
+    for (uint32_t g = 0; g < G; ++g) { fwd.insert(fwd_at(g)); rev.insert(rev_at(g)); }
     const uint64_t n_lib = fwd.size();  // len(barcodes) of the SET (heuristicount.py:174-176)
     // Pre-filter for the k-mer sweep (most windows of a read are no barcode): 2^24 bits set at a hash of the packed
     // value of every library entry and reverse complement.  Only when every entry is pure upper-case ACGT and fits a
     // 64-bit packing; otherwise the sweep asks the sets for every window, as the reference does.
     bool prefilter = k <= 32;
     for (uint32_t g = 0; g < G && prefilter; ++g)
-        for (int j = 0; j < k; ++j) prefilter = prefilter && base_code((unsigned char)fwd_store[g][j]) < 4;
+        for (int j = 0; j < k; ++j) prefilter = prefilter && base_code((unsigned char)barcodes[(size_t)g * k + j]) < 4;
     std::vector<uint64_t> pf_bits, pf_small;
     if (prefilter) {
         pf_bits.assign((1u << PF_BITS) / 64, 0);
         pf_small.assign((1u << PF_SMALL_BITS) / 64, 0);
         for (uint32_t g = 0; g < G; ++g)
-            for (const std::string* sp : {&fwd_store[g], &rev_store[g]}) {
+            for (const std::string_view sp : {fwd_at(g), rev_at(g)}) {
                 uint64_t v = 0;
-                for (int j = 0; j < k; ++j) v = (v << 2) | (uint64_t)base_code((unsigned char)(*sp)[j]);
+                for (int j = 0; j < k; ++j) v = (v << 2) | (uint64_t)base_code((unsigned char)sp[j]);
                 const uint32_t h = Roll::hash(v), hs = Roll::hash_small(v);
                 pf_bits[h >> 6] |= 1ull << (h & 63);
                 pf_small[hs >> 6] |= 1ull << (hs & 63);
@@ -275,6 +277,12 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     if (rc != BC_OK) return rc;
     if (paired && (rc = bc_reader_open(file2, &r2)) != BC_OK) { bc_reader_close(r1); return rc; }
 
+    const bool prof = getenv("BC_SAMPLE_PROF") != nullptr;  // tuning aid: where the sampling pass spends its time
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    double t_setup = 0, t_read = 0, t_sweep = 0;
+    static thread_local std::chrono::steady_clock::time_point t_enter;
+    t_setup = 0;
+    auto t_mark = now();
     int64_t div[2] = {0, 0};
     OrderedCounter<int> orients[2];      // 0 = "forward", 1 = "reverse"
     OrderedCounter<int64_t> offsets[2];
@@ -287,9 +295,12 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     bool last1_truthy = false, last2_truthy = false, any_read = false;
     Chunk c1, c2;
     for (;;) {
+        t_mark = now();
         if ((rc = next_chunk(r1, n_lib, c1)) != BC_OK) break;
         if (paired && (rc = next_chunk(r2, n_lib, c2)) != BC_OK) break;
+        t_read += std::chrono::duration<double, std::milli>(now() - t_mark).count();
         if (c1.n == 0) break;
+        t_mark = now();
         ++n_chunks;
         std::vector<int> c_or[2];
         std::vector<int64_t> c_off[2];
@@ -305,15 +316,18 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         constexpr uint64_t AHEAD = 12;
         constexpr int MAXC = 6;
         struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint64_t hk[MAXC]; };
-        Ahead ring[AHEAD];
         const bool lookahead = !paired && prefilter;
+        // what a read contributes before any set is consulted — its hash, the windows that pass the pre-filter, their
+        // hashes — is a pure function of the read: computed for the whole chunk by worker threads (this was two thirds
+        // of the sampling pass on one thread); the order-dependent set logic below then runs alone, prefetching the
+        // slots of the reads a few places ahead
+        std::vector<Ahead> prep(lookahead ? nz : 0);
         auto prepare = [&](uint64_t q) {
-            Ahead& a = ring[q % AHEAD];
+            Ahead& a = prep[q];
             const std::string_view rd = c1.read(q);
             a.h1 = str_hash(rd);
             a.ncand = 0;
             a.overflow = false;
-            c_reads.prefetch(a.h1); seen_reads.prefetch(a.h1); valid[0].prefetch(a.h1);
             if ((int64_t)rd.size() < k) return;
             // one pass over the characters: rolling packed value, length of the current ACGT run, both filter levels
             const uint64_t kmask2 = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -333,13 +347,30 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 if (!((big[hb >> 6] >> (hb & 63)) & 1ull)) continue;
                 if (a.ncand == MAXC) { a.overflow = true; break; }
                 const size_t i = e + 1 - (size_t)k;
-                const uint64_t hk = str_hash(rd.substr(i, k));
-                a.pos[a.ncand] = (uint32_t)i; a.hk[a.ncand] = hk; ++a.ncand;
-                c_barcodes.prefetch(hk); fwd.prefetch(hk); rev.prefetch(hk); observed.prefetch(hk);
+                a.pos[a.ncand] = (uint32_t)i; a.hk[a.ncand] = str_hash(rd.substr(i, k)); ++a.ncand;
             }
         };
-        if (lookahead)
-            for (uint64_t q = 0; q < std::min<uint64_t>(AHEAD, nz); ++q) prepare(q);
+        auto warm = [&](uint64_t q) {  // pull the slots read q will touch towards the core
+            const Ahead& a = prep[q];
+            c_reads.prefetch(a.h1); seen_reads.prefetch(a.h1); valid[0].prefetch(a.h1);
+            for (int c = 0; c < a.ncand; ++c) {
+                c_barcodes.prefetch(a.hk[c]); fwd.prefetch(a.hk[c]); rev.prefetch(a.hk[c]); observed.prefetch(a.hk[c]);
+            }
+        };
+        if (lookahead) {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(8, hw), nz / 4096 + 1));
+            if (T == 1) {
+                for (uint64_t q = 0; q < nz; ++q) prepare(q);
+            } else {
+                std::vector<std::thread> th;
+                const uint64_t per = (nz + T - 1) / T;
+                for (uint64_t t = 0; t < T; ++t)
+                    th.emplace_back([&, t] { for (uint64_t q = t * per; q < std::min(nz, (t + 1) * per); ++q) prepare(q); });
+                for (auto& x : th) x.join();
+            }
+            for (uint64_t q = 0; q < std::min<uint64_t>(AHEAD, nz); ++q) warm(q);
+        }
         for (uint64_t q = 0; q < nz; ++q) {
             const std::string_view read1 = c1.read(q);
             const std::string_view read2 = have2 ? c2.read(q) : std::string_view();
@@ -347,8 +378,8 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
             last1_truthy = !read1.empty();
             last2_truthy = have2 && !read2.empty();
             if (lookahead) {
-                const Ahead a = ring[q % AHEAD];  // (copied: the slot is reused for read q + AHEAD right away)
-                if (q + AHEAD < nz) prepare(q + AHEAD);
+                const Ahead& a = prep[q];
+                if (q + AHEAD < nz) warm(q + AHEAD);
                 const uint64_t h1 = a.h1;
                 if (c_reads.contains(h1, read1)) continue;
                 seen_reads.insert(h1, read1);
@@ -424,6 +455,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 }
             }
         }
+        t_sweep += std::chrono::duration<double, std::milli>(now() - t_mark).count();
         all_novel += c_barcodes.size();
         for (int s = 0; s < 2; ++s) {
             for (int o : c_or[s]) orients[s].add(o);
@@ -445,6 +477,9 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     }
     bc_reader_close(r1);
     if (r2) bc_reader_close(r2);
+    (void)t_enter; (void)t_setup;
+    if (prof) fprintf(stderr, "bc_sample_data: %llu chunks of %llu reads: reading %.1f ms, sweep %.1f ms\n",
+                      (unsigned long long)n_chunks, (unsigned long long)n_lib, t_read, t_sweep);
     if (rc != BC_OK) return rc;
     if (!any_read) { set_error("Unable to determine orientation of reads. Please check the input files."); return BC_EINVAL; }
     // most_common(1)[0][0] on an empty Counter is an IndexError in the reference (logged by main)
@@ -499,7 +534,64 @@ int bc_sample_flanks(const bc_sample* s, int which, int64_t start, int bc_len, i
         return BC_EINVAL;
     }
     const std::vector<std::string>& reads = which ? s->valid2 : s->valid1;
-    OrderedCounter<std::string> tally[2];
+    const auto t_begin = std::chrono::steady_clock::now();
+    // Counter of the flank candidates: a candidate is at most max_flank <= 64 characters... in practice ten, so up to
+    // 15 characters travel as one 128-bit key (characters + length) through an open-addressing table that remembers
+    // insertion order (Counter / max() resolve ties towards the first inserted key); longer ones take the string map
+    struct Key { uint64_t a, b; };
+    struct Entry { Key k; int64_t count; uint32_t order; bool used; };
+    struct FlankCounter {
+        std::vector<Entry> tab;
+        size_t mask, n = 0;
+        OrderedCounter<std::string> big;  // candidates of 16+ characters (max_flank > 15 only)
+        FlankCounter() : tab(1u << 12, Entry{{0, 0}, 0, 0, false}), mask((1u << 12) - 1) {}
+        static Key pack(std::string_view v) {
+            Key k{0, 0};
+            memcpy(&k.a, v.data(), std::min<size_t>(v.size(), 8));
+            if (v.size() > 8) memcpy(&k.b, v.data() + 8, v.size() - 8);
+            k.b |= (uint64_t)v.size() << 56;  // at most 15 characters: byte 7 of b is free
+            return k;
+        }
+        void add(std::string_view v) {
+            if (v.size() > 15) { big.add(std::string(v)); return; }
+            const Key k = pack(v);
+            size_t i = (size_t)((k.a * 0x9E3779B97F4A7C15ull) ^ (k.b * 0xD6E8FEB86659FD93ull)) >> 20 & mask;
+            for (;; i = (i + 1) & mask) {
+                Entry& e = tab[i];
+                if (!e.used) { e = Entry{k, 1, (uint32_t)n++, true}; break; }
+                if (e.k.a == k.a && e.k.b == k.b) { ++e.count; return; }
+            }
+            if (n * 2 > tab.size()) {
+                std::vector<Entry> old;
+                old.swap(tab);
+                tab.assign(old.size() * 2, Entry{{0, 0}, 0, 0, false});
+                mask = tab.size() - 1;
+                for (const Entry& e : old)
+                    if (e.used) {
+                        size_t j = (size_t)((e.k.a * 0x9E3779B97F4A7C15ull) ^ (e.k.b * 0xD6E8FEB86659FD93ull)) >> 20 & mask;
+                        while (tab[j].used) j = (j + 1) & mask;
+                        tab[j] = e;
+                    }
+            }
+        }
+        // items in insertion order: (text, count)
+        std::vector<std::pair<std::string, int64_t>> items() const {
+            std::vector<const Entry*> v;
+            for (const Entry& e : tab) if (e.used) v.push_back(&e);
+            std::sort(v.begin(), v.end(), [](const Entry* x, const Entry* y) { return x->order < y->order; });
+            std::vector<std::pair<std::string, int64_t>> out;
+            for (const Entry* e : v) {
+                const size_t len = (size_t)(e->k.b >> 56);
+                char buf[16];
+                memcpy(buf, &e->k.a, 8);
+                const uint64_t b = e->k.b & 0x00FFFFFFFFFFFFFFull;
+                memcpy(buf + 8, &b, 8);
+                out.emplace_back(std::string(buf, len), e->count);
+            }
+            return out;
+        }
+    };
+    FlankCounter tally[2];
     for (const std::string& read : reads) {
         const int64_t n = (int64_t)read.size();
         // python slices: read[start-max_flank:start] (or read[0:start]) and read[start+k : start+k+max_flank]
@@ -508,14 +600,18 @@ int bc_sample_flanks(const bc_sample* s, int which, int64_t start, int bc_len, i
         std::string_view left = b > a ? std::string_view(read).substr((size_t)a, (size_t)(b - a)) : std::string_view();
         int64_t c = std::min<int64_t>(std::max<int64_t>(start + bc_len, 0), n), d = std::min<int64_t>(std::max<int64_t>(start + bc_len + max_flank, 0), n);
         std::string_view right = d > c ? std::string_view(read).substr((size_t)c, (size_t)(d - c)) : std::string_view();
-        for (size_t m = left.size(); m > 0; --m) tally[0].add(std::string(left.substr(left.size() - m)));
-        for (size_t m = right.size(); m > 0; --m) tally[1].add(std::string(right.substr(0, m)));
+        for (size_t m = left.size(); m > 0; --m) tally[0].add(left.substr(left.size() - m));
+        for (size_t m = right.size(); m > 0; --m) tally[1].add(right.substr(0, m));
     }
-    auto best = [&](const OrderedCounter<std::string>& t, char* out_buf, int* out_len) {
+    auto best = [&](const FlankCounter& fc, char* out_buf, int* out_len) {
+        // (with max_flank <= 15 every candidate is in the packed table; the string map only fills beyond that, and the
+        // two never hold candidates of the same length, so per-length maxima need no merged order)
+        std::vector<std::pair<std::string, int64_t>> all = fc.items();
+        for (const auto& it : fc.big.items) all.push_back(it);
         const std::pair<std::string, int64_t>* chosen = nullptr;
         for (int n = max_flank; n > 0; --n) {
             const std::pair<std::string, int64_t>* top = nullptr;
-            for (const auto& it : t.items)
+            for (const auto& it : all)
                 if ((int)it.first.size() == n && (!top || it.second > top->second)) top = &it;  // max(): first maximum
             if (!top) continue;
             if (!chosen || top->second > 3 * chosen->second) chosen = top;
@@ -527,6 +623,9 @@ int bc_sample_flanks(const bc_sample* s, int which, int64_t start, int bc_len, i
     };
     best(tally[0], L_out, L_len);
     best(tally[1], R_out, R_len);
+    if (getenv("BC_SAMPLE_PROF"))
+        fprintf(stderr, "bc_sample_flanks: %zu reads, %.1f ms\n", reads.size(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     return BC_OK;
 }
 

@@ -28,7 +28,7 @@ from contextlib import nullcontext
 import numpy as np
 
 from . import _native as N
-from .encoding import pack_windows, reads_to_text, unpack_kmers
+from .encoding import pack_kmers, pack_windows, reads_to_text, unpack_kmers
 from .library import DeviceLibrary
 from .matcher import GpuMatcher
 
@@ -70,8 +70,10 @@ def read_fasta(fasta_file):
         return {line.strip() for line in fh if not line.startswith(">")}
 
 
-def read_fasta_ordered(fasta_file):
+def read_fasta_ordered(fasta_file, check_extension: bool = False):
     """Same lines as read_fasta, de-duplicated in file order (= guide index order)."""
+    if check_extension and not fasta_file.endswith((".gz", ".zst", ".fasta", ".fa")):
+        raise ValueError(f'"{fasta_file}" does not appear to be a supported fasta file: .fasta or .fa.')
     if fasta_file.endswith(".gz"):
         opener = gzip.open
     elif fasta_file.endswith(".zst"):
@@ -323,23 +325,42 @@ class ChunkCounter:
         self.need_swap = need_swap
         self.max_mismatch, self.algo = max_mismatch, algo
         ordered = list(dict.fromkeys(barcodes))
-        # entries that cannot be 2-bit packed can only ever equal an ODD window (host string compare)
-        self.labels = [b for b in ordered if len(b) == bc_len and set(b) <= set("ACGT")]
-        self.fwd_set = fwd_set if fwd_set is not None else {self.geom[2] + b + self.geom[3] for b in ordered}
-        self.rev_set = rev_set if rev_set is not None else {self.geom[4] + rev_comp(b) + self.geom[5] for b in ordered}
+        self._ordered = ordered
+        # entries that cannot be 2-bit packed can only ever equal an ODD window (host string compare); the packer's
+        # flags say which (one native pass instead of a Python test per entry)
+        same = [b for b in ordered if len(b) == bc_len]
+        if same and bc_len <= 32:
+            _pk, bad = pack_kmers(same, bc_len)
+            self.labels = [b for b, f in zip(same, bad.tolist()) if not f] if bad.any() else same
+        else:
+            self.labels = [b for b in same if set(b) <= set("ACGT")]
+        # the flanked string sets are needed for odd windows only: built when the first one turns up
+        self._fwd_set, self._rev_set = fwd_set, rev_set
         if not self.labels:
             raise ValueError("no pure-ACGT barcode of the stated length in the library")
         self.lib = DeviceLibrary.from_strings(self.labels, device)
         self.matcher = GpuMatcher(self.lib)
 
+    @property
+    def fwd_set(self):
+        if self._fwd_set is None:
+            self._fwd_set = {self.geom[2] + b + self.geom[3] for b in self._ordered}
+        return self._fwd_set
+
+    @property
+    def rev_set(self):
+        if self._rev_set is None:
+            self._rev_set = {self.geom[4] + rev_comp(b) + self.geom[5] for b in self._ordered}
+        return self._rev_set
+
     # windows of one mate: (packed, status, odd -> (in_lib, seq)); `buf` = (text, off)
-    def _windows(self, buf, start, L, R, reverse, lib_set):
+    def _windows(self, buf, start, L, R, reverse, which):
         text, off = buf
         packed, status = pack_windows(text, off, start, L, R, self.k, reverse)
         odd = {}
         for i in np.flatnonzero(status == N.WIN_ODD).tolist():
             w = _read_at(buf, i)[start:start + len(L) + self.k + len(R)]
-            odd[i] = (w in lib_set, w[len(L):len(w) - len(R)])
+            odd[i] = (w in (self.rev_set if which == "rev" else self.fwd_set), w[len(L):len(w) - len(R)])
         return packed, status, odd
 
     def process(self, chunk):
@@ -364,8 +385,8 @@ class ChunkCounter:
             if n1 != n2:
                 raise ValueError("Length of reads1 and reads2 must be the same for paired-end data.")
             n = n1
-            p1, st1, odd1 = self._windows(buf1, s1, Lf, Rf, False, self.fwd_set)
-            p2, st2, odd2 = self._windows(buf2, s2, Lr, Rr, True, self.rev_set)
+            p1, st1, odd1 = self._windows(buf1, s1, Lf, Rf, False, "fwd")
+            p2, st2, odd2 = self._windows(buf2, s2, Lr, Rr, True, "rev")
             ok = (st1 == N.WIN_OK) & (st2 == N.WIN_OK) & (p1 == p2)
             flags = (~ok).astype(np.uint8)
             res = self.matcher.match(p1, flags, self.max_mismatch, self.algo, first_index=first_index)
@@ -388,8 +409,8 @@ class ChunkCounter:
             n = n2 if reverse else n1
             if not n:
                 return ChunkResult(0, None, None, None, None, None, [])
-            start, L, R, lib_set = (s2, Lr, Rr, self.rev_set) if reverse else (s1, Lf, Rf, self.fwd_set)
-            packed, status, odd = self._windows(buf, start, L, R, reverse, lib_set)
+            start, L, R = (s2, Lr, Rr) if reverse else (s1, Lf, Rf)
+            packed, status, odd = self._windows(buf, start, L, R, reverse, "rev" if reverse else "fwd")
             res = self.matcher.match(packed, (status != N.WIN_OK).astype(np.uint8), self.max_mismatch, self.algo,
                                      first_index=first_index)
             for i, (in_lib, seq) in odd.items():
@@ -573,7 +594,8 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     from . import dist as D
     import time as _time
     t_start = _time.perf_counter()
-    barcodes = read_fasta(fasta_file)
+    ordered_lines = read_fasta_ordered(fasta_file, check_extension=True)  # one pass over the file: set and file order
+    barcodes = set(ordered_lines)
     validate_barcodes(barcodes)
     lengths = {len(b) for b in barcodes}
     if len(lengths) != 1:
@@ -582,7 +604,7 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     bc_len = lengths.pop()
     is_paired = bool(file2)
     log.info("Sampling reads to identify diversity characteristics...")
-    ordered = [b for b in read_fasta_ordered(fasta_file) if b in barcodes]
+    ordered = ordered_lines
     smp = NativeSample(file1, file2, ordered, is_paired)
     bc_start1, bc_start2, need_swap = smp.offset1, smp.offset2, smp.need_swap
     log.info("Sampled %s diverse contexts in %s chunks and found %s barcodes in %s forward and %s reverse reads...",
@@ -684,7 +706,7 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
                 lo, hi = 0, os.path.getsize(file1)
             s1, s2, Lf, Rf, Lr, Rr = cc.geom
             reverse = bool(need_swap)
-            start, L, R, lib_set = (s2, Lr, Rr, cc.rev_set) if reverse else (s1, Lf, Rf, cc.fwd_set)
+            start, L, R = (s2, Lr, Rr) if reverse else (s1, Lf, Rf)
             c64, f64 = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
             sr = stream_count_file(cc.lib.handle, file1, lo, hi, start, L, R, reverse, max_mismatch, cc.algo, lo, c64, f64)
             counts[:G], first_seen[:G] = c64, f64
@@ -694,7 +716,7 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
                 seq = w[len(L):len(w) - len(R)]
                 if reverse:
                     seq = rev_comp(seq)
-                odd_events.append((key, seq if w in lib_set else seq + "*"))
+                odd_events.append((key, seq if w in (cc.rev_set if reverse else cc.fwd_set) else seq + "*"))
             n_mine[0] = sr.n_reads
             counts[G] = sr.n_reads
             t_bulk[0] = _time.perf_counter() - t0
