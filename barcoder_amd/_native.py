@@ -48,6 +48,9 @@ SIGNATURES = {
     "bc_revcomp_kmers": (C.c_int, [vp, C.c_size_t, C.c_int, vp]),
     "bc_pack_windows": (C.c_int, [vp, vp, C.c_size_t, C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, vp, vp]),
+    "bc_hash_kmers": (C.c_int, [vp, C.c_size_t, C.c_int, vp]),
+    "bc_hash_windows": (C.c_int, [vp, vp, C.c_size_t, C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "bc_reader_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "bc_reader_open_range": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
     "bc_reader_tell": (C.c_int, [vp, C.POINTER(C.c_uint64)]),

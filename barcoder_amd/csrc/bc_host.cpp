@@ -157,6 +157,96 @@ int bc_pack_windows(const char* h_text, const uint64_t* h_off, size_t n_reads, i
     return BC_OK;
 }
 
+// ---- barcodes longer than 32 nt (exact match only) --------------------------------
+// The reference's set lookup (heuristicount.py:449-453) is length-agnostic up to 1 000 nt (:75-97); the packed matcher
+// holds 32 bases.  Longer windows travel as a 64-bit hash of the oriented barcode text (what the GPU's exact table
+// looks up, as a pseudo 32-mer) together with the text itself (what the caller verifies a hit against and names an
+// undocumented window by): bc_hash_windows is bc_pack_windows' twin for them, bc_hash_kmers hashes the library.
+static inline uint64_t text_hash64(const unsigned char* p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xD6E8FEB86659FD93ull);
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+        h ^= h >> 32;
+        p += 8; n -= 8;
+    }
+    if (n) {
+        uint64_t w = 0;
+        memcpy(&w, p, n);
+        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+        h ^= h >> 32;
+    }
+    h *= 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+
+int bc_hash_kmers(const char* h_seqs, size_t n, int k, uint64_t* h_out) {
+    if (k < 1 || (!h_seqs && n) || (!h_out && n)) { set_error("bc_hash_kmers: bad argument"); return BC_EINVAL; }
+    for (size_t i = 0; i < n; ++i) h_out[i] = text_hash64((const unsigned char*)h_seqs + i * (size_t)k, (size_t)k);
+    return BC_OK;
+}
+
+static void hash_windows_range(const char* text, const uint64_t* off, size_t a, size_t b, int64_t start, const char* L,
+                               int L_len, const char* R, int R_len, int k, int reverse, uint64_t* out, uint8_t* status,
+                               char* wbuf) {
+    const int64_t wlen = (int64_t)L_len + k + R_len;
+    for (size_t i = a; i < b; ++i) {
+        const char* rd = text + off[i];
+        const int64_t len = (int64_t)(off[i + 1] - off[i]);
+        char* dst = wbuf + i * (size_t)k;
+        out[i] = 0;
+        status[i] = BC_WIN_SKIP;
+        if (len > 0 && memchr(rd, 'N', (size_t)len) != nullptr) continue;  // heuristicount.py:524
+        const int64_t ws = std::min<int64_t>(start, len), we = std::min<int64_t>(start + wlen, len);
+        const int64_t n = we - ws;
+        const char* win = rd + ws;
+        const bool has = n >= L_len && n >= R_len && (L_len == 0 || memcmp(win, L, (size_t)L_len) == 0) &&
+                         (R_len == 0 || memcmp(win + n - R_len, R, (size_t)R_len) == 0);
+        if (!has) continue;
+        status[i] = BC_WIN_ODD;  // flanks present; a short window or an odd character keeps string semantics
+        if (n != wlen) continue;
+        const unsigned char* sq = (const unsigned char*)win + L_len;
+        bool bad = false;
+        for (int j = 0; j < k && !bad; ++j) bad = base_code(sq[j]) > 3;
+        if (bad) continue;
+        if (reverse) {  // heuristicount.py:532-533: the barcode as the library spells it
+            for (int j = 0; j < k; ++j) {
+                const char c = (char)sq[k - 1 - j];
+                dst[j] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : 'C';
+            }
+        } else {
+            memcpy(dst, sq, (size_t)k);
+        }
+        out[i] = text_hash64((const unsigned char*)dst, (size_t)k);
+        status[i] = BC_WIN_OK;
+    }
+}
+
+int bc_hash_windows(const char* h_text, const uint64_t* h_off, size_t n_reads, int64_t start, const char* L, int L_len,
+                    const char* R, int R_len, int k, int reverse, int n_threads, uint64_t* h_out, uint8_t* h_status,
+                    char* h_windows) {
+    if (k < 1 || k > 1000 || start < 0 || L_len < 0 || R_len < 0 || (L_len && !L) || (R_len && !R) ||
+        (n_reads && (!h_off || !h_out || !h_status || !h_windows))) {
+        set_error("bc_hash_windows: bad argument (k=%d start=%lld)", k, (long long)start);
+        return BC_EINVAL;
+    }
+    if (n_reads == 0) return BC_OK;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = n_threads > 0 ? (size_t)n_threads : (hw ? hw : 1);
+    nt = std::max<size_t>(1, std::min(nt, n_reads / 8192 + 1));
+    std::vector<std::thread> th;
+    const size_t per = (n_reads + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t) {
+        const size_t a = t * per, b = std::min(n_reads, a + per);
+        if (a >= b) break;
+        if (nt == 1) hash_windows_range(h_text, h_off, a, b, start, L, L_len, R, R_len, k, reverse, h_out, h_status, h_windows);
+        else th.emplace_back(hash_windows_range, h_text, h_off, a, b, start, L, L_len, R, R_len, k, reverse, h_out, h_status, h_windows);
+    }
+    for (auto& t : th) t.join();
+    return BC_OK;
+}
+
 // ---- genome packing -------------------------------------------------------------
 int bc_genome_pack(const char* h_seq, uint64_t len, uint64_t wrap, uint64_t* h_bases,
                    uint32_t* h_invalid) {

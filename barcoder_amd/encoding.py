@@ -69,6 +69,39 @@ def pack_windows(text: bytes, off, start: int, L: str, R: str, k: int, reverse: 
     return out, status
 
 
+def hash_kmers(seqs, k: int | None = None) -> np.ndarray:
+    """Equal-length strings of any length -> uint64[n]: the 64-bit text hash that stands for a barcode longer than
+    32 nt in the GPU's exact table (bc_hash_kmers)."""
+    seqs = list(seqs)
+    n = len(seqs)
+    if n == 0:
+        return np.zeros(0, np.uint64)
+    if k is None:
+        k = len(seqs[0])
+    if any(len(s) != k for s in seqs):
+        raise ValueError("All barcodes must be the same length")  # heuristicount.py:594
+    buf = "".join(seqs).encode("ascii", errors="replace")
+    out = np.empty(n, np.uint64)
+    N.check(N.load().bc_hash_kmers(buf, n, k, N.ptr(out)))
+    return out
+
+
+def hash_windows(text: bytes, off, start: int, L: str, R: str, k: int, reverse: bool = False, n_threads: int = 0):
+    """pack_windows for barcodes of 33 ... 1000 nt -> (hash uint64[n], status uint8[n], windows uint8[n, k]): the
+    hash and the text of the barcode as the library spells it (bc_hash_windows); both only where status is WIN_OK."""
+    n = off.size - 1
+    out = np.zeros(n, np.uint64)
+    status = np.empty(n, np.uint8)
+    wins = np.zeros((n, k), np.uint8)
+    Lb, Rb = (L or "").encode("ascii"), (R or "").encode("ascii")
+    if isinstance(text, np.ndarray):
+        text = N.ptr(np.ascontiguousarray(text)) if text.size else b""
+    off = np.ascontiguousarray(off, np.uint64)
+    N.check(N.load().bc_hash_windows(text, N.ptr(off), n, int(start), Lb, len(Lb), Rb, len(Rb), k,
+                                     1 if reverse else 0, n_threads, N.ptr(out), N.ptr(status), N.ptr(wins)))
+    return out, status, wins
+
+
 IUPAC = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15, "R": 5, "Y": 10, "S": 6, "W": 9, "K": 12, "M": 3,
          "B": 14, "D": 13, "H": 11, "V": 7}
 

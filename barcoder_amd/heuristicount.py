@@ -28,7 +28,7 @@ from contextlib import nullcontext
 import numpy as np
 
 from . import _native as N
-from .encoding import pack_kmers, pack_windows, reads_to_text, unpack_kmers
+from .encoding import hash_windows, pack_kmers, pack_windows, reads_to_text, unpack_kmers
 from .library import DeviceLibrary
 from .matcher import GpuMatcher
 
@@ -314,6 +314,16 @@ class NativeSample:
 
 
 # ------------------------------------------------------------------------------ hot path
+def window_labels(words, k: int):
+    """Undocumented windows as strings: packed words (k <= 32) or rows of text (a 1-D array of k-byte void items:
+    barcodes of more than 32 nt)."""
+    words = np.asarray(words)
+    if words.dtype.kind == "V":
+        raw = words.tobytes().decode("ascii", errors="replace")
+        return [raw[i * k:(i + 1) * k] for i in range(words.size)]
+    return unpack_kmers(words, k)
+
+
 class ChunkCounter:
     """Device-side state for process_chunk: the library in HBM plus the window
     geometry.  One instance serves every chunk of a run."""
@@ -321,6 +331,10 @@ class ChunkCounter:
     def __init__(self, barcodes, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
                  device: int = 0, max_mismatch: int = 0, algo: str = "auto", fwd_set=None, rev_set=None):
         self.k = bc_len
+        # more than 32 nt: exact match through a text hash, hits verified against the text (LongDeviceLibrary)
+        self.long = bc_len > 32
+        if self.long and max_mismatch:
+            raise ValueError(f"mismatch-tolerant counting needs barcodes of at most 32 nt (got {bc_len})")
         self.geom = (L_fwd_start, L_rev_start, L_fwd or "", R_fwd or "", L_rev or "", R_rev or "")
         self.need_swap = need_swap
         self.max_mismatch, self.algo = max_mismatch, algo
@@ -356,7 +370,11 @@ class ChunkCounter:
     # windows of one mate: (packed, status, odd -> (in_lib, seq)); `buf` = (text, off)
     def _windows(self, buf, start, L, R, reverse, which):
         text, off = buf
-        packed, status = pack_windows(text, off, start, L, R, self.k, reverse)
+        if self.long:
+            packed, status, wins = hash_windows(text, off, start, L, R, self.k, reverse)
+            self._wins[which] = wins
+        else:
+            packed, status = pack_windows(text, off, start, L, R, self.k, reverse)
         odd = {}
         for i in np.flatnonzero(status == N.WIN_ODD).tolist():
             w = _read_at(buf, i)[start:start + len(L) + self.k + len(R)]
@@ -377,6 +395,7 @@ class ChunkCounter:
         """The device pass of one chunk, results left in array form (no per-key
         Python work): what the bulk driver accumulates."""
         buf1, buf2 = (buf_b, buf_a) if self.need_swap else (buf_a, buf_b)
+        self._wins = {}
         n1 = 0 if buf1 is None else buf1[1].size - 1
         n2 = 0 if buf2 is None else buf2[1].size - 1
         s1, s2, Lf, Rf, Lr, Rr = self.geom
@@ -388,8 +407,10 @@ class ChunkCounter:
             p1, st1, odd1 = self._windows(buf1, s1, Lf, Rf, False, "fwd")
             p2, st2, odd2 = self._windows(buf2, s2, Lr, Rr, True, "rev")
             ok = (st1 == N.WIN_OK) & (st2 == N.WIN_OK) & (p1 == p2)
+            if self.long:  # equal hashes are a hint, equal texts the fact (seq1 == rev_comp(seq2), :506)
+                ok &= (self._wins["fwd"] == self._wins["rev"]).all(axis=1)
             flags = (~ok).astype(np.uint8)
-            res = self.matcher.match(p1, flags, self.max_mismatch, self.algo, first_index=first_index)
+            res = self._match(p1, flags, first_index, "fwd")
             # pairs with a window that cannot be packed: exact string semantics on the host
             for i in sorted(set(odd1) | set(odd2)):
                 x, y = _read_at(buf1, i), _read_at(buf2, i)
@@ -411,8 +432,7 @@ class ChunkCounter:
                 return ChunkResult(0, None, None, None, None, None, [])
             start, L, R = (s2, Lr, Rr) if reverse else (s1, Lf, Rf)
             packed, status, odd = self._windows(buf, start, L, R, reverse, "rev" if reverse else "fwd")
-            res = self.matcher.match(packed, (status != N.WIN_OK).astype(np.uint8), self.max_mismatch, self.algo,
-                                     first_index=first_index)
+            res = self._match(packed, (status != N.WIN_OK).astype(np.uint8), first_index, "rev" if reverse else "fwd")
             for i, (in_lib, seq) in odd.items():
                 if reverse:
                     seq = rev_comp(seq)
@@ -420,12 +440,33 @@ class ChunkCounter:
             miss_words = packed
         # undocumented: group the missed (but flank-valid) windows
         miss = np.flatnonzero(res.best_idx == N.IDX_MISS)
+        if self.long:  # the windows' texts (k bytes each) stand where the packed words do
+            wins = self._wins["fwd" if n1 else "rev"]  # (pairs are matched on the forward mate's window)
+            miss_words = np.ascontiguousarray(wins).view(np.dtype((np.void, self.k))).ravel()
         if miss.size:
             words, first, cnt = np.unique(miss_words[miss], return_index=True, return_counts=True)
             first = miss[first].astype(np.uint64) + np.uint64(first_index)
         else:
-            words, first, cnt = np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.int64)
+            words, first, cnt = miss_words[:0], np.zeros(0, np.uint64), np.zeros(0, np.int64)
         return ChunkResult(n, res.counts, res.first_seen, words, cnt.astype(np.uint64), first, odd_events)
+
+    def _match(self, words, flags, first_index, which):
+        """The GPU lookup of one chunk.  Long barcodes: the exact table is keyed on text hashes, so every hit is held
+        against the barcode's text, and the tallies are taken from the verified hits."""
+        if not self.long:
+            return self.matcher.match(words, flags, self.max_mismatch, self.algo, first_index=first_index)
+        res = self.matcher.match(words, flags, 0, "hash", first_index=first_index)
+        hit = np.flatnonzero(res.best_idx >= 0)
+        if hit.size:
+            same = (self.lib.label_bytes[res.best_idx[hit]] == self._wins[which][hit]).all(axis=1)
+            res.best_idx[hit[~same]] = N.IDX_MISS  # a hash collision with a library entry: not that barcode
+            hit = hit[same]
+        G = self.lib.size
+        res.counts = np.bincount(res.best_idx[hit], minlength=G).astype(np.uint64)
+        res.first_seen = np.full(G, np.iinfo(np.uint64).max, np.uint64)
+        if hit.size:
+            np.minimum.at(res.first_seen, res.best_idx[hit][::-1], (hit[::-1] + first_index).astype(np.uint64))
+        return res
 
 
 class ChunkResult:
@@ -446,7 +487,7 @@ class ChunkResult:
                    zip(seen.tolist(), self.counts[seen].tolist(), self.first_seen[seen].tolist())]
         if self.u_words.size:
             events += [(f, s + "*", c) for s, f, c in
-                       zip(unpack_kmers(self.u_words, cc.k), self.u_first.tolist(), self.u_counts.tolist())]
+                       zip(window_labels(self.u_words, cc.k), self.u_first.tolist(), self.u_counts.tolist())]
         counts = Counter()
         for _f, key, c in sorted(events, key=lambda e: e[0]):
             counts[key] += c
@@ -510,12 +551,12 @@ class PackedCounter:
             cand = np.arange(n)
         # ties resolve towards the earlier first-seen entry, like Counter.most_common on insertion order
         top = cand[np.lexsort((self._first[cand], -c[cand]))][:k]
-        out = [(s + "*", int(v)) for s, v in zip(unpack_kmers(self._words[top], self.k), self._counts[top].tolist())]
+        out = [(s + "*", int(v)) for s, v in zip(window_labels(self._words[top], self.k), self._counts[top].tolist())]
         out += list(self.extra.items())
         return sorted(out, key=lambda kv: -kv[1])[:k]
 
     def items(self):
-        yield from ((s + "*", int(c)) for s, c in zip(unpack_kmers(self.words, self.k), self.counts.tolist()))
+        yield from ((s + "*", int(c)) for s, c in zip(window_labels(self.words, self.k), self.counts.tolist()))
         yield from self.extra.items()
 
 
@@ -561,6 +602,16 @@ def merge_undocumented(tables):
     if not tables:
         z = np.zeros(0, np.uint64)
         return z, z, z
+    if np.asarray(tables[0][0]).dtype.kind == "V":  # windows of more than 32 nt: rows of text instead of packed words
+        w = np.concatenate([t[0] for t in tables])
+        c = np.concatenate([t[1] for t in tables]).astype(np.uint64)
+        f = np.concatenate([t[2] for t in tables]).astype(np.uint64)
+        uw, inv = np.unique(w, return_inverse=True)
+        uc = np.zeros(uw.size, np.uint64)
+        uf = np.full(uw.size, np.iinfo(np.uint64).max, np.uint64)
+        np.add.at(uc, inv, c)
+        np.minimum.at(uf, inv, f)
+        return uw, uc, uf
     if len(tables) == 1 and (tables[0][0].size < 2 or bool((tables[0][0][1:] > tables[0][0][:-1]).all())):
         return tuple(np.asarray(x, np.uint64) for x in tables[0])  # already one sorted table of distinct words
     w = np.concatenate([t[0] for t in tables])
@@ -647,12 +698,13 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     G = len(cc.labels)
     plan = shard_plan(file1, file2, world)
     # the device path takes a single uncompressed file whose start offset is known (not None after sampling)
-    device_ingest = (not is_paired and not file1.endswith((".gz", ".zst")) and (plan == "bytes" or world == 1)
+    # (barcodes of more than 32 nt take the host front half: text hashes + verification, see ChunkCounter._match)
+    device_ingest = (bc_len <= 32 and not is_paired and not file1.endswith((".gz", ".zst")) and (plan == "bytes" or world == 1)
                      and (bc_start2 if need_swap else bc_start1) is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                      and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     # paired-end: two uncompressed files, one process (ranks keep the strided host plan: every rank would need the
     # mates' byte ranges, i.e. a line index of both files)
-    device_pairs = (is_paired and world == 1 and not file1.endswith((".gz", ".zst")) and not file2.endswith((".gz", ".zst"))
+    device_pairs = (bc_len <= 32 and is_paired and world == 1 and not file1.endswith((".gz", ".zst")) and not file2.endswith((".gz", ".zst"))
                     and bc_start1 is not None and bc_start2 is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                     and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     undoc_tables, odd_events = [], []
@@ -760,7 +812,10 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     counts, first_seen = counts[:G], first_seen[:G]
     mine_u = merge_undocumented(undoc_tables)
     if world > 1:  # variable-length leftovers: undocumented windows (padded tensors) and the few odd string events
-        mine_u = merge_undocumented(D.gather_tables(mine_u, device=device))
+        if bc_len > 32:  # rows of text: few enough to pickle
+            mine_u = merge_undocumented(D.gather_objects(mine_u))
+        else:
+            mine_u = merge_undocumented(D.gather_tables(mine_u, device=device))
         odd_events = [e for part in D.gather_objects(odd_events) for e in part]
     uw, uc, uf = mine_u
     # documented: first-seen order (heuristicount.py:876-877 prints Counter insertion order)

@@ -151,8 +151,8 @@ class DeviceLibrary:
         if not seqs:
             raise ValueError("empty barcode library")
         k = len(seqs[0])
-        if k > 32:
-            raise ValueError(f"barcode length {k} > 32 is not supported by the packed matcher")
+        if k > 32:  # exact match through a 64-bit text hash, hits verified against the text (LongDeviceLibrary)
+            return LongDeviceLibrary(seqs, device)
         packed, flags = pack_kmers(seqs, k)
         if flags.any():
             bad = seqs[int(np.flatnonzero(flags)[0])]
@@ -162,6 +162,8 @@ class DeviceLibrary:
     @property
     def size(self) -> int:
         return int(self.packed.size)
+
+    long = False  # LongDeviceLibrary: barcodes of more than 32 nt
 
     @property
     def last_kernel(self) -> str:
@@ -178,3 +180,27 @@ class DeviceLibrary:
             self.close()
         except Exception:
             pass
+
+
+class LongDeviceLibrary(DeviceLibrary):
+    """Barcodes of 33 ... 1000 nt (heuristicount.py:75-97 admits them; its set lookup, :449-453, does not care about
+    length).  The device holds the 64-bit hash of every barcode as a pseudo 32-mer — exact table only — and the caller
+    verifies every hit against `label_bytes`, so a hash collision can cost a lookup, never a wrong count."""
+    long = True
+
+    def __init__(self, seqs, device: int = 0):
+        from .encoding import hash_kmers
+        seqs = list(seqs)
+        k = len(seqs[0])
+        if k > 1000:
+            raise ValueError(f"barcode length {k} > 1000")  # heuristicount.py:88-94
+        blob = "".join(seqs).encode("ascii", errors="replace")
+        self.label_bytes = np.frombuffer(blob, np.uint8).reshape(len(seqs), k)
+        if not np.isin(self.label_bytes, np.frombuffer(b"ACGT", np.uint8)).all():
+            bad = next(s for s in seqs if not set(s) <= set("ACGT"))
+            raise ValueError(f"library entry {bad!r} is not pure upper-case ACGT")
+        hashes = hash_kmers(seqs, k)
+        if np.unique(hashes).size != hashes.size:
+            raise ValueError("two barcodes share a 64-bit hash (a 2^-64 event per pair): cannot index this library")
+        super().__init__(hashes, 32, device, labels=seqs)
+        self.text_k = k

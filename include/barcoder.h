@@ -128,6 +128,21 @@ int bc_reader_next(bc_reader *r, uint64_t max_reads, char *h_text, uint64_t text
                    uint64_t *h_off /* max_reads + 1 */, uint64_t *n_out);
 int bc_reader_close(bc_reader *r);
 
+/* ---- barcodes of 33 ... 1000 nt (exact match) ---------------------------------
+ * heuristicount.py:75-97 admits barcodes up to 1 000 nt and its set lookup
+ * (:449-453) is length-agnostic; the packed matcher holds 32 bases.  Longer
+ * windows are matched through a 64-bit hash of the oriented barcode text — a
+ * pseudo 32-mer for the GPU's exact table (bc_lib_create with k = 32 over
+ * bc_hash_kmers of the library) — and every hit is verified against the text.
+ * bc_hash_windows = bc_pack_windows for such windows: same N-skip / slice / flank
+ * rules and status codes; h_out[i] = hash of the barcode as the library spells
+ * it (reverse-complemented when `reverse`), h_windows[i*k .. i*k+k) = that text
+ * (both only for status BC_WIN_OK). */
+int bc_hash_kmers(const char *h_seqs, size_t n, int k, uint64_t *h_out);
+int bc_hash_windows(const char *h_text, const uint64_t *h_off, size_t n_reads, int64_t start,
+                    const char *L, int L_len, const char *R, int R_len, int k, int reverse,
+                    int n_threads, uint64_t *h_out, uint8_t *h_status, char *h_windows);
+
 /* ---- a reads file straight through the device --------------------------------
  * bc_stream_count_file: everything process_chunk does per read
  * (heuristicount.py:428-562) for the records of an UNCOMPRESSED .reads / .fastq

@@ -132,3 +132,68 @@ def test_cli_twin(gpu_device, tmp_path):
     assert out.returncode == 0, out.stderr[-500:]
     assert out.stdout == s["stdout"]
     assert "Total Reads" in out.stderr and "Documented Barcode Reads" in out.stderr
+
+
+@pytest.mark.parametrize("k", [40, 120])
+def test_barcodes_longer_than_32_nt(gpu_device, oracle, tmp_path, k):
+    """heuristicount.py:75-97 admits barcodes up to 1 000 nt and its set lookup (:449-453) does not care about their
+    length; the packed matcher holds 32 bases.  Longer barcodes go through a text hash in the GPU's exact table with
+    every hit verified against the text: forward, reverse and paired chunks (N reads, short reads, odd characters,
+    unknown barcodes, disagreeing mates) must give the Counter — key order included — of the oracle's restatement
+    of process_chunk, and main() the stdout that restatement implies."""
+    import random
+    from barcoder_amd import heuristicount as H
+    rng = random.Random(7 + k)
+    lib = list(dict.fromkeys("".join(rng.choice("ACGT") for _ in range(k)) for _ in range(400)))
+    Lf, Rf = "CCGGATTCAG", "GTTTTAGAGC"
+    Lr, Rr = _rc(Rf), _rc(Lf)
+    fwd, mates = [], []
+    for i in range(6000):
+        bc = rng.choice(lib) if rng.random() > 0.12 else "".join(rng.choice("ACGT") for _ in range(k))
+        mid = Lf + bc + Rf
+        a = "".join(rng.choice("ACGT") for _ in range(5)) + mid + "".join(rng.choice("ACGT") for _ in range(rng.randrange(6)))
+        b = "".join(rng.choice("ACGT") for _ in range(3)) + _rc(mid) + "".join(rng.choice("ACGT") for _ in range(rng.randrange(6)))
+        v = rng.random()
+        if v < 0.02:
+            p = rng.randrange(len(a)); a = a[:p] + "N" + a[p + 1:]
+        elif v < 0.04:
+            p = rng.randrange(len(b)); b = b[:p] + "N" + b[p + 1:]
+        elif v < 0.06:
+            a = a[:rng.randrange(len(a))]
+        elif v < 0.08:   # an odd character inside the barcode of one mate
+            p = 15 + rng.randrange(k); a = a[:p] + "a" + a[p + 1:]
+        elif v < 0.10:   # the same odd character mirrored in both mates
+            j = rng.randrange(k)
+            a = a[:15 + j] + "a" + a[15 + j + 1:]
+            q = 3 + len(Rf) + (k - 1 - j); b = b[:q] + "a" + b[q + 1:]
+        elif v < 0.12:   # mates that disagree
+            b = b[:3] + _rc(Lf + rng.choice(lib) + Rf) + b[3 + len(mid):]
+        elif v < 0.13:   # one substitution away from a library entry: undocumented (exact match only)
+            p = 15 + rng.randrange(k); a = a[:p] + ("A" if a[p] != "A" else "C") + a[p + 1:]
+        fwd.append(a); mates.append(b)
+    fset = {Lf + x + Rf for x in lib}
+    rset = {Lr + _rc(x) + Rr for x in lib}
+    for name, chunk, swap in (("forward", (fwd, None), False), ("reverse", (None, mates), False),
+                              ("paired", (fwd, mates), False), ("paired swapped", (mates, fwd), True)):
+        got, n = H.process_chunk(chunk, fset, rset, 5, 3, k, Lf, Rf, Lr, Rr, swap, device=gpu_device)
+        want, n2 = oracle.process_chunk_py(chunk, lib, 5, 3, k, Lf, Rf, Lr, Rr, swap)
+        assert n == n2 == 6000, name
+        assert list(got.items()) == list(want.items()), name
+        assert sum(v for key, v in got.items() if not key.endswith("*")) > 3500, name
+        assert any(key.endswith("*") for key in got), name
+    with pytest.raises(ValueError, match="at most 32 nt"):
+        H.ChunkCounter(lib, k, 5, 3, Lf, Rf, Lr, Rr, False, device=gpu_device, max_mismatch=1)
+    # the driver: sampling finds offset and flanks for long barcodes too, stdout in first-seen order
+    fa = tmp_path / "long.fasta"
+    fa.write_text("".join(f">b{i}\n{s}\n" for i, s in enumerate(lib)))
+    rd = tmp_path / "long.reads"
+    rd.write_text("".join(r + "\n" for r in fwd))
+    r = H.count_barcodes(str(fa), str(rd), device=gpu_device)
+    assert (r["bc_start1"], r["flanks_fwd"]) == (15, (Lf, Rf))
+    want, _ = oracle.process_chunk_py((fwd, None), lib, 5, None, k, Lf, Rf, None, None, False)
+    assert list(r["doc"].items()) == [(key, v) for key, v in want.items() if not key.endswith("*")]
+    assert dict(r["undoc"].items()) == {key: v for key, v in want.items() if key.endswith("*")}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        H.main(types.SimpleNamespace(fasta_file=str(fa), file1=str(rd), file2=None), device=gpu_device)
+    assert buf.getvalue() == "".join(f"{key}\t{v}\n" for key, v in want.items() if not key.endswith("*"))
