@@ -1760,10 +1760,15 @@ int ensure_pair_index(bc_lib* lib) {
 int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
                  int max_mm, int algo, const MatchOut& o_in, hipStream_t st);
 
-// max_mismatch = 3 as a cascade.  Fully asynchronous, no workspace: the complete d <= 2 pass (results + its tally,
-// from the wave matcher's records) runs first; the second stage then walks best_idx, takes the reads still marked
-// BC_IDX_MISS through the pair index, writes their results in place and tallies its hits with device atomics.
-int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o_in, hipStream_t st) {
+// A budget as a cascade: the complete pass at max_mm - 1 (results + its tally) runs first — a guide within fewer
+// substitutions, once found, is the best hit under any larger budget, with the same tie count — then the second
+// stage walks best_idx, takes the reads still marked BC_IDX_MISS through the pair index at max_mm, writes their results
+// in place and tallies its hits with device atomics.  Fully asynchronous, no workspace.  Used for max_mm = 3 (the
+// four 5-base seeds of a 20-mer put ~G / 1024 guides in a bucket) and for max_mm = 2 on libraries whose single-segment
+// buckets are too long for the wave matcher (above ~6.5e5 20-mers: 7 / 7 / 6-base seeds cannot grow with the library,
+// the pair index's keys can).  The first pass may itself be a cascade.
+int launch_cascade(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, int max_mm, const MatchOut& o_in,
+                   hipStream_t st) {
     const uint64_t CH = 1ull << 31;  // positions travel as 32-bit values inside the second stage
     for (uint64_t a = 0; a < n; a += CH) {
         const uint64_t m = std::min(CH, n - a);
@@ -1773,12 +1778,12 @@ int launch_cascade3(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags
         if (o.n_best) o.n_best += a;
         o.base += a;
         o.part = PartOut{};
-        int rc = launch_match(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, 2, BC_ALGO_SEED, o, st);
+        int rc = launch_match(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, max_mm - 1, BC_ALGO_SEED, o, st);
         if (rc != BC_OK) return rc;
-        rc = launch_cascade_stage2(lib, 3, d_reads + a, m, o, st);
+        rc = launch_cascade_stage2(lib, max_mm, d_reads + a, m, o, st);
         if (rc != BC_OK) return rc;
     }
-    note_kernel(lib, "cascade3:d2+k_match_pairs");
+    note_kernel(lib, max_mm == 3 ? "cascade3:d2+k_match_pairs" : "cascade2:d1+k_match_pairs");
     return BC_OK;
 }
 
@@ -1797,7 +1802,19 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     if (algo == BC_ALGO_SEED && max_mm == 3 && lib->knobs.cascade) {
         int rc = ensure_pair_index(lib);
         if (rc != BC_OK) return rc;
-        if (lib->knobs.cascade == 1 && lib->d_pairs && aligned16(o_in.best_idx)) return launch_cascade3(lib, d_reads, d_flags, n, o_in, st);
+        if (lib->knobs.cascade == 1 && lib->d_pairs && aligned16(o_in.best_idx)) return launch_cascade(lib, d_reads, d_flags, n, 3, o_in, st);
+    }
+    // d = 2 on a library the wave matcher cannot serve at d = 2 (buckets above 40 guides) but can at d = 1: the d <= 1
+    // pass, then the pair index for the rest, instead of the previous-generation quad kernels over every read
+    // (measured at 7e5 / 1e6 20-mers: see profiles/r03_sweep_G_d.txt)
+    if (algo == BC_ALGO_SEED && max_mm == 2 && lib->knobs.cascade == 1 && lib->knobs.lane && aligned16(o_in.best_idx)) {
+        int q01, q2;
+        const bool vec_ok = vector_io_ok(d_reads, o_in, n);
+        if (!wave_kernel_serves(lib, 2, algo, vec_ok, &q01, &q2) && wave_kernel_serves(lib, 1, algo, vec_ok, &q01, &q2)) {
+            int rc = ensure_pair_index(lib);
+            if (rc != BC_OK) return rc;
+            if (lib->d_pairs) return launch_cascade(lib, d_reads, d_flags, n, 2, o_in, st);
+        }
     }
     // tally: in-kernel global atomics for small launches; otherwise LDS-privatised, from the matcher's range-partitioned
     // records (k_hist_part) when the kernel that runs can write them, else by sweeping best_idx once per range (k_hist)

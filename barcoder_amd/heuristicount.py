@@ -343,16 +343,22 @@ class ChunkCounter:
         # entries that cannot be 2-bit packed can only ever equal an ODD window (host string compare); the packer's
         # flags say which (one native pass instead of a Python test per entry)
         same = [b for b in ordered if len(b) == bc_len]
+        packed = None
         if same and bc_len <= 32:
-            _pk, bad = pack_kmers(same, bc_len)
-            self.labels = [b for b, f in zip(same, bad.tolist()) if not f] if bad.any() else same
+            packed, bad = pack_kmers(same, bc_len)
+            if bad.any():
+                self.labels, packed = [b for b, f in zip(same, bad.tolist()) if not f], packed[bad == 0]
+            else:
+                self.labels = same
         else:
             self.labels = [b for b in same if set(b) <= set("ACGT")]
         # the flanked string sets are needed for odd windows only: built when the first one turns up
         self._fwd_set, self._rev_set = fwd_set, rev_set
         if not self.labels:
             raise ValueError("no pure-ACGT barcode of the stated length in the library")
-        self.lib = DeviceLibrary.from_strings(self.labels, device)
+        # (the labels are distinct and already packed: no second pass over the strings)
+        self.lib = DeviceLibrary(packed, bc_len, device, labels=self.labels) if packed is not None else \
+            DeviceLibrary.from_strings(self.labels, device)
         self.matcher = GpuMatcher(self.lib)
 
     @property

@@ -171,7 +171,7 @@ def test_wave_kernel_geometries_at_scale(gpu_device, oracle, k, G):
         if (k, d) not in ((12, 2), (16, 2)):
             assert dl.last_kernel == "k_match_wq", (k, d, dl.last_kernel)
         else:
-            assert dl.last_kernel in ("k_match_wq", "k_match_fused", "k_match_slab", "k_match_seed")
+            assert dl.last_kernel in ("k_match_wq", "k_match_fused", "k_match_slab", "k_match_seed", "cascade2:d1+k_match_pairs")
 
 
 def test_tally_hot_guides(gpu_device):
@@ -503,6 +503,21 @@ def test_record_tally_many_ranges(gpu_device, G, d, algo):
         pos[pos == G] = 0
         want = np.where(lib[order][pos] == reads, order[pos], -1).astype(np.int32)
         np.testing.assert_array_equal(res.best_idx, want)
+    else:  # a prefix against the indexed oracle (1.2e6 guides at d = 2 run as a cascade: d <= 1 pass, then the pair index)
+        m = 150_000
+        sh = np.arange(k, dtype=np.uint64)
+        letters = np.frombuffer(b"ACGT", np.uint8)
+
+        def ascii_of(p):
+            q = np.ascontiguousarray(p, np.uint64)[:, None]
+            return letters[((q >> sh) & np.uint64(1)).astype(np.uint8) | (((q >> (sh + np.uint64(32))) & np.uint64(1)).astype(np.uint8) << 1)]
+        from oracle import oracle as orc
+        ref = orc.best_hit_arrays(ascii_of(lib), ascii_of(reads[:m] & E.kmer_mask(k)), d, indexed=True)
+        np.testing.assert_array_equal(res.best_idx[:m], ref["best_idx"])
+        np.testing.assert_array_equal(res.best_dist[:m], ref["best_dist"])
+        np.testing.assert_array_equal(res.n_best[:m], ref["n_best"])
+        if (G, d) == (1_200_000, 2):
+            assert dl.last_kernel == "cascade2:d1+k_match_pairs"
     np.testing.assert_array_equal(res.counts, np.bincount(res.best_idx[hit], minlength=G).astype(np.uint64))
     first = np.full(G, np.iinfo(np.uint64).max, np.uint64)
     idx = np.flatnonzero(hit)
