@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """PAM site scan timing (BASELINE configs[3]): NGG over a synthetic genome of
 E. coli size (4,641,652 bp, seed 4, circular) and over a 3.1e9-bp genome to show
-the HBM-bound regime.  Device-resident inputs; wall clock around `iters`
-back-to-back launches with one sync.  usage: python profiles/pam_bench.py"""
+the HBM-bound regime.  Device-resident inputs; HIP events around `iters` launches
+issued back to back from C (bc_pam_scan_time_dev), and — for comparison — the wall
+clock around a Python loop of the same launches (the host's launch rate, which is
+what round 2 reported).  usage: python profiles/pam_bench.py"""
 import ctypes as C, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,11 +32,15 @@ for label, n, iters in (("ecoli_size", 4_641_652, 2000), ("3.1e9_bp", 3_100_000_
         for _ in range(iters):
             N.check(L.bc_pam_scan_dev(d_b.ptr, d_i.ptr, total, N.ptr(masks), 3, d_f.ptr, d_r.ptr, None))
         N.check(L.bc_dev_sync(None))
-        dt = (time.perf_counter() - t0) / iters
+        host_dt = (time.perf_counter() - t0) / iters
+        ms = C.c_float(0)
+        N.check(L.bc_pam_scan_time_dev(d_b.ptr, d_i.ptr, total, N.ptr(masks), 3, d_f.ptr, d_r.ptr, iters, None, C.byref(ms)))
+        dt = ms.value * 1e-3
         fwd = d_f.to_numpy(np.uint32)
         sites = int(np.unpackbits(fwd.view(np.uint8)).sum()) if nw < 10_000_000 else None
     byts = nw * (8 + 4 + 4 + 4)
     out.append({"genome": label, "bp": n, "us_per_scan": round(dt * 1e6, 2), "Gbp_per_s": round(n / dt / 1e9, 2),
+                "timing": "HIP events, launches issued from C", "python_loop_us_per_launch": round(host_dt * 1e6, 2),
                 "algorithmic_GB_per_s": round(byts / dt / 1e9, 1), "frac_of_8TBps": round(byts / dt / 8e12, 4),
                 "fwd_sites": sites})
 if True:
@@ -43,6 +49,19 @@ if True:
     P.find_sites(g, "NGG", 20)
     t0 = time.perf_counter()
     st = P.find_sites(g, "NGG", 20)
-    out.append({"pipeline": "find_sites NGG/20 both strands incl. H2D/D2H", "ms": round((time.perf_counter() - t0) * 1e3, 2),
-                "sites": int(st.start.size)})
+    out.append({"pipeline": "find_sites NGG/20 both strands incl. H2D/D2H (two launches: bc_pam_sites_count_dev / _emit_dev)",
+                "ms": round((time.perf_counter() - t0) * 1e3, 2), "sites": int(st.start.size)})
+    t0 = time.perf_counter()
+    st2 = P.find_sites_staged(g, "NGG", 20)
+    out.append({"pipeline": "the same from separate stages (six launches, round 2's form)",
+                "ms": round((time.perf_counter() - t0) * 1e3, 2), "sites": int(st2.start.size)})
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5):
+        P.find_sites(g, "NGG", 20)
+    pr.disable()
+    buf = io.StringIO()
+    pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(8)
+    print(buf.getvalue(), file=sys.stderr)
 print(json.dumps(out, indent=1))
