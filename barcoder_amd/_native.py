@@ -107,6 +107,8 @@ SIGNATURES = {
     "bc_dev_h2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "bc_dev_d2h": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "bc_dev_sync": (C.c_int, [vp]),
+    "bc_host_alloc_pinned": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+    "bc_host_free_pinned": (C.c_int, [vp]),
     "bc_match_time_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp,
                                     C.POINTER(C.c_float)]),
 }

@@ -2627,6 +2627,13 @@ int bc_dev_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream) {
     BC_HIP(hipStreamSynchronize((hipStream_t)stream));
     return BC_OK;
 }
+int bc_host_alloc_pinned(void** h_ptr, size_t bytes) {
+    if (!h_ptr) { set_error("bc_host_alloc_pinned: null"); return BC_EINVAL; }
+    hipError_t e = hipHostMalloc(h_ptr, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return BC_ENOMEM; }
+    return BC_OK;
+}
+int bc_host_free_pinned(void* h_ptr) { BC_HIP(hipHostFree(h_ptr)); return BC_OK; }
 int bc_dev_sync(void* stream) {
     if (stream) BC_HIP(hipStreamSynchronize((hipStream_t)stream));
     else BC_HIP(hipDeviceSynchronize());

@@ -18,7 +18,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _native as N
-from .devmem import DevBuf
+from .devmem import DevBuf, PinnedBlock
 from .encoding import pam_masks, unpack_kmers
 from .library import read_fasta_records
 
@@ -120,15 +120,17 @@ def find_sites(g: PackedGenome, pam: str, k: int, direction: str = "downstream",
             N.check(L.bc_pam_sites_emit_dev(d_in.ptr, _at(d_in.ptr, o_inv), g.total, N.ptr(masks), pl, k, dirn,
                                             _at(d_in.ptr, o_cnt), _at(d_out.ptr, o_pos), d_out.ptr, n,
                                             _at(d_out.ptr, ((n * 12 + 15) // 16) * 16), None))
-            raw = np.empty(n * 12, np.uint8)
+            host = PinnedBlock(n * 12 + 16)  # page-locked: the copy runs at the link's rate; the views below keep it alive
             if n:
-                N.check(L.bc_dev_d2h(N.ptr(raw), d_out.ptr, n * 12, None))
-    words = raw[:n * 8].view(np.uint64)
-    pos = raw[n * 8:].view(np.uint32).astype(np.int64)
+                N.check(L.bc_dev_d2h(host.ptr, d_out.ptr, n * 12, None))
+    words = host.array(np.uint64, n)
+    pos = host.array(np.uint32, n, n * 8).astype(np.int64)
     strand = np.zeros(n, np.uint8)
     strand[n_f:] = 1
-    off = np.where(strand == 0, -k if dirn == 0 else pl, pl if dirn == 0 else -k)
-    return Sites(pos + off, strand, words.copy(), pos)
+    start = pos.copy()
+    start[:n_f] += -k if dirn == 0 else pl
+    start[n_f:] += pl if dirn == 0 else -k
+    return Sites(start, strand, words, pos)
 
 
 def find_sites_staged(g: PackedGenome, pam: str, k: int, direction: str = "downstream", device: int = 0,

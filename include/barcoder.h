@@ -444,6 +444,10 @@ int bc_dev_memset(void *d_ptr, int value, size_t bytes, void *stream);
 int bc_dev_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int bc_dev_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int bc_dev_sync(void *stream);
+/* page-locked host memory: a D2H / H2D copy to or from it runs at the link's rate
+ * and needs no staging copy inside the runtime */
+int bc_host_alloc_pinned(void **h_ptr, size_t bytes);
+int bc_host_free_pinned(void *h_ptr);
 
 /* ---- timing of the dominant kernel (bench.py roofline) --------------------
  * Runs bc_match_dev `iters` times on `stream` bracketed by HIP events recorded
