@@ -12,8 +12,9 @@
 //                    the exact stage); a wave owns 256 reads, quad-cooperative slab loads for
 //                    the full-width stages, a quad work list for the sparse ones, a filter line
 //                    in front of table 2.
-//   cascade (d = 3): k_match_wq at d <= 2 over every read, then the reads it left through the
-//                    pair-of-pieces index (k_match_pairs, bc_match_pairs.hip); launch_cascade3.
+//   cascade (d = 3): the whole d <= 2 pass over every read, then k_cascade_stage2 (bc_match_pairs.hip): the reads
+//                    still marked BC_IDX_MISS through the pair-of-pieces index, in place; launch_cascade.  Also d = 2 on
+//                    libraries whose buckets are too long for the wave matcher (d <= 1 pass + pair index).
 //   k_match_fused  : previous generation (bc_match_quad.hip: hash stage + LDS queue + DPP quad per
 //                    queued read): buckets above 40 guides (libraries above ~6.5e5 20-mers), BC_LANE=0.
 //   k_match_slab   : the slab index as one simple kernel (small / unaligned inputs, d = 0 via seed).
@@ -432,6 +433,9 @@ __device__ __forceinline__ void slab_slow_wide(const SlabParams& sp, uint32_t rl
 // ---------------------------------------------------------------------------
 constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 64 drains first when fewer are free
 
+// (amdgpu_waves_per_eu(6) is a register-budget floor — at least six waves per SIMD, i.e. at most 80 VGPRs — not the
+// occupancy: the kernel uses 55 VGPRs and 5.5 KiB of LDS per single-wave workgroup, so 29 workgroups fit a CU's 160 KiB:
+// seven waves per SIMD run.)
 template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01, bool FAST = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wq(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,

@@ -329,7 +329,7 @@ class ChunkCounter:
     geometry.  One instance serves every chunk of a run."""
 
     def __init__(self, barcodes, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
-                 device: int = 0, max_mismatch: int = 0, algo: str = "auto", fwd_set=None, rev_set=None):
+                 device: int = 0, max_mismatch: int = 0, algo: str = "auto", fwd_set=None, rev_set=None, lib=None):
         self.k = bc_len
         # more than 32 nt: exact match through a text hash, hits verified against the text (LongDeviceLibrary)
         self.long = bc_len > 32
@@ -340,26 +340,34 @@ class ChunkCounter:
         self.max_mismatch, self.algo = max_mismatch, algo
         ordered = list(dict.fromkeys(barcodes))
         self._ordered = ordered
-        # entries that cannot be 2-bit packed can only ever equal an ODD window (host string compare); the packer's
-        # flags say which (one native pass instead of a Python test per entry)
+        # the flanked string sets are needed for odd windows only: built when the first one turns up
+        self._fwd_set, self._rev_set = fwd_set, rev_set
+        # the device library depends on the barcodes alone, not on the geometry: a caller may have started building it
+        # before the geometry was known (count_barcodes does, under the sampling pass)
+        self.lib = lib if lib is not None else self.device_library(ordered, bc_len, device)
+        self.labels = self.lib.labels
+        self.matcher = GpuMatcher(self.lib)
+
+    @staticmethod
+    def device_library(ordered, bc_len, device: int = 0):
+        """The library in HBM for a de-duplicated barcode list: entries that cannot be 2-bit packed (wrong length, a
+        character outside ACGT) are left out — they can only ever equal an ODD window, which the host compares as a
+        string; the packer's flags say which (one native pass instead of a Python test per entry)."""
         same = [b for b in ordered if len(b) == bc_len]
         packed = None
         if same and bc_len <= 32:
             packed, bad = pack_kmers(same, bc_len)
             if bad.any():
-                self.labels, packed = [b for b, f in zip(same, bad.tolist()) if not f], packed[bad == 0]
+                labels, packed = [b for b, f in zip(same, bad.tolist()) if not f], packed[bad == 0]
             else:
-                self.labels = same
+                labels = same
         else:
-            self.labels = [b for b in same if set(b) <= set("ACGT")]
-        # the flanked string sets are needed for odd windows only: built when the first one turns up
-        self._fwd_set, self._rev_set = fwd_set, rev_set
-        if not self.labels:
+            labels = [b for b in same if set(b) <= set("ACGT")]
+        if not labels:
             raise ValueError("no pure-ACGT barcode of the stated length in the library")
         # (the labels are distinct and already packed: no second pass over the strings)
-        self.lib = DeviceLibrary(packed, bc_len, device, labels=self.labels) if packed is not None else \
-            DeviceLibrary.from_strings(self.labels, device)
-        self.matcher = GpuMatcher(self.lib)
+        return DeviceLibrary(packed, bc_len, device, labels=labels) if packed is not None else \
+            DeviceLibrary.from_strings(labels, device)
 
     @property
     def fwd_set(self):
@@ -662,44 +670,57 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     is_paired = bool(file2)
     log.info("Sampling reads to identify diversity characteristics...")
     ordered = ordered_lines
-    smp = NativeSample(file1, file2, ordered, is_paired)
-    bc_start1, bc_start2, need_swap = smp.offset1, smp.offset2, smp.need_swap
-    log.info("Sampled %s diverse contexts in %s chunks and found %s barcodes in %s forward and %s reverse reads...",
-             f"{smp.n_novel:,}", smp.num_chunks, f"{smp.n_observed:,}", f"{smp.n_valid1:,}", f"{smp.n_valid2:,}")
-    fwd_name = os.path.basename(file1)
-    rev_name = os.path.basename(file2) if file2 else None
-    if need_swap:
-        log.info("Swapping orientation...")
-        fwd_name, rev_name = rev_name, fwd_name
-    log.info("Identifying flanking sequences...")
-    # sample1 / sample2 are never None in the reference (empty sets at worst): heuristicount.py:626-638
-    L_fwd, R_fwd = smp.flanks(0, bc_start1, bc_len)
-    L_fwd_start = bc_start1 - len(L_fwd) if L_fwd else 0
-    L_rev, R_rev = smp.flanks(1, bc_start2, bc_len)
-    L_rev_start = bc_start2 - len(L_rev) if L_rev else 0
-    smp.close()
-    # the two mates must show reverse-complementary flanks (heuristicount.py:641-688)
-    L_rev_rc = rev_comp(L_rev) if L_rev else None
-    R_rev_rc = rev_comp(R_rev) if R_rev else None
-    violated = False
-    if L_fwd and R_rev_rc:
-        m = min(len(L_fwd), len(R_rev_rc))
-        violated |= L_fwd[-m:] != R_rev_rc[:m]
-    if R_fwd and L_rev_rc:
-        m = min(len(R_fwd), len(L_rev_rc))
-        violated |= R_fwd[:m] != L_rev_rc[:m]
-    if violated:
-        log.warning("Expected complemtarity not found for flanking sequences...")
+    # the device library needs the barcodes only: it is built (GPU start-up included) on a second thread while the
+    # sampling pass — pure host work inside one native call, the GIL released — discovers the geometry
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
+    t_lib0 = _time.perf_counter()
+    lib_future = pool.submit(lambda: (ChunkCounter.device_library(ordered, bc_len, device), _time.perf_counter()))
+    try:
+        smp = NativeSample(file1, file2, ordered, is_paired)
+        bc_start1, bc_start2, need_swap = smp.offset1, smp.offset2, smp.need_swap
+        log.info("Sampled %s diverse contexts in %s chunks and found %s barcodes in %s forward and %s reverse reads...",
+                 f"{smp.n_novel:,}", smp.num_chunks, f"{smp.n_observed:,}", f"{smp.n_valid1:,}", f"{smp.n_valid2:,}")
+        fwd_name = os.path.basename(file1)
+        rev_name = os.path.basename(file2) if file2 else None
+        if need_swap:
+            log.info("Swapping orientation...")
+            fwd_name, rev_name = rev_name, fwd_name
+        log.info("Identifying flanking sequences...")
+        # sample1 / sample2 are never None in the reference (empty sets at worst): heuristicount.py:626-638
+        L_fwd, R_fwd = smp.flanks(0, bc_start1, bc_len)
+        L_fwd_start = bc_start1 - len(L_fwd) if L_fwd else 0
+        L_rev, R_rev = smp.flanks(1, bc_start2, bc_len)
+        L_rev_start = bc_start2 - len(L_rev) if L_rev else 0
+        smp.close()
+        # the two mates must show reverse-complementary flanks (heuristicount.py:641-688)
+        L_rev_rc = rev_comp(L_rev) if L_rev else None
+        R_rev_rc = rev_comp(R_rev) if R_rev else None
+        violated = False
         if L_fwd and R_rev_rc:
-            log.info("Left flank:  '%s' (./%s) != '%s' (./%s revcomp)", L_fwd, fwd_name, R_rev_rc, rev_name)
+            m = min(len(L_fwd), len(R_rev_rc))
+            violated |= L_fwd[-m:] != R_rev_rc[:m]
         if R_fwd and L_rev_rc:
-            log.info("Right flank: '%s' (./%s) != '%s' (./%s revcomp)", R_fwd, fwd_name, L_rev_rc, rev_name)
-        raise ValueError("A critical error occurred: Flank complementarity violation")
+            m = min(len(R_fwd), len(L_rev_rc))
+            violated |= R_fwd[:m] != L_rev_rc[:m]
+        if violated:
+            log.warning("Expected complemtarity not found for flanking sequences...")
+            if L_fwd and R_rev_rc:
+                log.info("Left flank:  '%s' (./%s) != '%s' (./%s revcomp)", L_fwd, fwd_name, R_rev_rc, rev_name)
+            if R_fwd and L_rev_rc:
+                log.info("Right flank: '%s' (./%s) != '%s' (./%s revcomp)", R_fwd, fwd_name, L_rev_rc, rev_name)
+            raise ValueError("A critical error occurred: Flank complementarity violation")
 
-    log.info("Executing high-throughput read analysis...")
-    t_sampled = _time.perf_counter()
+        log.info("Executing high-throughput read analysis...")
+        t_sampled = _time.perf_counter()
+        dev_lib, t_lib_done = lib_future.result()
+    except BaseException:
+        lib_future.cancel()  # (a build already running finishes on its thread and is dropped)
+        raise
+    finally:
+        pool.shutdown(wait=True)
     cc = ChunkCounter(ordered, bc_len, L_fwd_start, L_rev_start, L_fwd, R_fwd, L_rev, R_rev, need_swap,
-                      device=device, max_mismatch=max_mismatch)
+                      device=device, max_mismatch=max_mismatch, lib=dev_lib)
     t_lib = _time.perf_counter()
     G = len(cc.labels)
     plan = shard_plan(file1, file2, world)
@@ -841,7 +862,8 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
                 bc_start1=bc_start1, bc_start2=bc_start2, flanks_fwd=(L_fwd, R_fwd), flanks_rev=(L_rev, R_rev),
                 need_swap=need_swap, forward_name=fwd_name, reverse_name=rev_name, shard_plan=plan,
                 bulk_mreads_per_s=(n_mine[0] / t_bulk[0] / 1e6 if t_bulk[0] > 0 else None),
-                seconds=dict(sampling=t_sampled - t_start, library=t_lib - t_sampled, bulk=t_bulk[0],
+                seconds=dict(sampling=t_sampled - t_start, library=t_lib - t_sampled,
+                             library_build_overlapped=t_lib_done - t_lib0, bulk=t_bulk[0],
                              merge=_time.perf_counter() - t_lib - t_bulk[0]))
 
 
