@@ -303,7 +303,7 @@ struct WindowStore {
     uint64_t cap = 0, estimate = 0;
     std::shared_mutex m;
     int grow(uint64_t need) {  // caller holds the exclusive lock
-        const uint64_t ncap = std::max<uint64_t>(std::max<uint64_t>(cap * 2, need + 65536), estimate);
+        const uint64_t ncap = std::max<uint64_t>(std::max<uint64_t>(cap * 2, need + (estimate && estimate < need ? 16 : 65536)), estimate);
         DevBuf np_, ns;
         int rc;
         if ((rc = np_.reserve(ncap * 8)) != BC_OK) return rc;
@@ -435,8 +435,12 @@ int run_file(FileJob& J) {
                     const uint64_t gri0_ = g.fastq ? ((line_base + 2) >> 2) : line_base;
                     const uint64_t gri1_ = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
                     reads_launched += gri1_ - gri0_;
-                    if (store && c == 0)  // size the run-wide arrays from the first chunk's density (+25 %)
-                        store->estimate = (uint64_t)((double)(gri1_ - gri0_) * ((double)span / (double)std::max<uint64_t>(core_hi - core_lo, 1)) * 1.25) + 65536;
+                    if (store && c == 0) {  // size the run-wide arrays from the first chunk's density (+25 %)
+                        const char* e = getenv("BC_STREAM_EST_PCT");  // (tests shrink the estimate to exercise the growth path)
+                        const double pct = e && atoi(e) > 0 ? atoi(e) / 100.0 : 1.25;
+                        store->estimate = (uint64_t)((double)(gri1_ - gri0_) * ((double)span / (double)std::max<uint64_t>(core_hi - core_lo, 1)) * pct) +
+                                          (pct < 1.0 ? 16 : 65536);
+                    }
                     ++next_to_publish;
                 }
                 order_cv.notify_all();

@@ -221,6 +221,8 @@ def test_paired_device_ingest_equals_host_front_half(gpu_device, tmp_path, monke
     assert os.path.getsize(f1) > 17 << 20
     for mm in (0, 1):
         monkeypatch.setenv("BC_DEVICE_INGEST", "1")
+        # (mm = 1: the per-read window arrays start at a tenth of what the file needs and grow under the workers)
+        monkeypatch.setenv("BC_STREAM_EST_PCT", "10" if mm else "125")
         dev = H.count_barcodes(str(fa), f1, f2, device=gpu_device, max_mismatch=mm)
         monkeypatch.setenv("BC_DEVICE_INGEST", "0")
         host = H.count_barcodes(str(fa), f1, f2, device=gpu_device, max_mismatch=mm, chunk_reads=100_003)
