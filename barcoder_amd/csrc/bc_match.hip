@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const uint64_t r = q_read[qi];
             const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
             // the rest of the read with the table picked per lane
-            const uint32_t st = t1 ? T1.start : T0.start, sh = t1 ? T1.start + T1.slen : T0.start + T0.slen;
+            const uint32_t st = t1 ? T1.start : 0u, sh = t1 ? T1.start + T1.slen : T0.slen;  // (table 0's seed starts at base 0)
             const uint32_t hf = t1 ? half1 : half0, hm = t1 ? hm1 : hm0;
             const RestW rest = rest_of<WIDE>(st, sh, hf, rlo, rhi);
             const char* base = FAST ? sp.fast.base : (t1 ? b1 : b0);
@@ -654,11 +654,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             r[j] &= kmask;
         }
         // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
-        auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), T0.start, T0.slen) << S01) : 0u; };
+        // table 0's seed starts at base 0 (build_seed_index; checked when the launch is chosen): with the start a
+        // constant the seed value is two and-s and a shift-or, the rest a shift per plane — phase 1 runs for every read
+        auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), 0, T0.slen) << S01) : 0u; };
         // myoff: the byte offset the read's own slab was fetched from (FAST: the secondary slab has the bucket's number)
         auto finish = [&](int j, const uint4 (&w)[4][NQ01], uint32_t myoff) {
             uint32_t l[4], key = 0xFFFFFFFFu;
-            visit_scan<NQ01, WIDE>(w, rest_of<WIDE>(T0.start, T0.start + T0.slen, half0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)),
+            visit_scan<NQ01, WIDE>(w, rest_of<WIDE>(0u, T0.slen, half0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)),
                                    half0, hm0, s, key, l);
             if (FAST) {  // no link slot: slot 7's index word says whether the bucket goes on
 #pragma unroll
@@ -1605,7 +1607,7 @@ bool wave_kernel_serves(const bc_lib* lib, int max_mm, int algo, bool vec_ok, in
     // table-0/1 slabs of 64 bytes (8 narrow entries) or 128 bytes (16 narrow entries: buckets above 16 guides; or
     // 8 wide entries): one or two 16-byte pieces per lane
     const int nq01 = (int)(((wide ? 16u : 8u) << hp.t[0].log2S) / 64u);
-    bool wave_ok = algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && vec_ok && !lib->knobs.single_slab &&
+    bool wave_ok = algo == BC_ALGO_SEED && lib->slab_ok[max_mm] && vec_ok && !lib->knobs.single_slab && hp.t[0].start == 0u &&
                    lib->knobs.lane && (nseg == 2 || nseg == 3) && hp.t[0].log2S == hp.t[1].log2S &&
                    (nq01 == 1 || nq01 == 2) && !lib->h_nn.empty();
     for (int t = 0; t < nseg && wave_ok; ++t) wave_ok = hp.t[t].empty < (1u << 22);  // slab numbers travel in 22-bit item fields
