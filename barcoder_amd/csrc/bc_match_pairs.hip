@@ -6,7 +6,7 @@
 // k-mer into FIVE pieces instead: a guide within three substitutions leaves at least TWO pieces clean, so it shares
 // one of the C(5,2) = 10 piece pairs with the read.  Table (a, b) is keyed on piece a and the first bases of piece
 // b — about log4(G / 6) bases in all: 16 384 buckets of 6 guides at G = 1e5 — and a read visits ten 64-byte slabs
-// (61 candidates) instead of four chains of seven 128-byte slabs.
+// of fifteen 4-byte rests (61 candidates) instead of four chains of seven 128-byte slabs.
 //
 // A guide with more than two clean pieces sits in several of the read's buckets; it is counted in ONE: the table of
 // the lexicographically first pair of its clean pieces (the entry's mismatch mask tells which pieces are clean), so
@@ -15,7 +15,7 @@
 // only the reads the d <= 2 pass left without a hit arrive.  One lane per read: the stage sees a tenth of the reads
 // and is bound by its ten dependent-free L2 / Infinity-Cache requests per read, not by instructions.
 //
-// Geometry limits: 8-byte entries hold a rest of at most 16 bases per plane, so key >= k - 16 bases; the key is
+// Geometry limits: an entry's rest holds at most 16 bases per plane, so key >= k - 16 bases; the key is
 // capped at 9 bases (10 tables x 262 144 slabs).  k from 8 to 25; other lengths keep the four-segment index.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -59,27 +59,29 @@ __device__ __forceinline__ PairBest pairs_lookup(const PairParams& pp, uint32_t 
         const PairTable& T = pp.t[t];
         const uint32_t rest = pair_rest_plane(T, rlo) | (pair_rest_plane(T, rhi) << 16);
         uint32_t slab = pair_bucket(T, rlo, rhi);
-        while (slab != 0xFFFFFFFFu) {
-            const uint4* p = reinterpret_cast<const uint4*>(T.slabs + (size_t)slab * 8u);
+        for (;;) {
+            const uint4* p = reinterpret_cast<const uint4*>(T.rests + (size_t)slab * 16u);
             const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
-            const uint32_t er[7] = {w0.x, w0.z, w1.x, w1.z, w2.x, w2.z, w3.x};
-            const uint32_t eg[7] = {w0.y, w0.w, w1.y, w1.w, w2.y, w2.w, w3.y};
+            const uint32_t er[15] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z};
+            const uint32_t cnt = w3.w & 15u, next = w3.w >> 4;
 #pragma unroll
-            for (int e = 0; e < 7; ++e) {
+            for (int e = 0; e < 15; ++e) {
                 const uint32_t x = rest ^ er[e];
                 const uint32_t mm = (x | (x >> 16)) & 0xFFFFu;
                 const uint32_t d = (uint32_t)__popc(mm);
                 // counted here only if this table's pair is the first pair of the guide's clean pieces: what is left
                 // of pieces a and b is clean, every earlier piece is dirty
-                bool ok = eg[e] < SLAB_LINK && d <= max_mm && (mm & T.must_clean) == 0u;
+                bool ok = (uint32_t)e < cnt && d <= max_mm && (mm & T.must_clean) == 0u;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) ok = ok && (c >= (int)T.n_other || (mm & T.other[c]) != 0u);
-                if (ok) {
-                    if (d < b.mind) { b.mind = d; b.cnt = 1u; b.bidx = eg[e]; }
-                    else if (d == b.mind) { ++b.cnt; b.bidx = min(b.bidx, eg[e]); }
+                if (ok) {  // rare: a guide within the budget — its index comes from the parallel array
+                    const uint32_t g = T.gidx[(size_t)slab * 16u + (uint32_t)e];
+                    if (d < b.mind) { b.mind = d; b.cnt = 1u; b.bidx = g; }
+                    else if (d == b.mind) { ++b.cnt; b.bidx = min(b.bidx, g); }
                 }
             }
-            slab = (w3.w == SLAB_LINK) ? w3.z : 0xFFFFFFFFu;  // the last slot: link or empty
+            if (!next) break;
+            slab = next;
         }
     }
     return b;
@@ -214,7 +216,7 @@ int build_pair_index(bc_lib* lib) {
     want = std::max(want, k - 16);
     if (want > 9) return BC_OK;
     // the ten tables are independent: one host thread each (50 ms single-threaded at 1e5 guides)
-    struct Built { PairTable T{}; std::vector<uint2> slabs; bool ok = false; };
+    struct Built { PairTable T{}; std::vector<uint32_t> rests, gidx; bool ok = false; };
     Built built[10];
     int pa[10], pb[10], nt = 0;
     for (int a = 0; a < 5; ++a)
@@ -235,8 +237,7 @@ int build_pair_index(bc_lib* lib) {
         T.n_other = 0;
         for (int c = 0; c < b; ++c)
             if (c != a) T.other[T.n_other++] = rest_mask(p_start[c], p_len[c]);
-        // slabs of 7 entries + link, bucket = slab number, overflow slabs appended
-        const uint32_t nb = 1u << (2 * (la + lb));
+        const uint32_t nb = 1u << (2 * (la + lb));  // bucket = slab number, overflow slabs appended
         std::vector<uint32_t> cnt(nb + 1, 0u);
         std::vector<uint32_t> bucket_of(lib->G);
         for (uint32_t g = 0; g < lib->G; ++g) {
@@ -247,26 +248,32 @@ int build_pair_index(bc_lib* lib) {
         for (uint32_t i = 0; i < nb; ++i) cnt[i + 1] += cnt[i];
         std::vector<uint32_t> order(lib->G), fill(cnt.begin(), cnt.end() - 1);
         for (uint32_t g = 0; g < lib->G; ++g) order[fill[bucket_of[g]]++] = g;  // ascending guide index inside a bucket
-        std::vector<uint2>& slabs = built[t].slabs;
-        slabs.assign((size_t)nb * 8, make_uint2(0u, SLAB_EMPTY));
+        // slabs of 15 rests + tail {next << 4 | count}; the guide indices in a parallel array
+        std::vector<uint32_t>& rests = built[t].rests;
+        std::vector<uint32_t>& gix = built[t].gidx;
+        rests.assign((size_t)nb * 16, 0u);
+        gix.assign((size_t)nb * 16, 0u);
         for (uint32_t bkt = 0; bkt < nb; ++bkt) {
             size_t cur = bkt;
             uint32_t pos = 0;
             for (uint32_t j = cnt[bkt]; j < cnt[bkt + 1]; ++j) {
-                if (pos == 7) {
-                    const size_t nxt = slabs.size() / 8;
-                    slabs.resize(slabs.size() + 8, make_uint2(0u, SLAB_EMPTY));
-                    slabs[cur * 8 + 7] = make_uint2((uint32_t)nxt, SLAB_LINK);
+                if (pos == 15) {
+                    const size_t nxt = rests.size() / 16;
+                    rests.resize(rests.size() + 16, 0u);
+                    gix.resize(gix.size() + 16, 0u);
+                    rests[cur * 16 + 15] = ((uint32_t)nxt << 4) | 15u;
                     cur = nxt;
                     pos = 0;
                 }
                 const uint32_t g = order[j];
                 const uint64_t v = lib->h_guides[g];
-                slabs[cur * 8 + pos++] =
-                    make_uint2(pair_rest_plane(T, (uint32_t)v) | (pair_rest_plane(T, (uint32_t)(v >> 32)) << 16), g);
+                rests[cur * 16 + pos] = pair_rest_plane(T, (uint32_t)v) | (pair_rest_plane(T, (uint32_t)(v >> 32)) << 16);
+                gix[cur * 16 + pos] = g;
+                ++pos;
             }
+            rests[cur * 16 + 15] = pos;  // last slab of the bucket: no next
         }
-        if ((slabs.size() / 8) >> 31) return;
+        if ((rests.size() / 16) >> 28) return;  // slab numbers travel in 28 bits
         built[t].T = T;
         built[t].ok = true;
     };
@@ -279,10 +286,12 @@ int build_pair_index(bc_lib* lib) {
     pp.ntab = 0;
     for (int t = 0; t < 10; ++t) {
         if (!built[t].ok) return BC_OK;  // a geometry the 8-byte entries cannot hold: the four-segment index stays
-        uint2* d_slabs;
-        int rc = upload(lib, built[t].slabs, &d_slabs);
+        uint32_t *d_rests, *d_gidx;
+        int rc = upload(lib, built[t].rests, &d_rests);
+        if (rc == BC_OK) rc = upload(lib, built[t].gidx, &d_gidx);
         if (rc != BC_OK) return rc;
-        built[t].T.slabs = d_slabs;
+        built[t].T.rests = d_rests;
+        built[t].T.gidx = d_gidx;
         pp.t[pp.ntab++] = built[t].T;
     }
     std::vector<PairParams> one(1, pp);
