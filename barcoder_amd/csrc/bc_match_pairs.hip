@@ -93,9 +93,12 @@ __device__ __forceinline__ PairBest pairs_lookup(const PairParams& pp, uint32_t 
 // result IN PLACE; hits are tallied with device atomics (5 % of the benchmark's reads).  No compacted copy of the
 // missed reads, no device-side count for the host to wait for, no scatter pass: the launch is asynchronous and needs
 // no workspace.  (Round 2: k_collect_missed 0.40 ms + k_match_pairs 1.49 ms + k_scatter_results 0.26 ms per 1e8
-// reads and a host synchronisation in between.  A quad-per-read form of the lookup — one vector-L1 access per
-// slab — measured 1.84 ms: the stage is bound by 64-byte requests into 13 MB of tables that the L2 does not hold,
-// ~80 G requests/s, not by L1 accesses.)
+// reads and a host synchronisation in between.  Measured and dropped: a quad-per-read form of the lookup — one
+// vector-L1 access per slab instead of four, but four lanes' worth of key arithmetic per read — 1.84 ms against 1.49
+// for the lane-per-read form on the round-2 tables; the primary slabs of five tables requested before the first is
+// scanned (twenty loads in flight per lane, 144 VGPRs, three waves per SIMD): 2.10 ms against 1.67 for one slab at
+// a time at eight waves per SIMD.  The stage sits between three walls at once — L2-missing requests into 10.5 MB
+// of tables (1e8 per 1e7 reads), four L1 tag look-ups per slab, and the scan's VALU work.)
 constexpr int ST2_SUB = 4096;
 __global__ __launch_bounds__(BLOCK) void k_cascade_stage2(const PairParams* __restrict__ ppp, const uint64_t* __restrict__ reads,
                                                          uint64_t n, uint64_t kmask, int max_mm_, int32_t* __restrict__ best_idx,
