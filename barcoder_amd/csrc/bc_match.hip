@@ -2019,13 +2019,40 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
 
 }  // namespace
 
+constexpr int HOST_WORKERS = 6;  // worker threads (and staging slots) of bc_match_host
 struct HostSlot {
     uint64_t cap = 0;
     uint64_t* d_r = nullptr;
     uint8_t *d_f = nullptr, *d_bd = nullptr, *d_nb = nullptr;
     int32_t* d_bi = nullptr;
     hipStream_t st = nullptr;
+    // page-locked staging of one chunk (pageable caller buffers): reads + flags in, index + distance + ties out
+    uint64_t pin_cap = 0;
+    uint64_t* h_r = nullptr;
+    uint8_t *h_f = nullptr, *h_bd = nullptr, *h_nb = nullptr;
+    int32_t* h_bi = nullptr;
 };
+
+static void slot_release(HostSlot& s) {
+    for (void* p : {(void*)s.d_r, (void*)s.d_f, (void*)s.d_bd, (void*)s.d_nb, (void*)s.d_bi}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)s.h_r, (void*)s.h_f, (void*)s.h_bd, (void*)s.h_nb, (void*)s.h_bi}) if (p) (void)hipHostFree(p);
+    if (s.st) (void)hipStreamDestroy(s.st);
+    s = HostSlot{};
+}
+
+static int slot_reserve_pinned(HostSlot& s, uint64_t cap) {
+    if (cap <= s.pin_cap) return BC_OK;
+    for (void* p : {(void*)s.h_r, (void*)s.h_f, (void*)s.h_bd, (void*)s.h_nb, (void*)s.h_bi}) if (p) (void)hipHostFree(p);
+    s.pin_cap = 0;
+    s.h_r = nullptr; s.h_bi = nullptr; s.h_f = s.h_bd = s.h_nb = nullptr;
+    BC_HIP(hipHostMalloc((void**)&s.h_r, cap * 8, hipHostMallocDefault));
+    BC_HIP(hipHostMalloc((void**)&s.h_bi, cap * 4, hipHostMallocDefault));
+    BC_HIP(hipHostMalloc((void**)&s.h_f, cap, hipHostMallocDefault));
+    BC_HIP(hipHostMalloc((void**)&s.h_bd, cap, hipHostMallocDefault));
+    BC_HIP(hipHostMalloc((void**)&s.h_nb, cap, hipHostMallocDefault));
+    s.pin_cap = cap;
+    return BC_OK;
+}
 
 static int slot_reserve(HostSlot& s, uint64_t cap) {
     if (!s.st) BC_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
@@ -2053,14 +2080,6 @@ struct DevMem {
         return BC_OK;
     }
 };
-struct Pinned {
-    std::vector<void*> v;
-    void pin(const void* p, size_t bytes) {
-        if (p && hipHostRegister((void*)p, bytes, hipHostRegisterDefault) == hipSuccess) v.push_back((void*)p);
-        else (void)hipGetLastError();
-    }
-    ~Pinned() { for (void* p : v) (void)hipHostUnregister(p); }
-};
 struct Events {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~Events() {
@@ -2070,31 +2089,30 @@ struct Events {
 };
 
 // Host buffers in, per-read results out to the host; counts / first-seen are left ON THE DEVICE (d_c: uint32[G],
-// d_fs: uint64[G], accumulated over the chunks).  The call is cut into chunks that HOST_WORKERS threads take in
-// turn, each with its own HIP stream and device staging slot (kept in the library object between calls): while one
-// worker copies results back, another uploads the next chunk and a third one's kernels run, so H2D, compute and
-// D2H overlap (PCIe is full duplex).  The caller holds lib->host_mutex.
+// d_fs: uint64[G], accumulated over the chunks).  The call is cut into chunks that worker threads take in turn, each
+// with its own HIP stream, device slot and PAGE-LOCKED staging buffers (kept in the library object between calls):
+// a worker copies its chunk of the caller's (pageable) reads into the staging buffer, uploads, launches, downloads
+// into staging and copies the results out to the caller — so several cores do the host-side copies that the runtime
+// would otherwise do on one, and every DMA runs at the link's rate; while one worker copies, another's transfer and
+// a third one's kernels run (PCIe is full duplex).  Round 2 registered the caller's buffers (hipHostRegister) for the
+// duration of a large call instead: 0.68 G reads/s, most of it the page pinning.  BC_HOST_PIN=0: no staging, plain
+// copies from the caller's memory.  The caller holds lib->host_mutex.
 int match_host_chunks(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, uint64_t n, int max_mismatch,
                       int algo, int32_t* h_best_idx, uint8_t* h_best_dist, uint8_t* h_n_best, uint32_t* d_c,
                       uint64_t* d_fs, uint64_t first_index_base) {
-    constexpr int HOST_WORKERS = 3;
-    const uint64_t CH = 1ull << 23;  // 8M reads = 64 MB up, 48 MB down per chunk
+    const bool stage = lib->knobs.host_pin != 0 && n >= (1ull << 18);
+    // staged: 1M reads per chunk (8 MB up, 6 MB down: 14 MB of page-locked memory per worker); direct: 8M
+    const uint64_t CH = stage ? (1ull << 20) : (1ull << 23);
     const uint64_t n_chunks = (n + CH - 1) / CH;
-    const int workers = (int)std::min<uint64_t>(HOST_WORKERS, n_chunks);
+    const int workers = (int)std::min<uint64_t>(stage ? HOST_WORKERS : 3, n_chunks);
     if (!lib->host_slots) lib->host_slots = new HostSlot[HOST_WORKERS];
     HostSlot* slots = (HostSlot*)lib->host_slots;
     for (int w = 0; w < workers; ++w) {
         int rc = slot_reserve(slots[w], std::min(n, CH));
+        if (rc == BC_OK && stage) rc = slot_reserve_pinned(slots[w], std::min(n, CH));
         if (rc != BC_OK) return rc;
     }
     BC_HIP(hipDeviceSynchronize());
-    // pageable copies serialise inside the runtime; pinning the caller's buffers for the duration of a
-    // large call lets the three workers' transfers really overlap (BC_HOST_PIN=0 disables)
-    Pinned pinned;
-    if (workers > 1 && lib->knobs.host_pin) {
-        pinned.pin(h_reads, n * 8); pinned.pin(h_best_idx, n * 4); pinned.pin(h_flags, n);
-        pinned.pin(h_best_dist, n); pinned.pin(h_n_best, n);
-    }
     std::atomic<uint64_t> next{0};
     std::atomic<int> first_rc{BC_OK};
     std::string err;
@@ -2110,15 +2128,27 @@ int match_host_chunks(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_fla
         };
         if (hipSetDevice(lib->device) != hipSuccess) { set_error("hipSetDevice failed in a worker"); fail(BC_EHIP); return; }
         auto step = [&](uint64_t a, uint64_t m) -> int {
-            BC_HIP(hipMemcpyAsync(s.d_r, h_reads + a, m * 8, hipMemcpyHostToDevice, s.st));
-            if (h_flags) BC_HIP(hipMemcpyAsync(s.d_f, h_flags + a, m, hipMemcpyHostToDevice, s.st));
+            const uint64_t* src_r = h_reads + a;
+            const uint8_t* src_f = h_flags ? h_flags + a : nullptr;
+            if (stage) {
+                memcpy(s.h_r, h_reads + a, m * 8);
+                if (h_flags) memcpy(s.h_f, h_flags + a, m);
+                src_r = s.h_r; src_f = h_flags ? s.h_f : nullptr;
+            }
+            BC_HIP(hipMemcpyAsync(s.d_r, src_r, m * 8, hipMemcpyHostToDevice, s.st));
+            if (h_flags) BC_HIP(hipMemcpyAsync(s.d_f, src_f, m, hipMemcpyHostToDevice, s.st));
             MatchOut o{s.d_bi, h_best_dist ? s.d_bd : nullptr, h_n_best ? s.d_nb : nullptr, d_c, d_fs, first_index_base + a, PartOut{}};
             int rc = launch_match(lib, s.d_r, h_flags ? s.d_f : nullptr, m, max_mismatch, algo, o, s.st);
             if (rc != BC_OK) return rc;
-            BC_HIP(hipMemcpyAsync(h_best_idx + a, s.d_bi, m * 4, hipMemcpyDeviceToHost, s.st));
-            if (h_best_dist) BC_HIP(hipMemcpyAsync(h_best_dist + a, s.d_bd, m, hipMemcpyDeviceToHost, s.st));
-            if (h_n_best) BC_HIP(hipMemcpyAsync(h_n_best + a, s.d_nb, m, hipMemcpyDeviceToHost, s.st));
+            BC_HIP(hipMemcpyAsync(stage ? s.h_bi : h_best_idx + a, s.d_bi, m * 4, hipMemcpyDeviceToHost, s.st));
+            if (h_best_dist) BC_HIP(hipMemcpyAsync(stage ? s.h_bd : h_best_dist + a, s.d_bd, m, hipMemcpyDeviceToHost, s.st));
+            if (h_n_best) BC_HIP(hipMemcpyAsync(stage ? s.h_nb : h_n_best + a, s.d_nb, m, hipMemcpyDeviceToHost, s.st));
             BC_HIP(hipStreamSynchronize(s.st));
+            if (stage) {
+                memcpy(h_best_idx + a, s.h_bi, m * 4);
+                if (h_best_dist) memcpy(h_best_dist + a, s.h_bd, m);
+                if (h_n_best) memcpy(h_n_best + a, s.h_nb, m);
+            }
             return BC_OK;
         };
         for (;;) {
@@ -2251,10 +2281,7 @@ int bc_lib_destroy(bc_lib* lib) {
         for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile}) if (p) (void)hipFree(p);
     if (lib->host_slots) {
         HostSlot* hs = (HostSlot*)lib->host_slots;
-        for (int w = 0; w < 3; ++w) {
-            for (void* p : {(void*)hs[w].d_r, (void*)hs[w].d_f, (void*)hs[w].d_bd, (void*)hs[w].d_nb, (void*)hs[w].d_bi}) if (p) (void)hipFree(p);
-            if (hs[w].st) (void)hipStreamDestroy(hs[w].st);
-        }
+        for (int w = 0; w < HOST_WORKERS; ++w) slot_release(hs[w]);
         delete[] hs;
     }
     delete lib;
