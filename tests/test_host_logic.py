@@ -105,6 +105,49 @@ def test_pack_windows_matches_oracle_statuses(oracle):
     assert done >= 12
 
 
+def test_hash_windows_follow_the_packed_window_rules(oracle):
+    """bc_hash_windows (barcodes of more than 32 nt) applies bc_pack_windows' N-skip / slice / flank rules: on the
+    golden chunk inputs (k <= 32, where both exist) the statuses are identical, the window text is the barcode slice
+    the oracle reports (reverse-complemented for the reverse orientation), equal texts hash equally and bc_hash_kmers
+    gives the library the same hashes."""
+    from barcoder_amd import encoding as E, _native as N
+    done = 0
+    for c in _load("heuristicount_chunks.json.gz"):
+        if "error" in c or (c["chunk"][0] and c["chunk"][1]):
+            continue
+        a, b = c["chunk"]
+        r1, r2 = (b, a) if c["need_swap"] else (a, b)
+        reads, start, L, R, rev = (r1, c["L_fwd_start"], c["L_fwd"], c["R_fwd"], False) if r1 else \
+                                  (r2, c["L_rev_start"], c["L_rev"], c["R_rev"], True)
+        k = c["bc_len"]
+        text, off = E.reads_to_text(reads)
+        _packed, status = E.pack_windows(text, off, start, L or "", R or "", k, rev)
+        h, st2, wins = E.hash_windows(text, off, start, L or "", R or "", k, rev)
+        np.testing.assert_array_equal(status, st2)
+        ok = np.flatnonzero(st2 == N.WIN_OK)
+        assert ok.size > 0
+        texts = [bytes(wins[i]).decode() for i in ok]
+        for i, s_ in zip(ok[:80], texts[:80]):
+            w = reads[i][start:start + len(L or "") + k + len(R or "")]
+            q = w[len(L or ""):len(w) - len(R or "")]
+            assert s_ == (oracle.rev_comp(q) if rev else q)
+        np.testing.assert_array_equal(h[ok], E.hash_kmers(texts, k))
+        assert (h[st2 != N.WIN_OK] == 0).all()
+        done += 1
+    assert done >= 12
+    # longer than the packed form holds: distinct texts, distinct hashes; the hash depends on every character
+    import random
+    rng = random.Random(3)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(120)) for _ in range(2000)]
+    hs = E.hash_kmers(seqs, 120)
+    assert np.unique(hs).size == 2000
+    one = list(seqs[0])
+    for p_ in (0, 7, 8, 63, 64, 119):
+        t = one.copy()
+        t[p_] = "A" if t[p_] != "A" else "C"
+        assert E.hash_kmers(["".join(t)], 120)[0] != hs[0]
+
+
 def test_read_fasta_and_chunks(tmp_path, scenarios):
     from barcoder_amd import heuristicount as H
     s, fa, f1, f2 = scenarios[0]
