@@ -66,6 +66,12 @@ SIGNATURES = {
     "bc_stream_count_pair": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                        C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                        C.c_int, vp, vp, C.POINTER(vp)]),
+    "bc_stream_count_pair_range": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint64,
+                                             C.c_int64, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int64, C.c_char_p, C.c_int,
+                                             C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp, vp, C.POINTER(vp)]),
+    "bc_file_count_newlines": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_int)]),
+    "bc_file_seek_newline": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bc_stream_result_pair_info": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bc_stream_result_pair_odd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "bc_sample_data": (C.c_int, [C.c_char_p, C.c_char_p, vp, C.c_uint32, C.c_int, C.POINTER(vp)]),

@@ -780,6 +780,18 @@ int bc_stream_count_pair(bc_lib* lib, const char* path_fwd, const char* path_rev
                          int L_fwd_len, const char* R_fwd, int R_fwd_len, int64_t start_rev, const char* L_rev,
                          int L_rev_len, const char* R_rev, int R_rev_len, int max_mismatch, int algo, uint64_t key_base,
                          int n_threads, uint64_t* h_counts, uint64_t* h_first_seen, bc_stream_result** out) {
+    return bc_stream_count_pair_range(lib, path_fwd, 0, ~0ull, path_rev, 0, ~0ull, start_fwd, L_fwd, L_fwd_len, R_fwd, R_fwd_len,
+                                      start_rev, L_rev, L_rev_len, R_rev, R_rev_len, max_mismatch, algo, key_base, n_threads,
+                                      h_counts, h_first_seen, out);
+}
+
+// The same over one byte range of each file — ranges that hold the SAME reads (record-aligned, found with
+// bc_file_count_newlines / bc_file_seek_newline): one rank's share when the pairs are spread over several GPUs.
+int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_begin, uint64_t fwd_end, const char* path_rev,
+                               uint64_t rev_begin, uint64_t rev_end, int64_t start_fwd, const char* L_fwd, int L_fwd_len,
+                               const char* R_fwd, int R_fwd_len, int64_t start_rev, const char* L_rev, int L_rev_len,
+                               const char* R_rev, int R_rev_len, int max_mismatch, int algo, uint64_t key_base, int n_threads,
+                               uint64_t* h_counts, uint64_t* h_first_seen, bc_stream_result** out) {
     if (!lib || !path_fwd || !path_rev || !out) { set_error("bc_stream_count_pair: null argument"); return BC_EINVAL; }
     uint32_t G = 0; int k = 0, device = 0;
     bc_lib_info(lib, &G, &k, &device);
@@ -791,9 +803,10 @@ int bc_stream_count_pair(bc_lib* lib, const char* path_fwd, const char* path_rev
     if ((rc = fill_geometry(J[0].g, k, start_fwd, L_fwd, L_fwd_len, R_fwd, R_fwd_len, 0, "bc_stream_count_pair")) != BC_OK) return rc;
     if ((rc = fill_geometry(J[1].g, k, start_rev, L_rev, L_rev_len, R_rev, R_rev_len, 1, "bc_stream_count_pair")) != BC_OK) return rc;
     const char* paths[2] = {path_fwd, path_rev};
+    const uint64_t begins[2] = {fwd_begin, rev_begin}, ends_[2] = {fwd_end, rev_end};
     for (int f = 0; f < 2; ++f) {
         if ((rc = file_kind(paths[f], "bc_stream_count_pair", &J[f].g.fastq)) != BC_OK) return rc;
-        J[f].lib = lib; J[f].path = paths[f]; J[f].byte_begin = 0; J[f].byte_end = ~0ull;
+        J[f].lib = lib; J[f].path = paths[f]; J[f].byte_begin = begins[f]; J[f].byte_end = ends_[f];
         J[f].n_threads = n_threads; J[f].key_base = key_base; J[f].store = &W[f];
         if ((rc = run_file(J[f])) != BC_OK) return rc;
     }
@@ -877,6 +890,68 @@ int bc_stream_count_pair(bc_lib* lib, const char* path_fwd, const char* path_rev
     if (rc != BC_OK) { delete res; return rc; }
     res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     *out = res;
+    return BC_OK;
+}
+
+// ---- line arithmetic on an uncompressed file (host): how ranks agree on byte ranges that hold the same reads ------
+// newlines in [begin, end) of the file (end clamped to its size); *size_out = file size; *last_byte_out = the file's
+// last byte (0 for an empty file): lines = newlines + (size > 0 and last byte != '\n')
+int bc_file_count_newlines(const char* path, uint64_t begin, uint64_t end, uint64_t* n_out, uint64_t* size_out, int* last_byte_out) {
+    if (!path || !n_out) { set_error("bc_file_count_newlines: null argument"); return BC_EINVAL; }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { set_error("cannot open %s", path); return BC_EINVAL; }
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { set_error("cannot stat %s", path); return BC_EINVAL; }
+    const uint64_t size = (uint64_t)sb.st_size;
+    end = std::min(end, size);
+    begin = std::min(begin, end);
+    std::vector<uint8_t> buf(8u << 20);
+    uint64_t n = 0;
+    for (uint64_t at = begin; at < end;) {
+        const size_t want = (size_t)std::min<uint64_t>(buf.size(), end - at);
+        const ssize_t got = pread(fd, buf.data(), want, (off_t)at);
+        if (got <= 0) { set_error("read error in %s", path); return BC_EINVAL; }
+        n += count_nl(buf.data(), (uint64_t)got);
+        at += (uint64_t)got;
+    }
+    *n_out = n;
+    if (size_out) *size_out = size;
+    if (last_byte_out) {
+        uint8_t c = 0;
+        if (size && pread(fd, &c, 1, (off_t)(size - 1)) != 1) { set_error("read error in %s", path); return BC_EINVAL; }
+        *last_byte_out = (int)c;
+    }
+    return BC_OK;
+}
+
+// offset of the byte after the nth newline (1-based) at or after `begin`; nth = 0 gives `begin`; past the last newline
+// the file size
+int bc_file_seek_newline(const char* path, uint64_t begin, uint64_t nth, uint64_t* offset_out) {
+    if (!path || !offset_out) { set_error("bc_file_seek_newline: null argument"); return BC_EINVAL; }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { set_error("cannot open %s", path); return BC_EINVAL; }
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { set_error("cannot stat %s", path); return BC_EINVAL; }
+    const uint64_t size = (uint64_t)sb.st_size;
+    begin = std::min(begin, size);
+    if (nth == 0) { *offset_out = begin; return BC_OK; }
+    std::vector<uint8_t> buf(8u << 20);
+    uint64_t seen = 0;
+    for (uint64_t at = begin; at < size;) {
+        const size_t want = (size_t)std::min<uint64_t>(buf.size(), size - at);
+        const ssize_t got = pread(fd, buf.data(), want, (off_t)at);
+        if (got <= 0) { set_error("read error in %s", path); return BC_EINVAL; }
+        const uint64_t c = count_nl(buf.data(), (uint64_t)got);
+        if (seen + c >= nth) {
+            for (ssize_t i = 0; i < got; ++i)
+                if (buf[(size_t)i] == '\n' && ++seen == nth) { *offset_out = at + (uint64_t)i + 1; return BC_OK; }
+        }
+        seen += c;
+        at += (uint64_t)got;
+    }
+    *offset_out = size;
     return BC_OK;
 }
 

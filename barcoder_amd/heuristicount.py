@@ -729,9 +729,9 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     device_ingest = (bc_len <= 32 and not is_paired and not file1.endswith((".gz", ".zst")) and (plan == "bytes" or world == 1)
                      and (bc_start2 if need_swap else bc_start1) is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                      and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
-    # paired-end: two uncompressed files, one process (ranks keep the strided host plan: every rank would need the
-    # mates' byte ranges, i.e. a line index of both files)
-    device_pairs = (bc_len <= 32 and is_paired and world == 1 and not file1.endswith((".gz", ".zst")) and not file2.endswith((".gz", ".zst"))
+    # paired-end: two uncompressed files; with several ranks every rank takes byte ranges of both files that hold the same
+    # reads (ingest.paired_read_ranges: newline counts per slice, made common knowledge by one small gather)
+    device_pairs = (bc_len <= 32 and is_paired and not file1.endswith((".gz", ".zst")) and not file2.endswith((".gz", ".zst"))
                     and bc_start1 is not None and bc_start2 is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                     and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     undoc_tables, odd_events = [], []
@@ -752,11 +752,13 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
         if device_pairs:
             # both mate files through the device (bc_stream_count_pair); the file whose reads carry the barcode in
             # library orientation is reads1 after the reference's swap (heuristicount.py:444-447)
-            from .ingest import stream_count_pair
+            from .ingest import paired_read_ranges, stream_count_pair
             s1, s2, Lf, Rf, Lr, Rr = cc.geom
             p_fwd, p_rev = (file2, file1) if need_swap else (file1, file2)
             c64, f64 = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
-            sr = stream_count_pair(cc.lib.handle, p_fwd, p_rev, s1, Lf, Rf, s2, Lr, Rr, max_mismatch, cc.algo, 0, c64, f64)
+            key0, rng_f, rng_r = (0, None, None) if world == 1 else paired_read_ranges(p_fwd, p_rev, rank, world, D.gather_objects)
+            sr = stream_count_pair(cc.lib.handle, p_fwd, p_rev, s1, Lf, Rf, s2, Lr, Rr, max_mismatch, cc.algo, key0, c64, f64,
+                                   range_fwd=rng_f, range_rev=rng_r)
             counts[:G], first_seen[:G] = c64, f64
             undoc_tables.append((sr.u_words, sr.u_counts, sr.u_first))
             for key, w1p, st1, w2p, st2, t1, t2 in sr.odd:  # string semantics (ChunkCounter.match_buffers)

@@ -150,19 +150,72 @@ def stream_count_file(lib_handle, path: str, byte_begin: int, byte_end: int, sta
         lib.bc_stream_result_free(h)
 
 
+def file_count_newlines(path: str, begin: int, end: int):
+    """(newlines in [begin, end), file size, last byte of the file) — bc_file_count_newlines."""
+    n, size, last = C.c_uint64(), C.c_uint64(), C.c_int()
+    N.check(N.load().bc_file_count_newlines(path.encode(), int(begin), int(end), C.byref(n), C.byref(size), C.byref(last)))
+    return int(n.value), int(size.value), int(last.value)
+
+
+def file_seek_newline(path: str, begin: int, nth: int) -> int:
+    """Offset of the byte after the nth newline at or after `begin` (nth = 0: `begin`) — bc_file_seek_newline."""
+    off = C.c_uint64()
+    N.check(N.load().bc_file_seek_newline(path.encode(), int(begin), int(nth), C.byref(off)))
+    return int(off.value)
+
+
+def paired_read_ranges(file_a: str, file_b: str, rank: int, world: int, gather):
+    """Byte ranges of two uncompressed mate files that hold the SAME reads, one pair of ranges per rank: every rank
+    counts the newlines of one slice of each file, `gather(obj)` (dist.gather_objects) makes the counts common
+    knowledge, and a line number becomes a byte offset by a short scan inside the slice that holds it.  Returns
+    (index of the rank's first read, (begin, end) in file_a, (begin, end) in file_b).  Files with different numbers
+    of reads raise the reference's error (heuristicount.py:484-486) on every rank."""
+    import bisect
+    info = []
+    for path in (file_a, file_b):
+        size = os.path.getsize(path)
+        cuts = [size * r // world for r in range(world + 1)]
+        n, _size, last = file_count_newlines(path, cuts[rank], cuts[rank + 1])
+        counts = [p[0] for p in gather((n, last))]
+        cum = [0]
+        for c in counts:
+            cum.append(cum[-1] + c)  # cum[j] = newlines in front of slice j
+        lines = cum[-1] + (1 if size and last != 10 else 0)
+        per = 4 if path.endswith(".fastq") else 1
+        reads = (lines + 2) // 4 if per == 4 else lines  # a FASTQ read = a line with index 1 mod 4
+        info.append((path, size, cuts, cum, lines, per, reads))
+    if info[0][6] != info[1][6]:
+        raise ValueError("Length of reads1 and reads2 must be the same for paired-end data.")
+    R = info[0][6]
+    r0, r1 = R * rank // world, R * (rank + 1) // world
+    ranges = []
+    for path, size, cuts, cum, lines, per, _reads in info:
+        def line_start(L):
+            if L <= 0:
+                return 0
+            if L > cum[-1]:  # past the last newline: nothing starts there
+                return size
+            j = bisect.bisect_left(cum, L) - 1  # the L-th newline lies in slice j: cum[j] < L <= cum[j + 1]
+            return file_seek_newline(path, cuts[j], L - cum[j])
+        ranges.append((line_start(r0 * per), size if rank == world - 1 else line_start(r1 * per)))
+    return r0, ranges[0], ranges[1]
+
+
 def stream_count_pair(lib_handle, path_fwd: str, path_rev: str, start_fwd: int, L_fwd: str, R_fwd: str, start_rev: int,
                       L_rev: str, R_rev: str, max_mismatch: int, algo: str, key_base: int, counts: np.ndarray,
-                      first_seen: np.ndarray, n_threads: int = 0) -> StreamResult:
+                      first_seen: np.ndarray, n_threads: int = 0, range_fwd=None, range_rev=None) -> StreamResult:
     """The device path for two uncompressed mate files (bc_stream_count_pair).  `odd` of the result holds, per pair
     with an odd window, (key, p1, st1, p2, st2, text1, text2): the packed word / status of each mate and the stripped
     text of each odd mate ('' for a packed one)."""
     lib = N.load()
     h = N.vp()
     enc = [x.encode("ascii") for x in (L_fwd, R_fwd, L_rev, R_rev)]
-    N.check(lib.bc_stream_count_pair(lib_handle, path_fwd.encode(), path_rev.encode(), int(start_fwd), enc[0], len(enc[0]),
-                                     enc[1], len(enc[1]), int(start_rev), enc[2], len(enc[2]), enc[3], len(enc[3]),
-                                     int(max_mismatch), N.ALGOS[algo], int(key_base), int(n_threads), N.ptr(counts),
-                                     N.ptr(first_seen), C.byref(h)))
+    fa, fb = range_fwd or (0, 2**64 - 1), range_rev or (0, 2**64 - 1)
+    N.check(lib.bc_stream_count_pair_range(lib_handle, path_fwd.encode(), int(fa[0]), int(fa[1]), path_rev.encode(),
+                                           int(fb[0]), int(fb[1]), int(start_fwd), enc[0], len(enc[0]), enc[1], len(enc[1]),
+                                           int(start_rev), enc[2], len(enc[2]), enc[3], len(enc[3]), int(max_mismatch),
+                                           N.ALGOS[algo], int(key_base), int(n_threads), N.ptr(counts), N.ptr(first_seen),
+                                           C.byref(h)))
     try:
         n, nu, no, ob, sec = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
         N.check(lib.bc_stream_result_info(h, C.byref(n), C.byref(nu), C.byref(no), C.byref(ob), C.byref(sec)))

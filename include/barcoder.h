@@ -193,6 +193,21 @@ int bc_stream_count_pair(bc_lib *lib, const char *path_fwd, const char *path_rev
                          const char *R_rev, int R_rev_len, int max_mismatch, int algo,
                          uint64_t key_base, int n_threads, uint64_t *h_counts,
                          uint64_t *h_first_seen, bc_stream_result **out);
+/* The same over one byte range of each file — ranges that hold the SAME reads: one rank's
+ * share when the pairs are spread over several GPUs (heuristicount.py:703-737).  The ranges
+ * come from line arithmetic both files allow: bc_file_count_newlines over a slice per rank,
+ * summed over the ranks, tells every rank which line its share starts at;
+ * bc_file_seek_newline turns a line number into a byte offset. */
+int bc_stream_count_pair_range(bc_lib *lib, const char *path_fwd, uint64_t fwd_begin, uint64_t fwd_end,
+                               const char *path_rev, uint64_t rev_begin, uint64_t rev_end,
+                               int64_t start_fwd, const char *L_fwd, int L_fwd_len, const char *R_fwd,
+                               int R_fwd_len, int64_t start_rev, const char *L_rev, int L_rev_len,
+                               const char *R_rev, int R_rev_len, int max_mismatch, int algo,
+                               uint64_t key_base, int n_threads, uint64_t *h_counts,
+                               uint64_t *h_first_seen, bc_stream_result **out);
+int bc_file_count_newlines(const char *path, uint64_t begin, uint64_t end, uint64_t *n_out,
+                           uint64_t *size_out, int *last_byte_out);
+int bc_file_seek_newline(const char *path, uint64_t begin, uint64_t nth, uint64_t *offset_out);
 int bc_stream_result_pair_info(const bc_stream_result *r, uint64_t *n_pairs, uint64_t *text1_bytes,
                                uint64_t *text2_bytes);
 int bc_stream_result_pair_odd(const bc_stream_result *r, uint64_t *keys, uint64_t *p1, uint8_t *st1,

@@ -57,10 +57,12 @@ def test_bench_refuses_mismatched_world(gpu_device):
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
 
 
-@pytest.mark.parametrize("scenario,compress", [("fwd_single", False), ("fwd_single", True), ("paired", False)])
-def test_heuristicount_cli_two_ranks_equals_reference(gpu_device, tmp_path, scenario, compress):
-    """`python -m barcoder_amd.heuristicount --gpus 2`: stdout byte-identical to the reference's single-process
-    run — byte-range shards of a plain single-end file, chunk striding for gz / paired input."""
+@pytest.mark.parametrize("scenario,compress,ranks", [("fwd_single", False, 2), ("fwd_single", True, 2), ("paired", False, 2),
+                                                     ("paired_swapped", False, 3), ("paired", True, 2)])
+def test_heuristicount_cli_two_ranks_equals_reference(gpu_device, tmp_path, scenario, compress, ranks):
+    """`python -m barcoder_amd.heuristicount --gpus N`: stdout byte-identical to the reference's single-process
+    run — byte-range shards of a plain single-end file, ranges of both mate files that hold the same reads for plain
+    paired input (line arithmetic, ingest.paired_read_ranges), chunk striding for compressed input."""
     with gzip.open(os.path.join(GOLDEN, "heuristicount_main.json.gz"), "rt") as f:
         cases = json.load(f)
     s = next((x for x in cases if x["name"] == scenario), None) or next(x for x in cases if x["paired"])
@@ -78,9 +80,11 @@ def test_heuristicount_cli_two_ranks_equals_reference(gpu_device, tmp_path, scen
     if s["paired"]:
         files.append(tmp_path / f"r2.{ext}")
         write(files[1], s["reads2"])
+    if scenario == "paired_swapped":  # the mate files in the other order: the sampler finds the swap, same output
+        files.reverse()
     for backend in _backends():
         out = subprocess.run([sys.executable, "-m", "barcoder_amd.heuristicount", str(fa)] + [str(p) for p in files] +
-                             ["--gpus", "2", "--chunk-reads", "257"], cwd=ROOT, capture_output=True, text=True,
+                             ["--gpus", str(ranks), "--chunk-reads", "257"], cwd=ROOT, capture_output=True, text=True,
                              timeout=900, env=_bare_env(backend))
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout == s["stdout"], (scenario, compress, backend)
