@@ -494,6 +494,60 @@ def test_reader_byte_ranges_tile_the_file(tmp_path):
         ingest.NativeReader(str(tmp_path / "x.reads.gz"), byte_range=(0, 5))
 
 
+@pytest.mark.parametrize("fastq", [False, True])
+def test_paired_read_ranges_hold_the_same_reads(tmp_path, fastq):
+    """ingest.paired_read_ranges: for every rank of 1, 2, 3 and 5 the two byte ranges start at record boundaries,
+    tile their files, and hold the same read indices although the mates' lines differ in length (and the last line
+    of one file has no newline); files with different numbers of reads raise the reference's error."""
+    import random
+    from barcoder_amd import ingest as I
+    rng = random.Random(5)
+    n = 1237
+    a = ["".join(rng.choice("ACGT") for _ in range(rng.randrange(20, 60))) for _ in range(n)]
+    b = ["".join(rng.choice("ACGT") for _ in range(rng.randrange(5, 90))) for _ in range(n)]
+    ext = ".fastq" if fastq else ".reads"
+
+    def write(path, reads, trailing=True):
+        rec = [f"@r{i}\n{r}\n+\n{'I' * len(r)}" if fastq else r for i, r in enumerate(reads)]
+        with open(path, "w") as f:
+            f.write("\n".join(rec) + ("\n" if trailing else ""))
+    fa, fb = str(tmp_path / ("a" + ext)), str(tmp_path / ("b" + ext))
+    write(fa, a)
+    write(fb, b, trailing=False)
+    per = 4 if fastq else 1
+    for world in (1, 2, 3, 5):
+        calls = {"i": 0}
+
+        def gather(obj):  # what dist.gather_objects returns: every rank's (newlines of its slice, last byte)
+            path = (fa, fb)[calls["i"] % 2]
+            calls["i"] += 1
+            size = os.path.getsize(path)
+            cuts = [size * r // world for r in range(world + 1)]
+            last = I.file_count_newlines(path, 0, 0)[2]
+            return [(I.file_count_newlines(path, cuts[r], cuts[r + 1])[0], last) for r in range(world)]
+        got = [I.paired_read_ranges(fa, fb, r, world, gather) for r in range(world)]
+        for path, reads, which in ((fa, a, 1), (fb, b, 2)):
+            data = open(path, "rb").read()
+            assert got[0][which][0] == 0 and got[-1][which][1] == len(data)
+            for r in range(world):
+                r0, (lo, hi) = got[r][0], got[r][which]
+                if r + 1 < world:
+                    assert hi == got[r + 1][which][0]
+                assert r0 == n * r // world
+                lines = data[lo:hi].decode().split("\n")
+                if lines and lines[-1] == "":
+                    lines.pop()
+                seqs = lines[1::4] if fastq else lines
+                assert seqs == reads[r0:n * (r + 1) // world], (world, r, which)
+                assert lo == 0 or data[lo - 1:lo] == b"\n"
+    write(fb, b[:-1])
+    calls = {"i": 0}
+    world = 2
+    with pytest.raises(ValueError, match="Length of reads1 and reads2 must be the same"):
+        I.paired_read_ranges(fa, fb, 0, world, gather)
+    assert I.file_seek_newline(fa, 0, 0) == 0 and I.file_seek_newline(fa, 0, 10**9) == os.path.getsize(fa)
+
+
 def test_merge_undocumented_any_order():
     from barcoder_amd import heuristicount as H
     u = np.uint64
