@@ -51,7 +51,7 @@ for name, e in d.items():
         rows[name]["note"] = note
     total += f * corr + add + w
 out = {"reads": reads, "algo": algo, "max_mismatch": mm, "hbm_bytes_per_pass": total, "per_kernel": rows,
-       "algorithmic_bytes_per_pass": 13 * reads, "source": src,
+       "algorithmic_bytes_per_pass": 13 * reads, "source": "profiles/" + os.path.basename(src),
        # what the counters were collected on: bench.py quotes the figure only for the same kernel sources and kernel
        "match_source_stamp": match_source_stamp(),
        "dominant_kernel": next((k for k in rows if k.startswith("k_match")), None),
