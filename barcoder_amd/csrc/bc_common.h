@@ -73,6 +73,29 @@ BC_HD static inline uint64_t sm_draw(uint64_t seed, uint64_t i, uint32_t j) {
     return sm64(seed ^ sm64(i * 8ULL + j));
 }
 
+// 64-bit hash of a text of n characters, character i = at(i) — what stands for a barcode of more than 32 nt in the
+// exact table.  Eight characters per step, assembled little-endian: the same value on the host (bc_hash_kmers /
+// bc_hash_windows) and on the device (k_lines_to_windows), whatever orientation `at` reads the text in.
+template <typename At>
+BC_HD static inline uint64_t text_hash64_at(size_t n, At at) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n * 0xD6E8FEB86659FD93ull);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w = 0;
+        for (int b = 0; b < 8; ++b) w |= (uint64_t)(unsigned char)at(i + (size_t)b) << (8 * b);
+        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+        h ^= h >> 32;
+    }
+    if (i < n) {
+        uint64_t w = 0;
+        for (int b = 0; i + (size_t)b < n; ++b) w |= (uint64_t)(unsigned char)at(i + (size_t)b) << (8 * b);
+        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+        h ^= h >> 32;
+    }
+    h *= 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+
 // One synthetic read (plane form) given the guide it derives from.
 //   mixture 0: u1 < 0.9 -> guide unmodified, else random k-mer
 //   mixture 1: 0/1/2/3 substitutions with P = .60/.20/.10/.05, else random

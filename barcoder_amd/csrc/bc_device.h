@@ -164,6 +164,9 @@ struct bc_lib {
     uint32_t* d_nbr_slot = nullptr;  // neighbour lists (see SlabParams)
     uint4* d_nbr = nullptr;
     uint64_t* d_guides = nullptr;  // [G] original order (also the brute-force tile source)
+    // barcodes of more than 32 nt (bc_lib_attach_text): the guides above are 64-bit hashes of the texts, these the texts
+    char* d_text = nullptr;        // [G][text_k]
+    int text_k = 0;
     // exact-match open-addressing table
     int log_slots = 0;
     bool wide = false;             // true: 32-bit index slots + verify against d_guides

@@ -163,22 +163,7 @@ int bc_pack_windows(const char* h_text, const uint64_t* h_off, size_t n_reads, i
 // looks up, as a pseudo 32-mer) together with the text itself (what the caller verifies a hit against and names an
 // undocumented window by): bc_hash_windows is bc_pack_windows' twin for them, bc_hash_kmers hashes the library.
 static inline uint64_t text_hash64(const unsigned char* p, size_t n) {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xD6E8FEB86659FD93ull);
-    while (n >= 8) {
-        uint64_t w;
-        memcpy(&w, p, 8);
-        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
-        h ^= h >> 32;
-        p += 8; n -= 8;
-    }
-    if (n) {
-        uint64_t w = 0;
-        memcpy(&w, p, n);
-        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
-        h ^= h >> 32;
-    }
-    h *= 0x9E3779B97F4A7C15ull;
-    return h ^ (h >> 29);
+    return text_hash64_at(n, [p](size_t i) { return p[i]; });
 }
 
 int bc_hash_kmers(const char* h_seqs, size_t n, int k, uint64_t* h_out) {

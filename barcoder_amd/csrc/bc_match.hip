@@ -2288,6 +2288,21 @@ int bc_lib_destroy(bc_lib* lib) {
     return BC_OK;
 }
 
+int bc_lib_attach_text(bc_lib* lib, const char* h_text, int text_k) {
+    if (!lib || !h_text || text_k < 33 || text_k > 1000 || lib->k != 32) {
+        set_error("bc_lib_attach_text: a k = 32 library of text hashes and texts of 33 ... 1000 characters are needed");
+        return BC_EINVAL;
+    }
+    BC_HIP(hipSetDevice(lib->device));
+    void* p = nullptr;
+    BC_HIP(hipMalloc(&p, (size_t)lib->G * (size_t)text_k));
+    lib->owned.push_back(p);
+    BC_HIP(hipMemcpy(p, h_text, (size_t)lib->G * (size_t)text_k, hipMemcpyHostToDevice));
+    lib->d_text = (char*)p;
+    lib->text_k = text_k;
+    return BC_OK;
+}
+
 int bc_lib_release_stream(bc_lib* lib, void* stream) {
     if (!lib) { set_error("bc_lib_release_stream: null"); return BC_EINVAL; }
     std::lock_guard<std::mutex> g(lib->ws_mutex);

@@ -42,6 +42,7 @@ constexpr uint64_t SLACK = 1ull << 20;    // longest line that may run past a ch
 struct Geometry {
     int64_t start;
     int L_len, R_len, k, reverse, fastq;
+    int text_k;  // > 0: barcodes of that many characters (more than 32): the window's 64-bit text hash stands for it
     char L[16], R[16];
 };
 
@@ -86,15 +87,16 @@ __global__ __launch_bounds__(BLOCK) void k_lines_to_windows(const uint8_t* __res
                                                             uint64_t gri0, Geometry g, uint64_t key0,
                                                             uint64_t* __restrict__ packed, uint8_t* __restrict__ status,
                                                             OddRec* __restrict__ odd, uint32_t odd_cap,
-                                                            uint32_t* __restrict__ flags) {
+                                                            uint32_t* __restrict__ flags, uint32_t* __restrict__ woff) {
     uint32_t* n_odd = flags;
+    const int kk = g.text_k ? g.text_k : g.k;  // characters of a barcode
     const uint64_t n_nl = *n_nl_p;
     if (n_nl > nl_cap) {  // the position list was cut short: refuse
         if (blockIdx.x == 0 && threadIdx.x == 0) flags[1] = 2u;
         return;
     }
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
-    const int64_t wlen = (int64_t)g.L_len + g.k + g.R_len;
+    const int64_t wlen = (int64_t)g.L_len + kk + g.R_len;
     for (uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; t < n_own; t += stride) {
         const uint64_t gl = line_base + t;
         uint64_t r;
@@ -125,7 +127,22 @@ __global__ __launch_bounds__(BLOCK) void k_lines_to_windows(const uint8_t* __res
             for (int j = 0; has && j < g.R_len; ++j) has = win[n - g.R_len + j] == (uint8_t)g.R[j];
             if (has) {
                 st = BC_WIN_ODD;  // flanks present: a short window or an odd character keeps string semantics
-                if (n == wlen) {
+                if (n == wlen && g.text_k) {  // more than 32 nt: pure ACGT -> the hash of the barcode as the library spells it
+                    const uint8_t* sq = win + g.L_len;
+                    bool bad = false;
+                    for (int j = 0; j < kk; ++j) bad = bad || dev_base_code(sq[j]) > 3;
+                    if (!bad) {
+                        if (g.reverse)
+                            w = text_hash64_at((size_t)kk, [&](size_t i) {
+                                const uint8_t c = sq[(size_t)kk - 1 - i];
+                                return (uint8_t)(c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : 'C');
+                            });
+                        else
+                            w = text_hash64_at((size_t)kk, [&](size_t i) { return sq[i]; });
+                        woff[r] = (uint32_t)(a + (uint64_t)ws + (uint64_t)g.L_len);
+                        st = BC_WIN_OK;
+                    }
+                } else if (n == wlen) {
                     uint32_t lo = 0, hi = 0;
                     bool bad = false;
                     for (int j = 0; j < g.k; ++j) {
@@ -180,6 +197,102 @@ __global__ __launch_bounds__(BLOCK) void k_collect_misses(const int32_t* __restr
         }
     }
 }
+
+// ---- barcodes of more than 32 nt: the exact table matched the window's text HASH; the text decides ---------------------
+__device__ __forceinline__ uint8_t oriented_char(const uint8_t* sq, int kk, int reverse, int j) {
+    if (!reverse) return sq[j];
+    const uint8_t c = sq[kk - 1 - j];
+    return (uint8_t)(c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : 'C');
+}
+
+// every hit against the library entry's text (a hash collision becomes a miss), then the tally of the verified hits
+__global__ __launch_bounds__(BLOCK) void k_long_verify_tally(int32_t* __restrict__ best_idx, const uint8_t* __restrict__ text,
+                                                            const uint32_t* __restrict__ woff, const char* __restrict__ lib_text,
+                                                            int kk, int reverse, uint64_t n, uint64_t key0,
+                                                            uint32_t* __restrict__ counts, uint64_t* __restrict__ first_seen) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += stride) {
+        const int32_t g = best_idx[r];
+        if (g < 0) continue;
+        const uint8_t* sq = text + woff[r];
+        const char* lt = lib_text + (size_t)g * (size_t)kk;
+        bool same = true;
+        for (int j = 0; j < kk && same; ++j) same = oriented_char(sq, kk, reverse, j) == (uint8_t)lt[j];
+        if (!same) { best_idx[r] = BC_IDX_MISS; continue; }
+        atomicAdd(&counts[g], 1u);
+        const unsigned long long v = key0 + r;
+        if (v < first_seen[g]) atomicMin((unsigned long long*)&first_seen[g], v);
+    }
+}
+
+// flank-valid windows that matched nothing -> (hash, key) pairs and the window's text
+__global__ __launch_bounds__(BLOCK) void k_collect_misses_long(const int32_t* __restrict__ best_idx, const uint64_t* __restrict__ packed,
+                                                              const uint8_t* __restrict__ text, const uint32_t* __restrict__ woff,
+                                                              int kk, int reverse, uint64_t n, uint64_t key0,
+                                                              uint64_t* __restrict__ m_words, uint64_t* __restrict__ m_keys,
+                                                              char* __restrict__ m_text, unsigned long long* __restrict__ cursor) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    const uint64_t n_round = (n + 63) & ~63ull;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_round; r += stride) {
+        const bool miss = r < n && best_idx[r] == BC_IDX_MISS;
+        const unsigned long long m = __ballot(miss);
+        if (m == 0ull) continue;
+        const uint32_t lane = threadIdx.x & 63u;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader);
+        if (miss) {
+            const uint64_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            m_words[at] = packed[r];
+            m_keys[at] = key0 + r;
+            const uint8_t* sq = text + woff[r];
+            char* dst = m_text + at * (uint64_t)kk;
+            for (int j = 0; j < kk; ++j) dst[j] = (char)oriented_char(sq, kk, reverse, j);
+        }
+    }
+}
+
+// after the sort by hash: neighbours with equal hashes must hold equal texts (else the grouping would merge two
+// different windows: reported, never silently done)
+__global__ __launch_bounds__(BLOCK) void k_long_check_groups(const uint64_t* __restrict__ sorted_hash, const uint64_t* __restrict__ ord,
+                                                            const char* __restrict__ m_text, int kk, uint64_t n,
+                                                            uint32_t* __restrict__ clash) {
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j == 0 || j >= n || sorted_hash[j] != sorted_hash[j - 1]) return;
+    const char *x = m_text + ord[j] * (uint64_t)kk, *y = m_text + ord[j - 1] * (uint64_t)kk;
+    for (int c = 0; c < kk; ++c)
+        if (x[c] != y[c]) { *clash = 1u; return; }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_long_gather(const uint64_t* __restrict__ rep, uint64_t n_u, uint64_t n_m, const uint64_t* __restrict__ m_keys,
+                                                      const char* __restrict__ m_text, int kk, uint64_t* __restrict__ first,
+                                                      char* __restrict__ out_text) {
+    const uint64_t u = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= n_u) return;
+    const uint64_t o = rep[u];  // (an ordinal: the reduction's operands behind the data never reach an output)
+    if (o >= n_m) return;
+    first[u] = m_keys[o];
+    for (int c = 0; c < kk; ++c) out_text[u * (uint64_t)kk + c] = m_text[o * (uint64_t)kk + c];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_iota64(uint64_t* __restrict__ p, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+// of two miss ordinals the one whose read comes first (keys are distinct: one per read).  rocprim's reduce_by_key scans
+// whole tiles: behind the last valid item of the last tile it hands the operator UNINITIALISED values (their results
+// are dropped behind a head flag), so an operand that is not an ordinal must not be followed into keys[].
+struct EarlierMiss {
+    const uint64_t* keys;
+    uint64_t n;
+    __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const {
+        if (a >= n) return b;
+        if (b >= n) return a;
+        return keys[a] <= keys[b] ? a : b;
+    }
+};
 
 // paired-end (heuristicount.py:469-518): a pair counts when both mates have their flanks, neither holds an N and
 // seq1 == rev_comp(seq2) (:506) — with both windows packed (the reverse mate's already reverse-complemented) that is
@@ -243,7 +356,8 @@ struct Slot {  // one worker's buffers
     uint8_t* h_text = nullptr;   // pinned, 1 + CHUNK + SLACK
     hipStream_t st = nullptr;
     DevBuf text, bits, nl, tmp, packed, status, best, odd;
-    DevBuf mw, mk;               // this chunk's undocumented windows (word, key) before they join the run-wide list
+    DevBuf mw, mk, mt;           // this chunk's undocumented windows (word, key[, text]) before they join the run-wide list
+    DevBuf woff;                 // long barcodes: offset of every window's barcode in the chunk text
     uint64_t* d_n = nullptr;     // expand count
     uint32_t* d_nodd = nullptr;  // [0] odd windows, [1] error flag, [2..3] the chunk's miss cursor (64 bits)
     ~Slot() {
@@ -261,34 +375,40 @@ struct OddOut { uint64_t key; std::string text; };
 // the chunk.  (Round 2 let every worker's kernel append to the shared list and grew it under a lock the launches
 // did not take: a worker past its capacity check could launch with pointers another one was swapping out.)
 struct MissList {
-    DevBuf words, keys;
+    DevBuf words, keys, texts;
+    int text_k = 0;  // > 0: every entry also carries its window's text (barcodes of more than 32 nt)
     uint64_t cap = 0, used = 0;
     std::mutex m;
     int reserve(uint64_t n) {
         int rc;
         if ((rc = words.reserve(n * 8)) != BC_OK) return rc;
         if ((rc = keys.reserve(n * 8)) != BC_OK) return rc;
+        if (text_k && (rc = texts.reserve(n * (uint64_t)text_k)) != BC_OK) return rc;
         cap = n;
         return BC_OK;
     }
     // append n entries from device buffers; the copies run on `st` and are complete on return
-    int append(const void* w, const void* k, uint64_t n, hipStream_t st) {
+    int append(const void* w, const void* k, const void* t, uint64_t n, hipStream_t st) {
         std::lock_guard<std::mutex> lk(m);
         if (used + n > cap) {
             const uint64_t ncap = std::max<uint64_t>(cap * 2, used + n + 65536);
-            DevBuf nw, nk;
+            DevBuf nw, nk, nt;
             int rc;
             if ((rc = nw.reserve(ncap * 8)) != BC_OK) return rc;
             if ((rc = nk.reserve(ncap * 8)) != BC_OK) return rc;
+            if (text_k && (rc = nt.reserve(ncap * (uint64_t)text_k)) != BC_OK) return rc;
             BC_HIP(hipMemcpyAsync(nw.p, words.p, used * 8, hipMemcpyDeviceToDevice, st));
             BC_HIP(hipMemcpyAsync(nk.p, keys.p, used * 8, hipMemcpyDeviceToDevice, st));
-            BC_HIP(hipStreamSynchronize(st));  // before the old buffers are freed (nw / nk leave scope)
+            if (text_k && used) BC_HIP(hipMemcpyAsync(nt.p, texts.p, used * (uint64_t)text_k, hipMemcpyDeviceToDevice, st));
+            BC_HIP(hipStreamSynchronize(st));  // before the old buffers are freed (nw / nk / nt leave scope)
             std::swap(nw.p, words.p); std::swap(nw.cap, words.cap);
             std::swap(nk.p, keys.p); std::swap(nk.cap, keys.cap);
+            std::swap(nt.p, texts.p); std::swap(nt.cap, texts.cap);
             cap = ncap;
         }
         BC_HIP(hipMemcpyAsync((uint64_t*)words.p + used, w, n * 8, hipMemcpyDeviceToDevice, st));
         BC_HIP(hipMemcpyAsync((uint64_t*)keys.p + used, k, n * 8, hipMemcpyDeviceToDevice, st));
+        if (text_k) BC_HIP(hipMemcpyAsync((char*)texts.p + used * (uint64_t)text_k, t, n * (uint64_t)text_k, hipMemcpyDeviceToDevice, st));
         BC_HIP(hipStreamSynchronize(st));  // complete before anybody else may grow (and copy) the list
         used += n;
         return BC_OK;
@@ -479,9 +599,11 @@ int run_file(FileJob& J) {
                     if ((rc2 = s.best.reserve(n_reads * 4 + 64)) != BC_OK) return rc2;
                     if ((rc2 = s.mw.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;  // every read could be a miss
                     if ((rc2 = s.mk.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;
+                    if (g.text_k && (rc2 = s.mt.reserve(n_reads * (uint64_t)g.text_k + 64)) != BC_OK) return rc2;
                     d_packed = (uint64_t*)s.packed.p;
                     d_status = (uint8_t*)s.status.p;
                 }
+                if (g.text_k && (rc2 = s.woff.reserve(n_reads * 4 + 64)) != BC_OK) return rc2;
                 BC_HIP(hipMemcpyAsync(s.text.p, s.h_text, nbytes, hipMemcpyHostToDevice, s.st));
                 BC_HIP(hipMemsetAsync(s.d_nodd, 0, 16, s.st));
                 hipLaunchKernelGGL(k_nl_bitmap, dim3(grid_for(n_words)), dim3(BLOCK), 0, s.st, (const uint8_t*)s.text.p, nbytes,
@@ -494,9 +616,22 @@ int run_file(FileJob& J) {
                 hipLaunchKernelGGL(k_lines_to_windows, dim3(grid_for(n_own)), dim3(BLOCK), 0, s.st, (const uint8_t*)s.text.p,
                                    nbytes, (const uint32_t*)s.nl.p, (const uint64_t*)s.d_n, nl_cap, n_own, virt,
                                    hi < fsize ? 1 : 0, line_base, gri0, g, key0, d_packed, d_status, (OddRec*)s.odd.p,
-                                   odd_cap, s.d_nodd);
+                                   odd_cap, s.d_nodd, (uint32_t*)s.woff.p);
                 BC_HIP(hipGetLastError());
-                if (!store) {
+                if (!store && g.text_k) {
+                    // barcodes of more than 32 nt: the exact table on the text hashes (no tally: a hit is a hint), the
+                    // texts decide, the verified hits are tallied, the misses keep their texts
+                    if ((rc2 = bc_match_dev(J.lib, d_packed, d_status, n_reads, 0, BC_ALGO_HASH, (int32_t*)s.best.p, nullptr,
+                                            nullptr, nullptr, nullptr, key0, s.st)) != BC_OK) return rc2;
+                    hipLaunchKernelGGL(k_long_verify_tally, dim3(grid_for(n_reads)), dim3(BLOCK), 0, s.st, (int32_t*)s.best.p,
+                                       (const uint8_t*)s.text.p, (const uint32_t*)s.woff.p, J.lib->d_text, g.text_k, g.reverse,
+                                       n_reads, key0, J.d_counts, J.d_first);
+                    hipLaunchKernelGGL(k_collect_misses_long, dim3(grid_for(n_reads)), dim3(BLOCK), 0, s.st,
+                                       (const int32_t*)s.best.p, (const uint64_t*)d_packed, (const uint8_t*)s.text.p,
+                                       (const uint32_t*)s.woff.p, g.text_k, g.reverse, n_reads, key0, (uint64_t*)s.mw.p,
+                                       (uint64_t*)s.mk.p, (char*)s.mt.p, (unsigned long long*)(s.d_nodd + 2));
+                    BC_HIP(hipGetLastError());
+                } else if (!store) {
                     if ((rc2 = bc_match_dev(J.lib, d_packed, d_status, n_reads, J.max_mismatch, J.algo, (int32_t*)s.best.p,
                                             nullptr, nullptr, J.d_counts, J.d_first, key0, s.st)) != BC_OK) return rc2;
                     hipLaunchKernelGGL(k_collect_misses, dim3(grid_for(n_reads)), dim3(BLOCK), 0, s.st, (const int32_t*)s.best.p,
@@ -514,7 +649,7 @@ int run_file(FileJob& J) {
                 prof_us[4] += since(t_a);
                 if (fl[1]) { set_error("%s: a line longer than %llu bytes", path, (unsigned long long)SLACK); return BC_EINVAL; }
                 const uint64_t n_m = (uint64_t)fl[2] | ((uint64_t)fl[3] << 32);
-                if (n_m && (rc2 = J.misses->append(s.mw.p, s.mk.p, n_m, s.st)) != BC_OK) return rc2;
+                if (n_m && (rc2 = J.misses->append(s.mw.p, s.mk.p, s.mt.p, n_m, s.st)) != BC_OK) return rc2;
                 const uint32_t n_odd = fl[0];
                 if (n_odd > odd_cap) { set_error("%s: more than %u odd windows in one chunk", path, odd_cap); return BC_EINVAL; }
                 if (n_odd) {
@@ -571,9 +706,11 @@ struct bc_stream_result {
     int device = 0;
     uint64_t n_undoc = 0;
     uint64_t *d_words = nullptr, *d_counts = nullptr, *d_first = nullptr;
+    int text_k = 0;            // > 0: the undocumented windows are texts of that length (d_utext), sorted by their hash
+    char* d_utext = nullptr;
     ~bc_stream_result() {
-        if (d_words || d_counts || d_first) (void)hipSetDevice(device);
-        for (void* q : {(void*)d_words, (void*)d_counts, (void*)d_first}) if (q) (void)hipFree(q);
+        if (d_words || d_counts || d_first || d_utext) (void)hipSetDevice(device);
+        for (void* q : {(void*)d_words, (void*)d_counts, (void*)d_first, (void*)d_utext}) if (q) (void)hipFree(q);
     }
     std::vector<uint64_t> odd_keys, odd_off;  // odd_off: n_odd + 1 offsets into odd_text
     std::string odd_text;
@@ -629,6 +766,61 @@ int group_misses(MissList& M, int device, bc_stream_result* res) {
     res->n_undoc = n_u;
     res->d_words = (uint64_t*)uw.p; res->d_first = (uint64_t*)uf.p; res->d_counts = (uint64_t*)uc.p;
     uw.p = nullptr; uf.p = nullptr; uc.p = nullptr;  // ownership moves to the result
+    return BC_OK;
+}
+
+// the same for windows of more than 32 nt: the sort key is the text hash, every group's representative (its earliest
+// read) lends the text, and equal hashes are checked to hold equal texts
+int group_misses_long(MissList& M, int device, bc_stream_result* res) {
+    const unsigned long long n_miss = M.used;
+    res->text_k = M.text_k;
+    if (!n_miss) return BC_OK;
+    const unsigned nb = (unsigned)((n_miss + BLOCK - 1) / BLOCK);
+    DevBuf ord, h2, o2, tmp, uh, rep, uc, un, clash;
+    int rc3;
+    if ((rc3 = ord.reserve(n_miss * 8)) != BC_OK || (rc3 = h2.reserve(n_miss * 8)) != BC_OK || (rc3 = o2.reserve(n_miss * 8)) != BC_OK ||
+        (rc3 = uh.reserve(n_miss * 8)) != BC_OK || (rc3 = rep.reserve(n_miss * 8)) != BC_OK || (rc3 = uc.reserve(n_miss * 8)) != BC_OK ||
+        (rc3 = un.reserve(16)) != BC_OK || (rc3 = clash.reserve(16)) != BC_OK) return rc3;
+    hipLaunchKernelGGL(k_iota64, dim3(nb), dim3(BLOCK), 0, 0, (uint64_t*)ord.p, (uint64_t)n_miss);
+    BC_HIP(hipMemset(clash.p, 0, 16));
+    size_t tb = 0;
+    BC_HIP(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)M.words.p, (uint64_t*)h2.p, (uint64_t*)ord.p, (uint64_t*)o2.p,
+                                     (size_t)n_miss, 0, 64, 0));
+    if ((rc3 = tmp.reserve(tb)) != BC_OK) return rc3;
+    BC_HIP(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t*)M.words.p, (uint64_t*)h2.p, (uint64_t*)ord.p, (uint64_t*)o2.p,
+                                     (size_t)n_miss, 0, 64, 0));
+    hipLaunchKernelGGL(k_long_check_groups, dim3(nb), dim3(BLOCK), 0, 0, (const uint64_t*)h2.p, (const uint64_t*)o2.p,
+                       (const char*)M.texts.p, M.text_k, (uint64_t)n_miss, (uint32_t*)clash.p);
+    const EarlierMiss earlier{(const uint64_t*)M.keys.p, (uint64_t)n_miss};
+    size_t tb2 = 0;
+    BC_HIP(rocprim::reduce_by_key(nullptr, tb2, (uint64_t*)h2.p, (uint64_t*)o2.p, (size_t)n_miss, (uint64_t*)uh.p, (uint64_t*)rep.p,
+                                  (uint64_t*)un.p, earlier, rocprim::equal_to<uint64_t>(), 0));
+    if ((rc3 = tmp.reserve(tb2)) != BC_OK) return rc3;
+    BC_HIP(rocprim::reduce_by_key(tmp.p, tb2, (uint64_t*)h2.p, (uint64_t*)o2.p, (size_t)n_miss, (uint64_t*)uh.p, (uint64_t*)rep.p,
+                                  (uint64_t*)un.p, earlier, rocprim::equal_to<uint64_t>(), 0));
+    size_t tb4 = 0;
+    auto ones_it = rocprim::make_constant_iterator<uint64_t>(1);
+    BC_HIP(rocprim::reduce_by_key(nullptr, tb4, (uint64_t*)h2.p, ones_it, (size_t)n_miss, (uint64_t*)uh.p, (uint64_t*)uc.p,
+                                  (uint64_t*)un.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), 0));
+    if ((rc3 = tmp.reserve(tb4)) != BC_OK) return rc3;
+    BC_HIP(rocprim::reduce_by_key(tmp.p, tb4, (uint64_t*)h2.p, ones_it, (size_t)n_miss, (uint64_t*)uh.p, (uint64_t*)uc.p,
+                                  (uint64_t*)un.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), 0));
+    BC_HIP(hipDeviceSynchronize());
+    uint64_t n_u = 0;
+    uint32_t bad = 0;
+    BC_HIP(hipMemcpy(&n_u, un.p, 8, hipMemcpyDeviceToHost));
+    BC_HIP(hipMemcpy(&bad, clash.p, 4, hipMemcpyDeviceToHost));
+    if (bad) { set_error("two different undocumented windows share a 64-bit text hash: take the host path (BC_DEVICE_INGEST=0)"); return BC_ECAP; }
+    DevBuf uf, ut;
+    if ((rc3 = uf.reserve(n_u * 8 + 16)) != BC_OK || (rc3 = ut.reserve(n_u * (uint64_t)M.text_k + 16)) != BC_OK) return rc3;
+    hipLaunchKernelGGL(k_long_gather, dim3((unsigned)((n_u + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, (const uint64_t*)rep.p, n_u,
+                       (uint64_t)n_miss, (const uint64_t*)M.keys.p, (const char*)M.texts.p, M.text_k, (uint64_t*)uf.p, (char*)ut.p);
+    BC_HIP(hipGetLastError());
+    BC_HIP(hipDeviceSynchronize());
+    res->device = device;
+    res->n_undoc = n_u;
+    res->d_words = (uint64_t*)uh.p; res->d_first = (uint64_t*)uf.p; res->d_counts = (uint64_t*)uc.p; res->d_utext = (char*)ut.p;
+    uh.p = nullptr; uf.p = nullptr; uc.p = nullptr; ut.p = nullptr;  // ownership moves to the result
     return BC_OK;
 }
 
@@ -696,6 +888,22 @@ int bc_stream_result_odd(const bc_stream_result* r, uint64_t* keys, uint64_t* of
     return BC_OK;
 }
 
+int bc_stream_result_text_info(const bc_stream_result* r, int* text_k) {
+    if (!r || !text_k) { set_error("bc_stream_result_text_info: null"); return BC_EINVAL; }
+    *text_k = r->text_k;
+    return BC_OK;
+}
+
+int bc_stream_result_undoc_text(const bc_stream_result* r, char* text, uint64_t* counts, uint64_t* first) {
+    if (!r || !r->text_k || ((!text || !counts || !first) && r->n_undoc)) { set_error("bc_stream_result_undoc_text: no texts / null"); return BC_EINVAL; }
+    if (!r->n_undoc) return BC_OK;
+    BC_HIP(hipSetDevice(r->device));
+    BC_HIP(hipMemcpy(text, r->d_utext, r->n_undoc * (uint64_t)r->text_k, hipMemcpyDeviceToHost));
+    BC_HIP(hipMemcpy(counts, r->d_counts, r->n_undoc * 8, hipMemcpyDeviceToHost));
+    BC_HIP(hipMemcpy(first, r->d_first, r->n_undoc * 8, hipMemcpyDeviceToHost));
+    return BC_OK;
+}
+
 int bc_stream_result_pair_info(const bc_stream_result* r, uint64_t* n_pairs, uint64_t* text1_bytes, uint64_t* text2_bytes) {
     if (!r) { set_error("bc_stream_result_pair_info: null"); return BC_EINVAL; }
     if (n_pairs) *n_pairs = r->pair_keys.size();
@@ -730,6 +938,8 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
     int rc;
     if ((rc = fill_geometry(J.g, k, start, L, L_len, R, R_len, reverse, "bc_stream_count_file")) != BC_OK) return rc;
     if ((rc = file_kind(path, "bc_stream_count_file", &J.g.fastq)) != BC_OK) return rc;
+    J.g.text_k = lib->text_k;  // > 0: a library of text hashes with its texts attached (barcodes of more than 32 nt)
+    if (J.g.text_k && max_mismatch != 0) { set_error("bc_stream_count_file: barcodes of more than 32 nt are matched exactly"); return BC_EINVAL; }
     const auto t_begin = std::chrono::steady_clock::now();
     BC_HIP(hipSetDevice(device));
     struct stat sb;
@@ -742,7 +952,13 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
     if ((rc = d_first.reserve((size_t)G * 8)) != BC_OK) return rc;
     BC_HIP(hipMemset(d_counts.p, 0, (size_t)G * 4));
     BC_HIP(hipMemset(d_first.p, 0xFF, (size_t)G * 8));
-    if ((rc = misses.reserve(span / 24 + 65536)) != BC_OK) return rc;  // grown when the file holds more misses than that
+    misses.text_k = J.g.text_k;
+    {
+        uint64_t est = span / (uint64_t)(24 + J.g.text_k) + 65536;  // grown when the file holds more misses than that
+        const char* e = getenv("BC_STREAM_EST_PCT");               // (tests shrink the estimate to exercise the growth path)
+        if (e && atoi(e) > 0 && atoi(e) < 100) est = (span / (uint64_t)(24 + J.g.text_k)) * (uint64_t)atoi(e) / 100 + 16;
+        if ((rc = misses.reserve(est)) != BC_OK) return rc;
+    }
     J.lib = lib; J.path = path; J.byte_begin = byte_begin; J.byte_end = byte_end;
     J.max_mismatch = max_mismatch; J.algo = algo; J.n_threads = n_threads; J.key_base = key_base;
     J.d_counts = (uint32_t*)d_counts.p; J.d_first = (uint64_t*)d_first.p; J.misses = &misses;
@@ -753,7 +969,7 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
         res->n_reads = J.n_reads;
         int rc3 = tallies_to_host(G, d_counts, d_first, h_counts, h_first_seen);
         if (rc3 != BC_OK) return rc3;
-        if ((rc3 = group_misses(misses, device, res)) != BC_OK) return rc3;
+        if ((rc3 = (J.g.text_k ? group_misses_long(misses, device, res) : group_misses(misses, device, res))) != BC_OK) return rc3;
         res->odd_off.push_back(0);
         for (const OddOut& o : J.odd_all) {
             res->odd_keys.push_back(o.key);

@@ -725,8 +725,9 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     G = len(cc.labels)
     plan = shard_plan(file1, file2, world)
     # the device path takes a single uncompressed file whose start offset is known (not None after sampling)
-    # (barcodes of more than 32 nt take the host front half: text hashes + verification, see ChunkCounter._match)
-    device_ingest = (bc_len <= 32 and not is_paired and not file1.endswith((".gz", ".zst")) and (plan == "bytes" or world == 1)
+    # (barcodes of more than 32 nt: text hashes + verification on the device too; paired or compressed input takes the
+    # host front half, see ChunkCounter._match)
+    device_ingest = (not is_paired and not file1.endswith((".gz", ".zst")) and (plan == "bytes" or world == 1)
                      and (bc_start2 if need_swap else bc_start1) is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                      and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     # paired-end: two uncompressed files; with several ranks every rank takes byte ranges of both files that hold the same

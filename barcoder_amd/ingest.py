@@ -134,7 +134,14 @@ def stream_count_file(lib_handle, path: str, byte_begin: int, byte_end: int, sta
         n, nu, no, ob, sec = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
         N.check(lib.bc_stream_result_info(h, C.byref(n), C.byref(nu), C.byref(no), C.byref(ob), C.byref(sec)))
         uw, uc, uf = (np.empty(nu.value, np.uint64) for _ in range(3))
-        if nu.value:
+        tk = C.c_int()
+        N.check(lib.bc_stream_result_text_info(h, C.byref(tk)))
+        if tk.value:  # barcodes of more than 32 nt: the undocumented windows come as rows of text (void dtype, one per row)
+            rows = np.empty((nu.value, tk.value), np.uint8)
+            if nu.value:
+                N.check(lib.bc_stream_result_undoc_text(h, N.ptr(rows), N.ptr(uc), N.ptr(uf)))
+            uw = rows.view(np.dtype((np.void, tk.value))).reshape(-1)
+        elif nu.value:
             N.check(lib.bc_stream_result_undoc(h, N.ptr(uw), N.ptr(uc), N.ptr(uf)))
         odd = []
         if no.value:

@@ -204,3 +204,5 @@ class LongDeviceLibrary(DeviceLibrary):
             raise ValueError("two barcodes share a 64-bit hash (a 2^-64 event per pair): cannot index this library")
         super().__init__(hashes, 32, device, labels=seqs)
         self.text_k = k
+        # the texts next to the hashes in HBM: the device ingest path (bc_stream_count_file) verifies its own hits
+        N.check(N.load().bc_lib_attach_text(self.handle, N.ptr(np.ascontiguousarray(self.label_bytes)), k))

@@ -171,6 +171,10 @@ int bc_stream_result_undoc(const bc_stream_result *r, uint64_t *words, uint64_t 
                            uint64_t *first);
 int bc_stream_result_odd(const bc_stream_result *r, uint64_t *keys, uint64_t *off /* n_odd + 1 */,
                          char *text);
+/* libraries with attached texts (bc_lib_attach_text): the undocumented windows as texts (n_undoc x text_k
+ * characters, sorted by their hash) instead of packed words; *text_k = 0 for a packed library */
+int bc_stream_result_text_info(const bc_stream_result *r, int *text_k);
+int bc_stream_result_undoc_text(const bc_stream_result *r, char *text, uint64_t *counts, uint64_t *first);
 int bc_stream_result_free(bc_stream_result *r);
 
 /* bc_stream_count_pair: the paired-end form (heuristicount.py:469-518, reached from
@@ -245,6 +249,10 @@ int bc_lib_info(const bc_lib *lib, uint32_t *n_guides, int *k, int *device);
  * that launches on it.  A caller that creates and destroys streams releases a
  * stream's workspace before destroying the stream (waits for the stream). */
 int bc_lib_release_stream(bc_lib *lib, void *stream);
+/* Barcodes of 33 ... 1000 nt: the library was created with k = 32 over bc_hash_kmers of the texts; attaching the
+ * texts (n_guides x text_k characters) lets bc_stream_count_file take such a library: windows are hashed on the
+ * device, every hit is verified against the text there, the undocumented table carries texts. */
+int bc_lib_attach_text(bc_lib *lib, const char *h_text, int text_k);
 /* name of the match kernel the last bc_match_* call on this library launched
  * ("k_match_wq", "k_match_hash", "cascade3:d2+k_match_pairs", "k_match_seed", ...): lets a test assert
  * which path a (k, max_mismatch, library size) combination takes. */

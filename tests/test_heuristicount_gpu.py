@@ -135,7 +135,7 @@ def test_cli_twin(gpu_device, tmp_path):
 
 
 @pytest.mark.parametrize("k", [40, 120])
-def test_barcodes_longer_than_32_nt(gpu_device, oracle, tmp_path, k):
+def test_barcodes_longer_than_32_nt(gpu_device, oracle, tmp_path, k, monkeypatch):
     """heuristicount.py:75-97 admits barcodes up to 1 000 nt and its set lookup (:449-453) does not care about their
     length; the packed matcher holds 32 bases.  Longer barcodes go through a text hash in the GPU's exact table with
     every hit verified against the text: forward, reverse and paired chunks (N reads, short reads, odd characters,
@@ -197,3 +197,29 @@ def test_barcodes_longer_than_32_nt(gpu_device, oracle, tmp_path, k):
     with contextlib.redirect_stdout(buf):
         H.main(types.SimpleNamespace(fasta_file=str(fa), file1=str(rd), file2=None), device=gpu_device)
     assert buf.getvalue() == "".join(f"{key}\t{v}\n" for key, v in want.items() if not key.endswith("*"))
+    # a single uncompressed file goes through the device ingest path (bc_stream_count_file in text-hash mode); the host
+    # front half (BC_DEVICE_INGEST=0) and a file of reverse mates (need_swap) must give the same tables, in small chunks too
+    rv = tmp_path / "long_rev.reads"
+    rv.write_text("".join(m + "\n" for m in mates))
+    want_rev, _ = oracle.process_chunk_py((None, mates), lib, 5, 3, k, Lf, Rf, Lr, Rr, False)
+    for path, ref in ((rd, want), (rv, want_rev)):
+        tables = []
+        for env in ("1", "0"):
+            monkeypatch.setenv("BC_DEVICE_INGEST", env)
+            r = H.count_barcodes(str(fa), str(path), device=gpu_device)
+            tables.append((list(r["doc"].items()), dict(r["undoc"].items()), r["total_reads"], r["need_swap"]))
+        assert tables[0] == tables[1], path
+        assert tables[0][0] == [(key, v) for key, v in ref.items() if not key.endswith("*")], path
+        assert tables[0][1] == {key: v for key, v in ref.items() if key.endswith("*")}, path
+    assert tables[0][3] is True
+    # several 16 MiB chunks on several worker threads, the miss list grown past its (shrunken) first estimate
+    big = tmp_path / "long_big.reads"
+    big.write_text("".join(r + "\n" for r in fwd) * (60 if k == 40 else 30))
+    monkeypatch.setenv("BC_STREAM_EST_PCT", "1")
+    tables = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("BC_DEVICE_INGEST", env)
+        r = H.count_barcodes(str(fa), str(big), device=gpu_device)
+        tables.append((list(r["doc"].items()), dict(r["undoc"].items()), r["total_reads"]))
+    assert tables[0] == tables[1]
+    assert tables[0][2] == 6000 * (60 if k == 40 else 30)
