@@ -118,6 +118,7 @@ struct PairTable {
     const uint32_t* rests;        // [slabs][16]: bucket = slab number; overflow slabs behind the primaries
     const uint32_t* gidx;         // [slabs][16]: guide index of each slot (slot 15 unused)
     uint32_t a_start, a_len, b_start, b_len;   // key fields, in bases
+    uint32_t m_low, m_mid, m_high;  // rest of a plane p = (p & m_low) | ((p >> a_len) & m_mid) | ((p >> (a_len + b_len)) & m_high)
     uint32_t must_clean;          // rest positions of what is left of pieces a and b: a counted guide is clean there
     uint32_t other[3], n_other;   // rest positions of each piece c < b, c != a: a counted guide is dirty in every one
 };
@@ -138,6 +139,9 @@ struct Knobs {
     int phase_prof = 0;   // BC_PHASE_PROF=1: per-stage cycle sums of the wave kernel on stderr
     int host_pin = 1;     // BC_HOST_PIN=0: bc_match_host does not pin the caller's buffers
     int prefetch = 8;     // BC_PREFETCH: read-stream prefetch distance of k_match_wq in units of 128 tiles (0 = none)
+    int pair_group_kb = 3300;  // BC_PAIR_GROUP_KB: pair tables taken together in one pass of the cascade's second stage
+                          // (their slabs stay in an XCD's 4 MiB L2); 0: the one-kernel form over all ten tables
+    int pair_pass_min = 65536; // BC_PAIR_PASS_MIN_READS: launches below that take the one-kernel form (tests: 0)
     int cascade = 1;      // BC_CASCADE=0: d = 3 by the four-segment index over every read (round 1's path); 2: the pair
                           // index over every read (no d <= 2 pass first); 1: cascade
 };
@@ -150,6 +154,20 @@ struct TallyWs {
     uint32_t* ovf_count = nullptr; // self-resetting (k_first_refine)
     uint32_t* first_tile = nullptr;  // [G], 0xFFFFFFFF between launches
     uint64_t tiles_cap = 0;
+    // second stage of a cascade (bc_match_pairs.hip): the reads the first stage left without a hit, as a list
+    // (tile t of 256 reads owns entries [256 t, 256 t + casc_cnt[t]))
+    uint64_t* casc_read = nullptr;   // [256 casc_tiles] the read (masked)
+    uint32_t* casc_pos = nullptr;    // [256 casc_tiles] its position
+    uint64_t* casc_state = nullptr;  // [256 casc_tiles] best so far between table groups {distance, ties, lowest index}
+    uint32_t* casc_cnt = nullptr;    // [casc_tiles]
+    uint64_t casc_tiles = 0;
+    // ... and packed for the passes over the table groups: entry j of casc_count[0]
+    uint32_t* casc_off = nullptr;    // [casc_tiles] exclusive prefix sum of casc_cnt
+    uint64_t* casc_dread = nullptr;  // [256 casc_tiles]
+    uint32_t* casc_dpos = nullptr;   // [256 casc_tiles]
+    unsigned long long* casc_count = nullptr;
+    void* casc_scan_tmp = nullptr;   // rocprim scratch of the prefix sum
+    size_t casc_scan_bytes = 0;
 };
 
 }  // namespace bc
@@ -178,6 +196,7 @@ struct bc_lib {
     bool slab_ok[bc::MAX_SEG] = {false, false, false, false};
     bool slab_wide[bc::MAX_SEG] = {false, false, false, false};  // wide entries: only k_match_wq reads them
     const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<uint32_t> pair_slabs;          // slabs of each pair table (64 bytes each): the second stage groups by size
     const bc::PairParams* d_pairs = nullptr;   // 3-mismatch pair index (NULL: not built yet, or k outside 8..25)
     bool pairs_tried = false;                  // under ws_mutex
     std::vector<uint2> fast_stage[4];          // library creation only: regions of SlabParams::fast before upload

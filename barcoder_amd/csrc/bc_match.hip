@@ -436,7 +436,10 @@ constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 
 // (amdgpu_waves_per_eu(6) is a register-budget floor — at least six waves per SIMD, i.e. at most 80 VGPRs — not the
 // occupancy: the kernel uses 55 VGPRs and 5.5 KiB of LDS per single-wave workgroup, so 29 workgroups fit a CU's 160 KiB:
 // seven waves per SIMD run.)
-template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01, bool FAST = false>
+// LIST: the first stage of a cascade — the reads left without a hit also go on the second stage's list (MatchOut::miss_*).
+// Its own instantiation: the default kernel carries none of it (the list entry kept for a miss, the ballots at the end:
+// +0.03 ms per 1e8 reads when they sat in the one kernel).
+template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01, bool FAST = false, bool LIST = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wq(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,
                                                    const uint8_t* __restrict__ flags, uint64_t n, int k,
@@ -449,6 +452,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     // FAST: tables 0/1 in their second form (FastTable): primary slabs of eight entries, the next seven at an implied
     // address; an item's slab number then counts in the secondary region, item code 3 = a primary slab of table 1
     static_assert(!FAST || (!WIDE && NQ01 == 1), "the second form exists for 64-byte slabs of 8-byte entries");
+    static_assert(!LIST || (!WIDE && NQ01 == 1), "the list form is instantiated for 64-byte slabs of 8-byte entries");
     constexpr uint32_t S01 = NQ01 == 2 ? 7u : 6u;     // log2 of that slab's bytes
     (void)o_arg;  // read from the kernel-argument segment in the last phase, see there
     __shared__ uint64_t q_read[WAVE_T];                                 // listed read; later its result
@@ -501,6 +505,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     };
     auto put = [&](uint32_t qi, uint32_t idx, uint32_t dist, uint32_t nb) {
         q_read[qi] = (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)(nb > 255u ? 255u : nb) << 40);
+    };
+    // no guide within the budget.  LIST: up to 31 bases the listed read stays where it is with bit 63 set (free: the
+    // planes end below it, and a result record has zeros there) — the second stage gets the read from there; a
+    // 32-mer has no free bit and takes the plain record
+    auto put_miss = [&](uint32_t qi) {
+        if (!LIST || k > 31) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+        else __hip_atomic_fetch_or(&q_read[qi], 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     uint32_t qn = 0, t2n = 0, sn = 0, wn = 0, tien = 0;  // wave-uniform list lengths
 
@@ -595,7 +606,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         const bool inrange = mine && d <= max_mm;
         const bool tie = inrange && !key_unique(kmin, max_mm) && !(diag & 4u);
         if (inrange && !tie) put(qi, kmin & SLAB_GIDX_MASK, d, 1u);
-        if (mine && !inrange && final_miss) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+        if (mine && !inrange && final_miss) put_miss(qi);
         const unsigned long long m = __ballot(tie);
         if (tie) l_tie[tien + rank_of(m)] = (uint16_t)qi;
         tien += (uint32_t)__popcll(m);
@@ -792,7 +803,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
                 }
                 pass = ((hit[0] | hit[1]) & (hit[2] | hit[3])) != 0u;
             }
-            if (mine && !inrange && !pass) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+            if (mine && !inrange && !pass) put_miss(qi);
             const unsigned long long m = __ballot(pass);
             if (pass) l_t2[t2n + rank_of(m)] = (uint16_t)qi;
             t2n += (uint32_t)__popcll(m);
@@ -862,7 +873,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             else slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), (int)max_mm, s, last_lane, key, nb);
             if (s == 0) {
                 if ((key >> 24) <= max_mm) put(qi, key & SLAB_GIDX_MASK, key >> 24, nb);
-                else put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
+                else put_miss(qi);
             }
         }
         wave_lds_sync();
@@ -884,6 +895,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         const MatchOut o = o_arg;  // host pass of the single-source compile: never executed
 #endif
         uint32_t dist[4], nb[4];
+        uint64_t mr[4] = {0, 0, 0, 0};  // the reads that found nothing (narrow entries: see put_miss)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             dist[j] = idx[j] >= 0 ? ((dist4 >> (8 * j)) & 0xFFu) : (uint32_t)BC_DIST_NONE;
@@ -891,6 +903,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             if (at[j] != 0xFFFFFFFFu) {
                 const uint64_t e = q_read[at[j]];
                 idx[j] = (int32_t)(uint32_t)e; dist[j] = (uint32_t)(e >> 32) & 0xFFu; nb[j] = (uint32_t)(e >> 40) & 0xFFu;
+                if (LIST && k <= 31 && (e >> 63)) { idx[j] = BC_IDX_MISS; dist[j] = (uint32_t)BC_DIST_NONE; nb[j] = 0u; mr[j] = e & ~(1ull << 63); }
             }
         }
         if (full) {
@@ -924,6 +937,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             static_assert(sizeof(q_read) >= PART_SLOTS * sizeof(uint16_t) && WL_CAP >= PART_MAX_NR, "record staging");
             wave_lds_sync();
             part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_read), wl);
+        }
+        if (LIST && o.miss_cnt) {
+            // first stage of a cascade: the reads left without a hit go on the second stage's list (position, read), in
+            // this tile's own 256 entries — no atomic, and the read is still in the list entry (put_miss; a cascade
+            // exists for k <= 25 only.  Fetching it from memory again made 24 more requests per tile: +0.2 ms)
+            uint32_t off[4], mtot = 0;
+            bool ms[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ms[j] = p0 + j < tn && idx[j] == BC_IDX_MISS;
+                const unsigned long long m = __ballot(ms[j]);
+                off[j] = mtot + rank_of(m);
+                mtot += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) o.miss_cnt[blockIdx.x] = mtot;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ms[j]) {
+                    o.miss_pos[tile0 + off[j]] = (uint32_t)(tile0 + p0 + j);
+                    o.miss_read[tile0 + off[j]] = k > 31 ? (reads[tile0 + p0 + j] & kmask) : mr[j];
+                }
         }
     }
     phase_mark(3);
@@ -1739,6 +1773,35 @@ int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, 
     return BC_OK;
 }
 
+// the miss list of a cascade's second stage: room for every read of the launch (all of them may miss)
+int cascade_workspace_impl(bc_lib* lib, hipStream_t st, uint64_t n, TallyWs** out) {
+    std::lock_guard<std::mutex> g(lib->ws_mutex);
+    TallyWs* w = nullptr;
+    int rc = stream_workspace(lib, st, &w);
+    if (rc != BC_OK) return rc;
+    const uint64_t tiles = (n + 255) >> 8;
+    if (tiles > w->casc_tiles) {
+        BC_HIP(hipStreamSynchronize(st));  // nothing of this stream may still use the old buffers
+        for (void* p : {(void*)w->casc_read, (void*)w->casc_pos, (void*)w->casc_state, (void*)w->casc_cnt, (void*)w->casc_off,
+                        (void*)w->casc_dread, (void*)w->casc_dpos, (void*)w->casc_count, w->casc_scan_tmp}) if (p) (void)hipFree(p);
+        w->casc_read = nullptr; w->casc_pos = nullptr; w->casc_state = nullptr; w->casc_cnt = nullptr; w->casc_tiles = 0;
+        w->casc_off = nullptr; w->casc_dread = nullptr; w->casc_dpos = nullptr; w->casc_count = nullptr; w->casc_scan_tmp = nullptr;
+        BC_HIP(hipMalloc((void**)&w->casc_read, tiles * 256 * 8));
+        BC_HIP(hipMalloc((void**)&w->casc_pos, tiles * 256 * 4));
+        BC_HIP(hipMalloc((void**)&w->casc_state, tiles * 256 * 8));
+        BC_HIP(hipMalloc((void**)&w->casc_cnt, tiles * 4));
+        BC_HIP(hipMalloc((void**)&w->casc_off, tiles * 4));
+        BC_HIP(hipMalloc((void**)&w->casc_dread, tiles * 256 * 8));
+        BC_HIP(hipMalloc((void**)&w->casc_dpos, tiles * 256 * 4));
+        BC_HIP(hipMalloc((void**)&w->casc_count, 16));
+        w->casc_scan_bytes = cascade_scan_bytes(tiles);
+        BC_HIP(hipMalloc(&w->casc_scan_tmp, std::max<size_t>(w->casc_scan_bytes, 16)));
+        w->casc_tiles = tiles;
+    }
+    *out = w;
+    return BC_OK;
+}
+
 int launch_hist_part(bc_lib* lib, const MatchOut& o, const TallyWs* w, uint64_t n, uint64_t tail_begin, hipStream_t st) {
     int rc = ensure_big_lds(k_hist_part, lib->device, HIST_LDS_BYTES);
     if (rc != BC_OK) return rc;
@@ -1784,9 +1847,18 @@ int launch_cascade(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags,
         if (o.n_best) o.n_best += a;
         o.base += a;
         o.part = PartOut{};
-        int rc = launch_match(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, max_mm - 1, BC_ALGO_SEED, o, st);
+        o.miss_pos = nullptr; o.miss_read = nullptr; o.miss_cnt = nullptr; o.miss_listed = nullptr;  // (an outer cascade's list is not ours)
+        TallyWs* w = nullptr;
+        bool listed = false;
+        MatchOut o1 = o;
+        if (cascade_uses_list(lib, m)) {  // the second stage works from a list: the first stage may as well write it
+            int rcw = cascade_workspace_impl(lib, st, m, &w);
+            if (rcw != BC_OK) return rcw;
+            o1.miss_pos = w->casc_pos; o1.miss_read = w->casc_read; o1.miss_cnt = w->casc_cnt; o1.miss_listed = &listed;
+        }
+        int rc = launch_match(lib, d_reads + a, d_flags ? d_flags + a : nullptr, m, max_mm - 1, BC_ALGO_SEED, o1, st);
         if (rc != BC_OK) return rc;
-        rc = launch_cascade_stage2(lib, max_mm, d_reads + a, m, o, st);
+        rc = launch_cascade_stage2(lib, max_mm, d_reads + a, m, o, st, w, listed);
         if (rc != BC_OK) return rc;
     }
     note_kernel(lib, max_mm == 3 ? "cascade3:d2+k_match_pairs" : "cascade2:d1+k_match_pairs");
@@ -1941,16 +2013,20 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     (void)prof;
 #endif
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
+                    const bool listing = o.miss_cnt != nullptr && !wide && nq01 == 1;  // (the shapes the list form exists for)
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
 #define BC_WAVE_FAST(NSEG_, NQ2_)                                                                                    \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
+#define BC_WAVE_LIST(NSEG_, NQ2_, FAST_)                                                                             \
+    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, FAST_, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
+                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
 #ifdef BC_DIAG_BUILD
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (listing && hp.fast.ok) BC_WAVE_LIST(NSEG_, NQ2_, true); else if (listing) BC_WAVE_LIST(NSEG_, NQ2_, false); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
 #else
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (listing && hp.fast.ok) BC_WAVE_LIST(NSEG_, NQ2_, true); else if (listing) BC_WAVE_LIST(NSEG_, NQ2_, false); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
 #endif
                     if (!wide && nq01 == 1) {
                         if (nseg == 2) BC_WAVE_P(2, 1);
@@ -1967,11 +2043,13 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                         else BC_WAVE_LAUNCH(3, 4, false, true, 2);
                     }
 #undef BC_WAVE_P
+#undef BC_WAVE_LIST
 #undef BC_WAVE_FAST
 #undef BC_WAVE_LAUNCH
                     note_kernel(lib, "k_match_wq");
                     BC_HIP(hipGetLastError());
                     if (o.part.rec) { *part_done = true; *tail_begin = n; }
+                    if (listing && o.miss_listed) *o.miss_listed = true;  // (a cascade's first stage: the list is written)
 #ifdef BC_DIAG_BUILD
                     if (prof) {
                         unsigned long long c[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2018,6 +2096,10 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
 }
 
 }  // namespace
+
+namespace bc {
+int cascade_workspace(bc_lib* lib, hipStream_t st, uint64_t n, TallyWs** out) { return cascade_workspace_impl(lib, st, n, out); }
+}  // namespace bc
 
 constexpr int HOST_WORKERS = 6;  // worker threads (and staging slots) of bc_match_host
 struct HostSlot {
@@ -2240,6 +2322,8 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.tally = env_int("BC_TALLY", 0);
     lib->knobs.host_pin = env_int("BC_HOST_PIN", 1);
     lib->knobs.cascade = env_int("BC_CASCADE", 1);
+    lib->knobs.pair_group_kb = env_int("BC_PAIR_GROUP_KB", 3300);
+    lib->knobs.pair_pass_min = env_int("BC_PAIR_PASS_MIN_READS", 65536);
     lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));
     {
         PartOut pg{};
@@ -2278,7 +2362,9 @@ int bc_lib_destroy(bc_lib* lib) {
     (void)hipDeviceSynchronize();
     for (void* p : lib->owned) (void)hipFree(p);
     for (auto& w : lib->ws)
-        for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)w.rec, (void*)w.ovf_list, (void*)w.ovf_count, (void*)w.first_tile, (void*)w.casc_read, (void*)w.casc_pos,
+                        (void*)w.casc_state, (void*)w.casc_cnt, (void*)w.casc_off, (void*)w.casc_dread, (void*)w.casc_dpos,
+                        (void*)w.casc_count, w.casc_scan_tmp}) if (p) (void)hipFree(p);
     if (lib->host_slots) {
         HostSlot* hs = (HostSlot*)lib->host_slots;
         for (int w = 0; w < HOST_WORKERS; ++w) slot_release(hs[w]);
@@ -2310,7 +2396,9 @@ int bc_lib_release_stream(bc_lib* lib, void* stream) {
         if (it->stream != stream) continue;
         BC_HIP(hipSetDevice(lib->device));
         BC_HIP(hipStreamSynchronize((hipStream_t)stream));  // nothing of this stream may still use the buffers
-        for (void* p : {(void*)it->rec, (void*)it->ovf_list, (void*)it->ovf_count, (void*)it->first_tile}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)it->rec, (void*)it->ovf_list, (void*)it->ovf_count, (void*)it->first_tile, (void*)it->casc_read,
+                        (void*)it->casc_pos, (void*)it->casc_state, (void*)it->casc_cnt, (void*)it->casc_off, (void*)it->casc_dread,
+                        (void*)it->casc_dpos, (void*)it->casc_count, it->casc_scan_tmp}) if (p) (void)hipFree(p);
         lib->ws.erase(it);
         break;
     }

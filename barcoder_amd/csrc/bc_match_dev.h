@@ -39,7 +39,18 @@ struct MatchOut {
     uint64_t* first_seen;  // idem
     uint64_t base;
     PartOut part;
+    // first stage of a cascade (launch_cascade): the reads left at BC_IDX_MISS also go on a list — position in this
+    // launch and masked read — for the second stage.  NULL otherwise.  The list is laid out by TILE of 256 reads:
+    // tile t owns entries [256 t, 256 t + miss_cnt[t]) — no atomics, no order between tiles (one shared counter
+    // serialised the tiles' atomics: 3.7 ms per 1e8 reads; 1 024 counters still cost every wave an atomic round trip
+    // at its end: +0.23 ms).  k_match_wq fills it (its launcher then sets *miss_listed, a HOST flag); after any other
+    // kernel the second stage gathers the list from best_idx itself (k_cascade_collect).
+    uint32_t* miss_pos = nullptr;
+    uint64_t* miss_read = nullptr;
+    uint32_t* miss_cnt = nullptr;
+    bool* miss_listed = nullptr;
 };
+
 
 // launchers of bc_match_quad.hip (the kernels stay in their own file; see there for when they run)
 int launch_quad_fused(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n,
@@ -51,7 +62,11 @@ int launch_quad_slab(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uin
 int build_pair_index(bc_lib* lib);
 int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o,
                  hipStream_t st);
-int launch_cascade_stage2(bc_lib* lib, int max_mm, const uint64_t* d_reads, uint64_t n, const MatchOut& o, hipStream_t st);
+bool cascade_uses_list(const bc_lib* lib, uint64_t n);  // the second stage as passes over table groups (needs the workspace)
+size_t cascade_scan_bytes(uint64_t tiles);  // rocprim scratch for the prefix sum over that many tile counts
+int cascade_workspace(bc_lib* lib, hipStream_t st, uint64_t n, TallyWs** out);
+int launch_cascade_stage2(bc_lib* lib, int max_mm, const uint64_t* d_reads, uint64_t n, const MatchOut& o, hipStream_t st,
+                          TallyWs* w, bool listed);
 
 }  // namespace bc
 

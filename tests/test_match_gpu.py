@@ -441,8 +441,13 @@ def test_three_mismatch_pair_index(gpu_device, oracle, k, cluster, monkeypatch):
         assert (ref["best_dist"] == 3).sum() > 500
         if cluster:
             assert ((ref["n_best"] > 1) & (ref["best_dist"] == 3)).sum() > 50
-    for mode, want in (("1", "cascade3:d2+k_match_pairs"), ("2", "k_match_pairs"), ("0", None)):
-        monkeypatch.setenv("BC_CASCADE", mode)
+    # ("1p", "1g": the second stage as passes over table groups — one table per pass, a few per pass — which large
+    # launches on large libraries take by default; the state carried between passes must give the same ties)
+    for mode, want in (("1", "cascade3:d2+k_match_pairs"), ("1p", "cascade3:d2+k_match_pairs"), ("1g", "cascade3:d2+k_match_pairs"),
+                       ("2", "k_match_pairs"), ("0", None)):
+        monkeypatch.setenv("BC_CASCADE", mode[0])
+        monkeypatch.setenv("BC_PAIR_PASS_MIN_READS", "0" if len(mode) > 1 else "65536")
+        monkeypatch.setenv("BC_PAIR_GROUP_KB", {"1p": "1", "1g": "200"}.get(mode, "3300"))
         dl = DeviceLibrary(lib, k, gpu_device)
         _check(GpuMatcher(dl).match(reads, flags, max_mismatch=3, algo="seed", first_index=9), ref)
         if want:  # (a dense library of short k-mers may leave the second stage nothing to do)
