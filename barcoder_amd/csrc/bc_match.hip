@@ -247,6 +247,13 @@ __device__ __forceinline__ uint4 load16(const char* base, uint32_t off) {
     const u32x4 t = *(gquarter_t)(uintptr_t)(base + off);
     return make_uint4(t.x, t.y, t.z, t.w);
 }
+// the same for the filter lines and neighbour lists (pointers out of the same descriptor)
+typedef const uint32_t __attribute__((address_space(1)))* gword_t;
+__device__ __forceinline__ uint32_t gload32(const uint32_t* p, size_t i) { return ((gword_t)(uintptr_t)p)[i]; }
+__device__ __forceinline__ uint4 gload128(const uint4* p, size_t i) {
+    const u32x4 t = ((gquarter_t)(uintptr_t)p)[i];
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
 
 // Two entry formats share the slab layout.  NARROW (k - seed <= 16 bases): 8-byte entries {rest, giw}, both planes of
 // the rest packed into one dword (hi plane << half); a 16-byte piece holds two.  WIDE (longer rests, k up to 32):
@@ -799,7 +806,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
 #pragma unroll
                 for (int hh = 0; hh < 4; ++hh) {
                     const uint32_t bit = flt_hash7(seed_value(rlo, rhi, sp.f_pos[hh], sp.f_len[hh]));
-                    hit[hh] = (line[hh * 4 + (bit >> 5)] >> (bit & 31u)) & 1u;
+                    hit[hh] = (gload32(line, hh * 4 + (bit >> 5)) >> (bit & 31u)) & 1u;
                 }
                 pass = ((hit[0] | hit[1]) & (hit[2] | hit[3])) != 0u;
             }
@@ -840,11 +847,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         const uint32_t kmin = q_key[qi];
         const uint32_t d1 = kmin >> 24, g0 = kmin & SLAB_GIDX_MASK;
         uint32_t slot = NBR_NONE;
-        if (act && sp.nbr_slot) slot = sp.nbr_slot[g0];
+        if (act && sp.nbr_slot) slot = gload32(sp.nbr_slot, g0);
         const bool listed = slot < NBR_OVER;
         uint32_t cnt = 0, best = g0;
         if (listed) {
-            const uint4 e0 = sp.nbr[(size_t)slot * NBR_CAP + s], e1 = sp.nbr[(size_t)slot * NBR_CAP + s + 4];
+            const uint4 e0 = gload128(sp.nbr, (size_t)slot * NBR_CAP + s), e1 = gload128(sp.nbr, (size_t)slot * NBR_CAP + s + 4);
             const bool t0 = e0.w != 0u && (uint32_t)__popc((rlo ^ e0.x) | (rhi ^ e0.y)) == d1;
             const bool t1 = e1.w != 0u && (uint32_t)__popc((rlo ^ e1.x) | (rhi ^ e1.y)) == d1;
             cnt = (t0 ? 1u : 0u) + (t1 ? 1u : 0u);
