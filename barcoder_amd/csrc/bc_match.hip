@@ -1895,7 +1895,8 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     if (algo == BC_ALGO_SEED && max_mm == 2 && lib->knobs.cascade == 1 && lib->knobs.lane && aligned16(o_in.best_idx)) {
         int q01, q2;
         const bool vec_ok = vector_io_ok(d_reads, o_in, n);
-        if (!wave_kernel_serves(lib, 2, algo, vec_ok, &q01, &q2) && wave_kernel_serves(lib, 1, algo, vec_ok, &q01, &q2)) {
+        const bool big = lib->knobs.cascade2_min_g > 0 && lib->G >= (uint32_t)lib->knobs.cascade2_min_g;
+        if ((big || !wave_kernel_serves(lib, 2, algo, vec_ok, &q01, &q2)) && wave_kernel_serves(lib, 1, algo, vec_ok, &q01, &q2)) {
             int rc = ensure_pair_index(lib);
             if (rc != BC_OK) return rc;
             if (lib->d_pairs) return launch_cascade(lib, d_reads, d_flags, n, 2, o_in, st);
@@ -2331,6 +2332,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.cascade = env_int("BC_CASCADE", 1);
     lib->knobs.pair_group_kb = env_int("BC_PAIR_GROUP_KB", 3300);
     lib->knobs.pair_pass_min = env_int("BC_PAIR_PASS_MIN_READS", 65536);
+    lib->knobs.cascade2_min_g = env_int("BC_CASCADE2_MIN_G", 0);
     lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));
     {
         PartOut pg{};
