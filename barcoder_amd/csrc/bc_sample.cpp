@@ -231,6 +231,7 @@ extern "C" {
 int bc_sample_data(const char* file1, const char* file2, const char* barcodes, uint32_t G, int k, bc_sample** out) {
     if (!file1 || !barcodes || !out || G == 0 || k < 1) { set_error("bc_sample_data: bad argument"); return BC_EINVAL; }
     const bool paired = file2 && *file2;
+    const auto t_entry = std::chrono::steady_clock::now();
     // the library and its reverse complements as two contiguous blobs (no per-entry allocation), the sets hold views
     std::vector<char> rev_blob((size_t)G * k);
     auto fwd_at = [&](uint32_t g) { return std::string_view(barcodes + (size_t)g * k, (size_t)k); };
@@ -251,7 +252,11 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         }
     }
     StrSet fwd(G, false), rev(G, false);
-    for (uint32_t g = 0; g < G; ++g) { fwd.insert(fwd_at(g)); rev.insert(rev_at(g)); }
+    {
+        std::thread other([&] { for (uint32_t g = 0; g < G; ++g) rev.insert(rev_at(g)); });
+        for (uint32_t g = 0; g < G; ++g) fwd.insert(fwd_at(g));
+        other.join();
+    }
     const uint64_t n_lib = fwd.size();  // len(barcodes) of the SET (heuristicount.py:174-176)
     // Pre-filter for the k-mer sweep (most windows of a read are no barcode): 2^24 bits set at a hash of the packed
     // value of every library entry and reverse complement.  Only when every entry is pure upper-case ACGT and fits a
@@ -279,16 +284,25 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
 
     const bool prof = getenv("BC_SAMPLE_PROF") != nullptr;  // tuning aid: where the sampling pass spends its time
     auto now = [] { return std::chrono::steady_clock::now(); };
-    double t_setup = 0, t_read = 0, t_sweep = 0;
+    double t_setup = 0, t_read = 0, t_sweep = 0, t_prep = 0, t_rem = 0;
     static thread_local std::chrono::steady_clock::time_point t_enter;
-    t_setup = 0;
+    t_setup = std::chrono::duration<double, std::milli>(now() - t_entry).count();
     auto t_mark = now();
     int64_t div[2] = {0, 0};
     OrderedCounter<int> orients[2];      // 0 = "forward", 1 = "reverse"
     OrderedCounter<int64_t> offsets[2];
     std::vector<std::string> valid_store[2];
-    StrSet valid[2] = {StrSet(2 * (size_t)n_lib), StrSet(2 * (size_t)n_lib)}, seen_reads(6 * (size_t)n_lib), observed(2 * (size_t)n_lib);
+    // (single-end runs with the pre-filter count their distinct reads in seen_part instead: no table to clear for nothing)
+    StrSet valid[2] = {StrSet(2 * (size_t)n_lib), StrSet(paired ? 2 * (size_t)n_lib : 0)},
+           seen_reads((!paired && prefilter) ? 0 : 6 * (size_t)n_lib), observed(2 * (size_t)n_lib);
     StrSet c_barcodes((size_t)n_lib, false), c_reads((size_t)n_lib, false);  // per chunk: views into the chunk's text
+    std::vector<StrSet> seen_part;  // single-end runs with the pre-filter: seen_reads in eight parts (see `remember`)
+    for (int p = 0; p < 8; ++p) seen_part.emplace_back((size_t)0);  // (they grow inside their own threads)
+    auto seen_count = [&]() {
+        size_t n = seen_reads.size();
+        for (const StrSet& p : seen_part) n += p.size();
+        return n;
+    };
     uint64_t all_novel = 0;
     bool satisfied = false;
     uint64_t n_chunks = 0;
@@ -315,13 +329,14 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         // runs the reference's sequential logic unchanged on warm lines.
         constexpr uint64_t AHEAD = 12;
         constexpr int MAXC = 6;
-        struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint64_t hk[MAXC]; };
+        struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint64_t hk[MAXC]; uint8_t in[MAXC]; };  // in: bit 0 forward set, bit 1 reverse
         const bool lookahead = !paired && prefilter;
-        // what a read contributes before any set is consulted — its hash, the windows that pass the pre-filter, their
-        // hashes — is a pure function of the read: computed for the whole chunk by worker threads (this was two thirds
-        // of the sampling pass on one thread); the order-dependent set logic below then runs alone, prefetching the
-        // slots of the reads a few places ahead
+        // what a read contributes before any growing set is consulted — its hash, the windows that ARE library entries
+        // (pre-filter, then the two library sets, which never change) — is a pure function of the read: computed for the
+        // whole chunk by worker threads; the order-dependent logic below then touches only the reads that hold a
+        // library k-mer (the reference's loop does nothing for the others except remember the read: see seen_part)
         std::vector<Ahead> prep(lookahead ? nz : 0);
+        std::vector<std::thread> rem_threads;
         auto prepare = [&](uint64_t q) {
             Ahead& a = prep[q];
             const std::string_view rd = c1.read(q);
@@ -345,29 +360,47 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 if (!((small[hs >> 6] >> (hs & 63)) & 1ull)) continue;
                 const uint32_t hb = Roll::hash(v);
                 if (!((big[hb >> 6] >> (hb & 63)) & 1ull)) continue;
-                if (a.ncand == MAXC) { a.overflow = true; break; }
                 const size_t i = e + 1 - (size_t)k;
-                a.pos[a.ncand] = (uint32_t)i; a.hk[a.ncand] = str_hash(rd.substr(i, k)); ++a.ncand;
+                const std::string_view kmer = rd.substr(i, k);
+                const uint64_t hk = str_hash(kmer);
+                const uint8_t in = (uint8_t)((fwd.contains(hk, kmer) ? 1 : 0) | (rev.contains(hk, kmer) ? 2 : 0));
+                if (!in) continue;  // (a false positive of the pre-filter)
+                if (a.ncand == MAXC) { a.overflow = true; break; }
+                a.pos[a.ncand] = (uint32_t)i; a.hk[a.ncand] = hk; a.in[a.ncand] = in; ++a.ncand;
             }
         };
         auto warm = [&](uint64_t q) {  // pull the slots read q will touch towards the core
             const Ahead& a = prep[q];
-            c_reads.prefetch(a.h1); seen_reads.prefetch(a.h1); valid[0].prefetch(a.h1);
-            for (int c = 0; c < a.ncand; ++c) {
-                c_barcodes.prefetch(a.hk[c]); fwd.prefetch(a.hk[c]); rev.prefetch(a.hk[c]); observed.prefetch(a.hk[c]);
+            if (a.ncand) valid[0].prefetch(a.h1);
+            for (int c = 0; c < a.ncand; ++c) { c_barcodes.prefetch(a.hk[c]); observed.prefetch(a.hk[c]); }
+        };
+        // seen_reads only ever answers "how many distinct reads so far": eight sets, one per range of the hash, filled by
+        // as many threads (every thread looks at every read's hash and keeps its own)
+        auto remember = [&](unsigned part0, unsigned step) {
+            for (uint64_t q = 0; q < nz; ++q) {
+                const unsigned part = (unsigned)(prep[q].h1 >> 61);
+                if (part % step == part0) seen_part[part].insert(prep[q].h1, c1.read(q));
             }
         };
         if (lookahead) {
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(8, hw), nz / 4096 + 1));
+            const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(16, hw), nz / 4096 + 1));
+            const auto t_p0 = now();
             if (T == 1) {
                 for (uint64_t q = 0; q < nz; ++q) prepare(q);
+                t_prep += std::chrono::duration<double, std::milli>(now() - t_p0).count();
+                remember(0, 1);
             } else {
                 std::vector<std::thread> th;
                 const uint64_t per = (nz + T - 1) / T;
                 for (uint64_t t = 0; t < T; ++t)
                     th.emplace_back([&, t] { for (uint64_t q = t * per; q < std::min(nz, (t + 1) * per); ++q) prepare(q); });
                 for (auto& x : th) x.join();
+                th.clear();
+                t_prep += std::chrono::duration<double, std::milli>(now() - t_p0).count();
+                // (they run beside the order-dependent loop below, which touches none of their sets; joined behind it)
+                const unsigned step = T >= 8 ? 8u : T >= 4 ? 4u : 2u;  // (eight parts: a divisor of eight threads take them)
+                for (unsigned t = 0; t < step; ++t) rem_threads.emplace_back([&, t] { remember(t, step); });
             }
             for (uint64_t q = 0; q < std::min<uint64_t>(AHEAD, nz); ++q) warm(q);
         }
@@ -381,23 +414,23 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 const Ahead& a = prep[q];
                 if (q + AHEAD < nz) warm(q + AHEAD);
                 const uint64_t h1 = a.h1;
-                if (c_reads.contains(h1, read1)) continue;
-                seen_reads.insert(h1, read1);
-                if ((int64_t)read1.size() < k) continue;
+                // (the reference skips a read that equals an earlier valid read of the chunk: that read's library
+                // k-mers are all in c_barcodes by then, so going through them again changes nothing — no c_reads here;
+                // and it remembers every other read in seen_reads: done above, by the partitions)
+                if (a.ncand == 0 && !a.overflow) continue;
                 if (!a.overflow) {
-                    // the windows that pass the pre-filter, in ascending position: exactly the iterations of the loop
-                    // below that do anything
+                    // the windows that are library entries, in ascending position: exactly the iterations of the
+                    // reference's loop that do anything
                     for (int c = 0; c < a.ncand; ++c) {
                         const size_t i = a.pos[c];
                         const uint64_t hk = a.hk[c];
                         const std::string_view kmer = read1.substr(i, k);
                         if (c_barcodes.contains(hk, kmer)) continue;
                         for (int lib = 0; lib < 2; ++lib)
-                            if ((lib == 0 ? fwd : rev).contains(hk, kmer)) {
+                            if (a.in[c] & (1 << lib)) {
                                 div[0]++; c_barcodes.insert(hk, kmer); observed.insert(hk, kmer);
                                 c_or[0].push_back(lib); c_off[0].push_back((int64_t)i);
                                 if (valid[0].insert(h1, read1)) valid_store[0].emplace_back(read1);
-                                c_reads.insert(h1, read1);
                             }
                     }
                     continue;
@@ -455,6 +488,11 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 }
             }
         }
+        {
+            const auto t_r0 = now();
+            for (auto& x : rem_threads) x.join();
+            t_rem += std::chrono::duration<double, std::milli>(now() - t_r0).count();
+        }
         t_sweep += std::chrono::duration<double, std::milli>(now() - t_mark).count();
         all_novel += c_barcodes.size();
         for (int s = 0; s < 2; ++s) {
@@ -464,7 +502,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         const auto top1 = offsets[0].most_common(2), top2 = offsets[1].most_common(2);
         const int64_t need = 5 * (int64_t)n_lib;
         if (paired ? (div[0] >= need && div[1] >= need) : (div[0] >= need)) satisfied = true;
-        if ((int64_t)seen_reads.size() >= need && all_novel > 0) satisfied = true;
+        if ((int64_t)seen_count() >= need && all_novel > 0) satisfied = true;
         if ((int64_t)all_novel >= need) satisfied = true;
         if (satisfied) {
             auto dominant = [](const std::vector<std::pair<int64_t, int64_t>>& t) {
@@ -478,8 +516,9 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     bc_reader_close(r1);
     if (r2) bc_reader_close(r2);
     (void)t_enter; (void)t_setup;
-    if (prof) fprintf(stderr, "bc_sample_data: %llu chunks of %llu reads: reading %.1f ms, sweep %.1f ms\n",
-                      (unsigned long long)n_chunks, (unsigned long long)n_lib, t_read, t_sweep);
+    if (prof) fprintf(stderr, "bc_sample_data: %llu chunks of %llu reads: reading %.1f ms, sweep %.1f ms (of it: per-read work on threads %.1f, "
+                      "waiting for the distinct-read count %.1f), sets + filter before the first chunk %.1f ms\n",
+                      (unsigned long long)n_chunks, (unsigned long long)n_lib, t_read, t_sweep, t_prep, t_rem, t_setup);
     if (rc != BC_OK) return rc;
     if (!any_read) { set_error("Unable to determine orientation of reads. Please check the input files."); return BC_EINVAL; }
     // most_common(1)[0][0] on an empty Counter is an IndexError in the reference (logged by main)
@@ -492,7 +531,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     const int64_t f1 = last1_truthy ? offsets[0].most_common(1)[0].first : -1;
     const int64_t f2 = last2_truthy ? offsets[1].most_common(1)[0].first : -1;
     bc_sample* s = new bc_sample();
-    s->n_novel = (int64_t)seen_reads.size();
+    s->n_novel = (int64_t)seen_count();
     s->n_observed = observed.size();
     s->n_chunks = n_chunks;
     s->satisfied = satisfied;
@@ -554,12 +593,14 @@ int bc_sample_flanks(const bc_sample* s, int which, int64_t start, int bc_len, i
         }
         void add(std::string_view v) {
             if (v.size() > 15) { big.add(std::string(v)); return; }
-            const Key k = pack(v);
+            add_packed(pack(v), 1);
+        }
+        void add_packed(const Key k, int64_t times) {
             size_t i = (size_t)((k.a * 0x9E3779B97F4A7C15ull) ^ (k.b * 0xD6E8FEB86659FD93ull)) >> 20 & mask;
             for (;; i = (i + 1) & mask) {
                 Entry& e = tab[i];
-                if (!e.used) { e = Entry{k, 1, (uint32_t)n++, true}; break; }
-                if (e.k.a == k.a && e.k.b == k.b) { ++e.count; return; }
+                if (!e.used) { e = Entry{k, times, (uint32_t)n++, true}; break; }
+                if (e.k.a == k.a && e.k.b == k.b) { e.count += times; return; }
             }
             if (n * 2 > tab.size()) {
                 std::vector<Entry> old;
@@ -592,16 +633,47 @@ int bc_sample_flanks(const bc_sample* s, int which, int64_t start, int bc_len, i
         }
     };
     FlankCounter tally[2];
-    for (const std::string& read : reads) {
-        const int64_t n = (int64_t)read.size();
-        // python slices: read[start-max_flank:start] (or read[0:start]) and read[start+k : start+k+max_flank]
-        int64_t a = start - max_flank >= 0 ? start - max_flank : 0, b = std::min<int64_t>(std::max<int64_t>(start, 0), n);
-        a = std::min(a, n);
-        std::string_view left = b > a ? std::string_view(read).substr((size_t)a, (size_t)(b - a)) : std::string_view();
-        int64_t c = std::min<int64_t>(std::max<int64_t>(start + bc_len, 0), n), d = std::min<int64_t>(std::max<int64_t>(start + bc_len + max_flank, 0), n);
-        std::string_view right = d > c ? std::string_view(read).substr((size_t)c, (size_t)(d - c)) : std::string_view();
-        for (size_t m = left.size(); m > 0; --m) tally[0].add(left.substr(left.size() - m));
-        for (size_t m = right.size(); m > 0; --m) tally[1].add(right.substr(0, m));
+    auto count_range = [&](size_t r0, size_t r1, FlankCounter (&tl)[2]) {
+        for (size_t ri = r0; ri < r1; ++ri) {
+            const std::string& read = reads[ri];
+            const int64_t n = (int64_t)read.size();
+            // python slices: read[start-max_flank:start] (or read[0:start]) and read[start+k : start+k+max_flank]
+            int64_t a = start - max_flank >= 0 ? start - max_flank : 0, b = std::min<int64_t>(std::max<int64_t>(start, 0), n);
+            a = std::min(a, n);
+            std::string_view left = b > a ? std::string_view(read).substr((size_t)a, (size_t)(b - a)) : std::string_view();
+            int64_t c = std::min<int64_t>(std::max<int64_t>(start + bc_len, 0), n), d = std::min<int64_t>(std::max<int64_t>(start + bc_len + max_flank, 0), n);
+            std::string_view right = d > c ? std::string_view(read).substr((size_t)c, (size_t)(d - c)) : std::string_view();
+            for (size_t m = left.size(); m > 0; --m) tl[0].add(left.substr(left.size() - m));
+            for (size_t m = right.size(); m > 0; --m) tl[1].add(right.substr(0, m));
+        }
+    };
+    // contiguous ranges of the sample on worker threads, their counters merged in range order: a key's place in the
+    // insertion order is where the earliest range that holds it put it — the order one sequential pass gives
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, hw), reads.size() / 8192 + 1));
+    if (T == 1) {
+        count_range(0, reads.size(), tally);
+    } else {
+        std::vector<FlankCounter> part(2 * T);
+        std::vector<std::thread> th;
+        const size_t per = (reads.size() + T - 1) / T;
+        for (size_t t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                FlankCounter tl[2];
+                count_range(std::min(reads.size(), t * per), std::min(reads.size(), (t + 1) * per), tl);
+                part[2 * t] = std::move(tl[0]);
+                part[2 * t + 1] = std::move(tl[1]);
+            });
+        for (auto& x : th) x.join();
+        for (size_t t = 0; t < T; ++t)
+            for (int side = 0; side < 2; ++side) {
+                const FlankCounter& src = part[2 * t + side];
+                std::vector<const Entry*> v;
+                for (const Entry& e : src.tab) if (e.used) v.push_back(&e);
+                std::sort(v.begin(), v.end(), [](const Entry* x, const Entry* y) { return x->order < y->order; });
+                for (const Entry* e : v) tally[side].add_packed(e->k, e->count);
+                for (const auto& it : src.big.items) tally[side].big.add(it.first, it.second);
+            }
     }
     auto best = [&](const FlankCounter& fc, char* out_buf, int* out_len) {
         // (with max_flank <= 15 every candidate is in the packed table; the string map only fills beyond that, and the
@@ -624,7 +696,7 @@ int bc_sample_flanks(const bc_sample* s, int which, int64_t start, int bc_len, i
     best(tally[0], L_out, L_len);
     best(tally[1], R_out, R_len);
     if (getenv("BC_SAMPLE_PROF"))
-        fprintf(stderr, "bc_sample_flanks: %zu reads, %.1f ms\n", reads.size(),
+        fprintf(stderr, "bc_sample_flanks: %zu reads, %zu threads, %.1f ms\n", reads.size(), T,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     return BC_OK;
 }

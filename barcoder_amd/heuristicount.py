@@ -20,6 +20,7 @@ from __future__ import annotations
 import argparse
 import gzip
 import logging
+import operator
 import os
 import sys
 from collections import Counter
@@ -849,17 +850,27 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
         odd_events = [e for part in D.gather_objects(odd_events) for e in part]
     uw, uc, uf = mine_u
     # documented: first-seen order (heuristicount.py:876-877 prints Counter insertion order)
-    doc_events = [(int(f), cc.labels[g], int(c)) for g, c, f in
-                  zip(np.flatnonzero(counts).tolist(), counts[counts > 0].tolist(), first_seen[counts > 0].tolist())]
     extra_undoc = Counter()
+    odd_doc = []
     for f, key in odd_events:
         if key.endswith("*"):
             extra_undoc[key] += 1
         else:
-            doc_events.append((f, key, 1))
-    doc = Counter()
-    for _f, key, c in sorted(doc_events, key=lambda e: e[0]):
-        doc[key] += c
+            odd_doc.append((f, key, 1))
+    seen = np.flatnonzero(counts)
+    if not odd_doc:
+        # the usual case, without a Python object per event: a guide's first read is its own (one read, one guide), so
+        # the first-seen keys are distinct and their order is the Counter's insertion order
+        order = seen[np.argsort(first_seen[seen], kind="stable")]
+        idx = order.tolist()
+        names = operator.itemgetter(*idx)(cc.labels) if len(idx) > 1 else tuple(cc.labels[i] for i in idx)
+        doc = Counter(dict(zip(names, counts[order].tolist())))
+    else:  # documented barcodes seen in odd windows (string semantics): events merged by first-seen key
+        doc_events = [(int(f), cc.labels[g], int(c)) for g, c, f in
+                      zip(seen.tolist(), counts[seen].tolist(), first_seen[seen].tolist())] + odd_doc
+        doc = Counter()
+        for _f, key, c in sorted(doc_events, key=lambda e: e[0]):
+            doc[key] += c
     undoc = PackedCounter(bc_len, uw, uc, uf, extra_undoc)
     return dict(doc=doc, undoc=undoc, total_reads=total_reads, barcodes=barcodes, bc_len=bc_len,
                 bc_start1=bc_start1, bc_start2=bc_start2, flanks_fwd=(L_fwd, R_fwd), flanks_rev=(L_rev, R_rev),

@@ -585,3 +585,32 @@ def test_launch_workers_starts_ranks_and_reports_failure(tmp_path):
     assert "rank 1 of 3" in ok.stderr and "rank 2 of 3" in ok.stderr
     bad = subprocess.run([sys.executable, "-c", drv, "2"], capture_output=True, text=True, env=env)
     assert bad.returncode == 7
+
+
+def test_native_flanks_on_worker_threads(tmp_path):
+    """bc_sample_flanks counts a large sample on worker threads and merges their counters: same flanks as the Python
+    restatement of find_flanks (heuristicount.py:382-425) on a sample big enough for several threads — a majority
+    flank, a minority variant of it, reads that end inside the right flank."""
+    import random
+    from barcoder_amd import heuristicount as H
+    rng = random.Random(11)
+    k = 18
+    lib = list(dict.fromkeys("".join(rng.choice("ACGT") for _ in range(k)) for _ in range(8000)))
+    reads = []
+    for i in range(90000):
+        L = "CCGGATTCAG" if rng.random() < 0.7 else "CCGGTTTCAG"
+        R = "GTTTTAGAGC" if rng.random() < 0.8 else "GTTTAAGAGC"
+        r = "".join(rng.choice("ACGT") for _ in range(4)) + L + rng.choice(lib) + R + "AC"
+        if rng.random() < 0.1:
+            r = r[:4 + 10 + k + rng.randrange(10)]
+        reads.append(r)
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">b{i}\n{s}\n" for i, s in enumerate(lib)))
+    rd = tmp_path / "r.reads"
+    rd.write_text("".join(r + "\n" for r in reads))
+    ordered = H.read_fasta_ordered(str(fa))
+    smp = H.NativeSample(str(rd), None, ordered, False)
+    want = H.sample_data(str(rd), None, set(ordered), False)
+    assert smp.offset1 == want[1] == 14 and smp.n_valid1 == len(want[3]) > 24576
+    assert tuple(smp.flanks(0, smp.offset1, k)) == tuple(H.find_flanks(want[3], want[1], k)) == ("CCGGATTCAG", "GTTTTAGAGC")
+    smp.close()
