@@ -400,7 +400,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 t_prep += std::chrono::duration<double, std::milli>(now() - t_p0).count();
                 // (they run beside the order-dependent loop below, which touches none of their sets; joined behind it)
                 const unsigned step = T >= 8 ? 8u : T >= 4 ? 4u : 2u;  // (eight parts: a divisor of eight threads take them)
-                for (unsigned t = 0; t < step; ++t) rem_threads.emplace_back([&, t] { remember(t, step); });
+                for (unsigned t = 0; t < step; ++t) rem_threads.emplace_back([&, t, step] { remember(t, step); });  // (step by value: its scope ends before the threads do)
             }
             for (uint64_t q = 0; q < std::min<uint64_t>(AHEAD, nz); ++q) warm(q);
         }
