@@ -69,6 +69,7 @@ if has e2e; then
   echo "e2e" >> $OUT/progress.log
   BC_LIB_PROF=1 BC_SAMPLE_PROF=1 python3 profiles/e2e_bench.py 1e8 > $OUT/${TAG}_e2e_bench.txt 2>&1
   python3 profiles/e2e_bench.py 5e7 100000 paired > $OUT/${TAG}_e2e_paired.txt 2>&1
+  BC_LIB_PROF=1 BC_SAMPLE_PROF=1 BC_STREAM_PROF=1 python3 profiles/e2e_bench.py 1e7 > $OUT/${TAG}_e2e_1e7.txt 2>&1   # a small job: the fixed costs
 fi
 if has targets; then
   echo "targets" >> $OUT/progress.log
