@@ -282,13 +282,17 @@ const char *bc_lib_last_kernel(const bc_lib *lib);
  *
  * Asynchronous on `stream` for every budget.  max_mismatch = 3 runs as a cascade
  * (8 <= k <= 25): the whole <= 2-mismatch pass over every read (kernel
- * k_match_wq, tally included), then k_cascade_stage2, which finds the reads still
- * marked BC_IDX_MISS in d_best_idx itself, takes them through the pair-of-pieces
- * index and writes their results in place — no compacted copy, no device-side
- * count the host would wait for.  (The first launch with a tally on a stream, or
- * one larger than every earlier launch on it, allocates the record workspace and
- * waits for the stream once.)  0 <= max_mismatch < k; the seed algorithms take
- * max_mismatch <= 3.
+ * k_match_wq, tally included), then the reads still marked BC_IDX_MISS through the
+ * pair-of-pieces index, results written in place.  Launches of 65 536 reads or
+ * more work from a list of those reads that k_match_wq writes itself (packed by a
+ * prefix sum on the device, k_cascade_pack, then k_cascade_pass over groups of
+ * tables); smaller ones find them in d_best_idx (k_cascade_stage2).  Either way
+ * the count of missed reads stays on the device: nothing the host waits for.
+ * (The first launch with a tally or a cascade on a stream, or one larger than
+ * every earlier launch on it, allocates that stream's workspace — records, and
+ * for the list form 32 bytes per read — and waits for the stream once;
+ * bc_lib_release_stream frees it.)  0 <= max_mismatch < k; the seed algorithms
+ * take max_mismatch <= 3.
  */
 int bc_match_dev(bc_lib *lib, const uint64_t *d_reads, const uint8_t *d_flags, uint64_t n,
                  int max_mismatch, int algo,
