@@ -276,7 +276,11 @@ __global__ __launch_bounds__(BLOCK) void k_cascade_stage2(const PairParams* __re
 // asynchronous like the one-kernel form.  What the groups buy is modest (a pass costs 96-100 us per table and 1e7
 // reads whether it holds one table or five: the lookup is bound by its instructions and its chain of dependent
 // loads, not by where the slabs live); what the list buys is the walk (0.36 ms) and a lookup that runs with every
-// lane busy.
+// lane busy.  (Measured and dropped: two or three tables' slabs requested together and their first candidates decided in
+// one batch of loads — one chain slab -> entry -> index per group instead of per table: 252 us per three-table pass
+// against 228.  Counters of the pass kernel: 210 vector instructions per slab visit, 56 % of the issue slots, 92 % of
+// the lanes active, 1.43 L2 requests per visit, waves waiting on an instruction's operands 28 % of their time —
+// `KPREFIX=k_cascade bash profiles/prof_valu.sh --max-mismatch 3`.)
 __global__ __launch_bounds__(BLOCK) void k_cascade_collect(const uint64_t* __restrict__ reads, uint64_t n, uint64_t kmask,
                                                           const int32_t* __restrict__ best_idx, uint32_t* __restrict__ l_pos,
                                                           uint64_t* __restrict__ l_read, uint32_t* __restrict__ l_cnt) {
