@@ -1845,7 +1845,9 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
 // the pair index's keys can).  The first pass may itself be a cascade.
 int launch_cascade(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, int max_mm, const MatchOut& o_in,
                    hipStream_t st) {
-    const uint64_t CH = 1ull << 31;  // positions travel as 32-bit values inside the second stage
+    // positions travel as 32-bit values inside the second stage; the list form keeps 32 bytes of workspace per read of a
+    // launch (every read may miss), so it takes very long inputs 2^27 reads at a time (4.3 GB)
+    const uint64_t CH = cascade_uses_list(lib, n) ? (1ull << std::min(31, std::max(8, lib->knobs.pair_chunk_log2))) : (1ull << 31);
     for (uint64_t a = 0; a < n; a += CH) {
         const uint64_t m = std::min(CH, n - a);
         MatchOut o = o_in;
@@ -2333,6 +2335,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.pair_group_kb = env_int("BC_PAIR_GROUP_KB", 3300);
     lib->knobs.pair_pass_min = env_int("BC_PAIR_PASS_MIN_READS", 65536);
     lib->knobs.cascade2_min_g = env_int("BC_CASCADE2_MIN_G", 0);
+    lib->knobs.pair_chunk_log2 = env_int("BC_PAIR_CHUNK_LOG2", 27);
     lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));
     {
         PartOut pg{};

@@ -55,6 +55,7 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
                                  # d = 2 as a cascade too (then d = 3 is a cascade over a cascade and gathers its own list)
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_GROUP_KB": "64"},
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_FAST01": "1"},
+                                 {"BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_CHUNK_LOG2": "13"},  # (very long inputs: several launches)
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1"}, {"BC_CASCADE2_MIN_G": "1"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
     """Tally by global atomics vs LDS histogram vs records, wave vs quad vs single
