@@ -143,6 +143,7 @@ struct Knobs {
                           // (their slabs stay in an XCD's 4 MiB L2); 0: the one-kernel form over all ten tables
     int cascade2_min_g = 0;    // BC_CASCADE2_MIN_G: d = 2 as d <= 1 pass + pair index from that many guides on (0: only where
                           // the wave matcher cannot serve d = 2)
+    int pair_grid = 16384;     // BC_PAIR_GRID: workgroups of a second-stage pass at most (2 048 = 8 per CU fill the chip; more balance the tail: 226 -> 210 us)
     int pair_chunk_log2 = 27;  // BC_PAIR_CHUNK_LOG2: reads per launch of a cascade in its list form (workspace: 32 bytes per read)
     int pair_pass_min = 65536; // BC_PAIR_PASS_MIN_READS: launches below that take the one-kernel form (tests: 0)
     int cascade = 1;      // BC_CASCADE=0: d = 3 by the four-segment index over every read (round 1's path); 2: the pair

@@ -2336,6 +2336,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.pair_pass_min = env_int("BC_PAIR_PASS_MIN_READS", 65536);
     lib->knobs.cascade2_min_g = env_int("BC_CASCADE2_MIN_G", 0);
     lib->knobs.pair_chunk_log2 = env_int("BC_PAIR_CHUNK_LOG2", 27);
+    lib->knobs.pair_grid = std::max(1, env_int("BC_PAIR_GRID", 16384));
     lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));
     {
         PartOut pg{};

@@ -103,7 +103,7 @@ __device__ __forceinline__ void pairs_lookup_tables(const PairParams& pp, int t0
     const uint32_t q = threadIdx.x & 3u;
     bool hooked = false;
     for (int t = t0; t < t1; ++t) {
-        const PairTable& T = pp.t[t];
+        const PairTable T = pp.t[t];  // (by value: every field in one batch of scalar loads — by reference the candidate path loaded them one by one, a wait each)
         const uint32_t rest = pair_rest_masks(T, rlo) | (pair_rest_masks(T, rhi) << 16);
         uint32_t slab = pair_bucket(T, rlo, rhi);  // (a lane without a read: bucket of the all-A read, a valid address)
         bool live = valid;
@@ -571,7 +571,7 @@ int launch_cascade_stage2(bc_lib* lib, int max_mm, const uint64_t* d_reads, uint
                            n_tiles, (const uint32_t*)w->casc_pos, (const uint64_t*)w->casc_read, w->casc_dpos, w->casc_dread,
                            w->casc_count);
     }
-    const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + BLOCK - 1) / BLOCK, 2048));  // 8 workgroups per CU
+    const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + BLOCK - 1) / BLOCK, (uint64_t)lib->knobs.pair_grid));  // 8 workgroups per CU
     for (int t0 = 0; t0 < ntab;) {  // greedy groups: tables in order while their slabs fit the budget, at least one
         int t1 = t0 + 1;
         uint64_t bytes = (uint64_t)lib->pair_slabs[(size_t)t0] * 64u;
