@@ -68,7 +68,8 @@ def test_device_ingest_equals_host_front_half(gpu_device, tmp_path, monkeypatch,
     n = 420_000 if fastq else 900_000                  # > 2 device chunks of 16 MiB either way
     path = _make_file(tmp_path, "r.fastq" if fastq else "r.reads", n, k, fastq, rng, lib_s, reverse, trailing)
     assert os.path.getsize(path) > 34 << 20
-    for mm in (0, 1):
+    # (three mismatches: the cascade's list form — workspace per worker stream, released with the stream — inside the ingest)
+    for mm in (0, 1) + ((3,) if (k == 20 and not fastq) else ()):
         monkeypatch.setenv("BC_DEVICE_INGEST", "1")
         dev = H.count_barcodes(str(fa), path, device=gpu_device, max_mismatch=mm)
         monkeypatch.setenv("BC_DEVICE_INGEST", "0")
