@@ -448,8 +448,8 @@ def to_tsv(cols, rows) -> str:
 
 def _json_str(s: str) -> str:
     """a JSON string the way pandas' writer escapes it (ASCII only, '/' escaped)"""
-    import json
-    return json.dumps(str(s), ensure_ascii=True).replace("/", "\\/")
+    from json.encoder import encode_basestring_ascii  # (the C-accelerated escaper json.dumps itself uses)
+    return encode_basestring_ascii(str(s)).replace("/", "\\/")
 
 
 def to_json(cols, rows) -> str:
@@ -458,23 +458,30 @@ def to_json(cols, rows) -> str:
     without a space, 4-space indentation."""
     if not rows:
         return "[\n\n]"
+    from json.encoder import encode_basestring_ascii as esc
+    keys = [f"        {_json_str(c)}:" for c in cols]
+    memo = {}  # spacers, genes, locus tags and notes repeat from row to row
+
+    def text(v):
+        if v is None:
+            return "null"
+        if isinstance(v, str):
+            t = memo.get(v)
+            if t is None:
+                t = memo[v] = esc(v).replace("/", "\\/")
+            return t
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, (int, np.integer)):
+            return str(int(v))
+        if isinstance(v, (float, np.floating)):
+            return "null" if v != v else repr(float(v))
+        return _json_str(v)
+
     objs = []
     for r in rows:
-        fields = []
-        for c in cols:
-            v = r.get(c)
-            if v is None:
-                txt = "null"
-            elif isinstance(v, bool):
-                txt = "true" if v else "false"
-            elif isinstance(v, (int, np.integer)):
-                txt = str(int(v))
-            elif isinstance(v, (float, np.floating)):
-                txt = "null" if v != v else repr(float(v))
-            else:
-                txt = _json_str(v)
-            fields.append(f"        {_json_str(c)}:{txt}")
-        objs.append("    {\n" + ",\n".join(fields) + "\n    }")
+        get = r.get
+        objs.append("    {\n" + ",\n".join([k + text(get(c)) for k, c in zip(keys, cols)]) + "\n    }")
     return "[\n" + ",\n".join(objs) + "\n]"
 
 
