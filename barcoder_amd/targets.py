@@ -390,7 +390,7 @@ def final_table(rows, seq_lens):
     with missing values last (pandas sort_values), per-spacer site / gene / intergenic counts ->
     note, column selection.  Returns (columns, list of row dicts)."""
     def freeze(r, keys):
-        return tuple(r.get(k) for k in keys)
+        return tuple(map(r.get, keys))  # (missing keys are None, as r.get(k) for every k)
     rows = list({freeze(r, ALL_KEYS): r for r in rows}.values())                      # drop_duplicates (:607)
     targeting = {r["spacer"] for r in rows if r.get("target") is not None}            # filter_offtargets_by_pam
     rows = [r for r in rows if not (r.get("target") is None and r["spacer"] in targeting)]
