@@ -1579,9 +1579,14 @@ int build_seed_index(bc_lib* lib, int d);
 
 int build_hash(bc_lib* lib) {
     const int k = lib->k;
-    int ls = 4;
-    const int pct = std::max(110, env_int("BC_HASH_SLOTS_PCT", 500));  // slots >= pct % of G (tuning aid)
-    while ((1ull << ls) < (uint64_t)lib->G * pct / 100 + 1) ++ls;
+    // Slots: a power of two.  A sparse table (five slots per guide) saves probes while it is small anyway; from 2^17 slots
+    // (1 MB) on it is its footprint in the L2 that costs, and two slots per guide win: 0.655 -> 0.630 ms per 1e8 reads
+    // at 1e5 guides, 1.29 -> 0.83 at 2.5e5, 1.84 -> 1.42 at 1e6 (profiles/r03_hash_slots.txt).  BC_HASH_SLOTS_PCT
+    // (tuning aid, tests) sets slots >= pct % of G instead.
+    auto log2_at_least = [&](uint64_t want) { int l = 4; while ((1ull << l) < want) ++l; return l; };
+    const int pct = env_int("BC_HASH_SLOTS_PCT", 0);
+    int ls = pct > 0 ? log2_at_least((uint64_t)lib->G * std::max(110, pct) / 100 + 1)
+                     : std::max(log2_at_least((uint64_t)lib->G * 2 + 1), std::min(log2_at_least((uint64_t)lib->G * 5 + 1), 17));
     lib->log_slots = ls;
     const uint32_t nslots = 1u << ls, smask = nslots - 1;
     int free_bits = 2 * (32 - k);
