@@ -89,3 +89,33 @@ def test_heuristicount_cli_two_ranks_equals_reference(gpu_device, tmp_path, scen
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout == s["stdout"], (scenario, compress, backend)
         assert "Total Reads" in out.stderr
+
+
+def test_long_barcodes_two_ranks_equal_one(gpu_device, tmp_path):
+    """Barcodes of more than 32 nt over two ranks (byte-range shards of one plain file, every rank on the device
+    ingest path in its text-hash mode, undocumented windows gathered as rows of text): stdout and the undocumented
+    table equal the single-process run, which test_heuristicount_gpu.py holds against the oracle."""
+    import random
+    rng = random.Random(3)
+    k = 44
+    lib = list(dict.fromkeys("".join(rng.choice("ACGT") for _ in range(k)) for _ in range(300)))
+    L, R = "CCGGATTCAG", "GTTTTAGAGC"
+    reads = []
+    for i in range(20000):
+        bc = rng.choice(lib) if rng.random() > 0.15 else "".join(rng.choice("ACGT") for _ in range(k))
+        r = "".join(rng.choice("ACGT") for _ in range(6)) + L + bc + R + "".join(rng.choice("ACGT") for _ in range(rng.randrange(5)))
+        if rng.random() < 0.02:
+            p = rng.randrange(len(r)); r = r[:p] + "N" + r[p + 1:]
+        reads.append(r)
+    fa = tmp_path / "long.fasta"
+    fa.write_text("".join(f">b{i}\n{s}\n" for i, s in enumerate(lib)))
+    rd = tmp_path / "long.reads"
+    rd.write_text("".join(r + "\n" for r in reads))
+    outs = []
+    for ranks in (1, 2):
+        out = subprocess.run([sys.executable, "-m", "barcoder_amd.heuristicount", str(fa), str(rd), "--gpus", str(ranks)],
+                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=_bare_env("gloo"))
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append((out.stdout, [ln for ln in out.stderr.splitlines() if "Barcode" in ln or "Fraction" in ln or ln.rstrip().endswith(("*  1", "*  2"))]))
+    assert outs[0][0] == outs[1][0] and len(outs[0][0].splitlines()) > 250
+    assert outs[0][1] == outs[1][1] and any("Undocumented" in ln for ln in outs[0][1])
