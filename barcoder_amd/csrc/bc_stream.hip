@@ -782,6 +782,7 @@ int group_misses_long(MissList& M, int device, bc_stream_result* res) {
         (rc3 = uh.reserve(n_miss * 8)) != BC_OK || (rc3 = rep.reserve(n_miss * 8)) != BC_OK || (rc3 = uc.reserve(n_miss * 8)) != BC_OK ||
         (rc3 = un.reserve(16)) != BC_OK || (rc3 = clash.reserve(16)) != BC_OK) return rc3;
     hipLaunchKernelGGL(k_iota64, dim3(nb), dim3(BLOCK), 0, 0, (uint64_t*)ord.p, (uint64_t)n_miss);
+    BC_HIP(hipGetLastError());
     BC_HIP(hipMemset(clash.p, 0, 16));
     size_t tb = 0;
     BC_HIP(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)M.words.p, (uint64_t*)h2.p, (uint64_t*)ord.p, (uint64_t*)o2.p,
@@ -791,6 +792,7 @@ int group_misses_long(MissList& M, int device, bc_stream_result* res) {
                                      (size_t)n_miss, 0, 64, 0));
     hipLaunchKernelGGL(k_long_check_groups, dim3(nb), dim3(BLOCK), 0, 0, (const uint64_t*)h2.p, (const uint64_t*)o2.p,
                        (const char*)M.texts.p, M.text_k, (uint64_t)n_miss, (uint32_t*)clash.p);
+    BC_HIP(hipGetLastError());
     const EarlierMiss earlier{(const uint64_t*)M.keys.p, (uint64_t)n_miss};
     size_t tb2 = 0;
     BC_HIP(rocprim::reduce_by_key(nullptr, tb2, (uint64_t*)h2.p, (uint64_t*)o2.p, (size_t)n_miss, (uint64_t*)uh.p, (uint64_t*)rep.p,

@@ -82,7 +82,11 @@ def read_fasta_ordered(fasta_file, check_extension: bool = False):
     else:
         opener = open
     with opener(fasta_file, "rt") as fh:
-        return list(dict.fromkeys(line.strip() for line in fh if not line.startswith(">")))
+        text = fh.read()  # (text mode: every line end already "\n", as file iteration sees them)
+    lines = text.split("\n")
+    if lines and lines[-1] == "":  # (behind the last newline, or an empty file: iteration yields no such line)
+        lines.pop()
+    return list(dict.fromkeys([ln.strip() for ln in lines if not ln.startswith(">")]))
 
 
 def open_reads_file(file_path, mode):
