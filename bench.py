@@ -402,11 +402,11 @@ def run(args):
 
     # dominant kernel alone (the matcher without the tally), HIP events on the launch stream: roofline.achieved;
     # then the whole pass (matcher + tally) the same way
-    k_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(3, args.steps),
+    k_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(20, args.steps),
                       d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), stream=stream)
     counts32.zero_()
     first_seen.fill_(-1)
-    pass_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(3, args.steps),
+    pass_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(20, args.steps),
                          d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), d_counts=counts32.data_ptr(),
                          d_first_seen=first_seen.data_ptr(), stream=stream)
     achieved = n * ALGO_BYTES / (k_ms * 1e-3) / 1e9
