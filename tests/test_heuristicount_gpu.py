@@ -8,6 +8,7 @@ import os
 import types
 from collections import Counter
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN
@@ -223,3 +224,31 @@ def test_barcodes_longer_than_32_nt(gpu_device, oracle, tmp_path, k, monkeypatch
         tables.append((list(r["doc"].items()), dict(r["undoc"].items()), r["total_reads"]))
     assert tables[0] == tables[1]
     assert tables[0][2] == 6000 * (60 if k == 40 else 30)
+
+
+def test_long_barcode_entry_points_refuse_what_they_cannot_do(gpu_device, tmp_path):
+    """bc_lib_attach_text needs a k = 32 library of text hashes and texts of 33 ... 1000 characters; the device ingest
+    path matches such a library exactly only (heuristicount.py:449-453 is a set lookup): anything else is an error
+    through the C ABI, never a silent fallback."""
+    import ctypes as C
+    from barcoder_amd import _native as N, library as Lb, synth as S
+    from barcoder_amd.ingest import stream_count_file
+    L = N.load()
+    short = Lb.DeviceLibrary(S.library(100, 20), 20, gpu_device)
+    text = np.frombuffer(b"ACGT" * 10 * 100, np.uint8)
+    with pytest.raises(ValueError, match="bc_lib_attach_text"):
+        N.check(L.bc_lib_attach_text(short.handle, N.ptr(text), 40))
+    seqs = ["".join("ACGT"[(i * 7 + j * 3 + (i >> j % 5)) % 4] for j in range(40)) for i in range(50)]
+    seqs = list(dict.fromkeys(seqs))
+    long_lib = Lb.DeviceLibrary.from_strings(seqs, device=gpu_device)
+    assert long_lib.long and long_lib.text_k == 40
+    with pytest.raises(ValueError, match="bc_lib_attach_text"):
+        N.check(L.bc_lib_attach_text(long_lib.handle, N.ptr(text), 32))
+    rd = tmp_path / "x.reads"
+    rd.write_text("".join("AAAAA" + s + "CC\n" for s in seqs))
+    G = long_lib.size
+    c64, f64 = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
+    with pytest.raises(ValueError, match="matched exactly"):
+        stream_count_file(long_lib.handle, str(rd), 0, os.path.getsize(rd), 5, "", "", False, 1, "auto", 0, c64, f64)
+    sr = stream_count_file(long_lib.handle, str(rd), 0, os.path.getsize(rd), 5, "", "", False, 0, "auto", 0, c64, f64)
+    assert sr.n_reads == len(seqs) and int(c64.sum()) == len(seqs) and sr.u_words.size == 0
