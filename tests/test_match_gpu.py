@@ -494,7 +494,7 @@ def test_bucket_size_boundaries(gpu_device, oracle, which):
 
 
 @pytest.mark.parametrize("G,d,algo", [(170_000, 1, "seed"), (300_000, 2, "seed"), (400_000, 1, "seed"), (700_000, 0, "hash"),
-                                      (1_200_000, 0, "hash"), (1_200_000, 2, "seed")])
+                                      (1_200_000, 0, "hash"), (1_200_000, 2, "seed"), (300_000, 3, "seed"), (1_200_000, 3, "seed")])
 def test_record_tally_many_ranges(gpu_device, G, d, algo):
     """Libraries of 9 ... 59 tally ranges with at least 4 reads per guide (the size from which the LDS tally runs):
     record lines of 64 / 32 / 16 entries written by k_match_wq / k_match_hash, the sweeps or atomics for kernels
@@ -508,7 +508,7 @@ def test_record_tally_many_ranges(gpu_device, G, d, algo):
     dl = DeviceLibrary(lib, k, gpu_device)
     res = GpuMatcher(dl).match(reads, None, max_mismatch=d, algo=algo, first_index=7)
     hit = res.best_idx >= 0
-    assert 0.75 * n < hit.sum() < 0.95 * n
+    assert 0.75 * n < hit.sum() < (0.97 if d == 3 else 0.95) * n
     if d == 0:  # exact: the answer is known without the oracle
         order = np.argsort(lib)
         pos = np.searchsorted(lib[order], reads)
@@ -530,6 +530,8 @@ def test_record_tally_many_ranges(gpu_device, G, d, algo):
         np.testing.assert_array_equal(res.n_best[:m], ref["n_best"])
         if (G, d) == (1_200_000, 2):
             assert dl.last_kernel == "cascade2:d1+k_match_pairs"
+        if d == 3:  # (at 1.2e6 guides a cascade over a cascade: the outer one gathers its own list)
+            assert dl.last_kernel == "cascade3:d2+k_match_pairs"
     np.testing.assert_array_equal(res.counts, np.bincount(res.best_idx[hit], minlength=G).astype(np.uint64))
     first = np.full(G, np.iinfo(np.uint64).max, np.uint64)
     idx = np.flatnonzero(hit)
