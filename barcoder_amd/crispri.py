@@ -7,33 +7,44 @@ Mirrors (reference file:line):
        PySamParser.py:38-46 + feature columns Type / Start_b / End_b / Strand_b)
 
 `joined_frame` builds that frame from `targets.find_hits` rows and `Gene` records:
-one row per (hit, overlapping feature), the whole-chromosome "source" feature
-included, exactly what a pyranges join of hits with GenBank features yields.
+one row per (hit, overlapping feature) — the whole-record "source" feature first, then
+every `gene` feature PART in record order (GenBankParser.py:69-103 lists the parts of a
+compound location separately; read the gene table without the origin-merging rule:
+`targets.read_genes_tsv(path)`), overlap tested regardless of strand like `PyRanges.join`.
 The class itself is the same pandas logic (annotate PAM -> Targeting, source-unique,
-mapped with Offset / Overlap, unique, unambiguous)."""
+mapped with Offset / Overlap, unique, unambiguous); `tests/golden/crispri.json.gz` holds what
+the reference's own class computed from the same frame (oracle/gen_golden.py)."""
 from __future__ import annotations
 
 import pandas as pd
 
+FRAME_COLUMNS = ["Chromosome", "Start", "End", "Mapped", "Strand", "Barcode", "Mismatches",
+                 "Start_b", "End_b", "Strand_b", "Locus_Tag", "Gene", "Type"]
+
 
 def joined_frame(rows, genes, seq_lens):
     """DataFrame with Chromosome, Start, End, Mapped, Strand, Barcode, Mismatches (PySamParser.py:38-46)
-    and Type, Start_b, End_b, Strand_b, locus_tag of every feature the hit overlaps."""
+    and Start_b, End_b, Strand_b, Locus_Tag, Gene, Type of every feature the hit overlaps
+    (GenBankParser.py:89-97).  Hits in (Chromosome, Start, End, Strand, Barcode) order."""
     by_chr = {}
     for g in genes:
         by_chr.setdefault(g.chrom, []).append(g)
-    out = []
+    hits = []
     for r in rows:
+        if "chr" not in r:  # the bare row of a guide without a placement: an unmapped read joins nothing
+            continue
         a = r["tar_start"] % seq_lens[r["chr"]]  # SAM coordinates are unfolded positions on the reference
-        b = a + r["len"]
-        base = {"Chromosome": r["chr"], "Start": a, "End": b, "Mapped": True,
-                "Strand": "+" if r["sp_dir"] == "F" else "-", "Barcode": r["spacer"], "Mismatches": r["mismatches"]}
-        out.append(dict(base, Type="source", Start_b=0, End_b=seq_lens[r["chr"]], Strand_b="+", locus_tag=None))
-        for g in by_chr.get(r["chr"], ()):
+        hits.append((r["chr"], a, a + r["len"], "+" if r["sp_dir"] == "F" else "-", r["spacer"], r["mismatches"]))
+    hits.sort()
+    out = []
+    for c, a, b, strand, spacer, mm in hits:
+        base = {"Chromosome": c, "Start": a, "End": b, "Mapped": True, "Strand": strand, "Barcode": spacer, "Mismatches": mm}
+        out.append(dict(base, Start_b=0, End_b=seq_lens[c], Strand_b="+", Locus_Tag=None, Gene=None, Type="source"))
+        for g in by_chr.get(c, ()):
             if g.start < b and g.end > a:
-                out.append(dict(base, Type="gene", Start_b=g.start, End_b=g.end,
-                                Strand_b="+" if g.strand == 1 else "-", locus_tag=g.locus_tag))
-    return pd.DataFrame(out)
+                out.append(dict(base, Start_b=g.start, End_b=g.end, Strand_b="+" if g.strand == 1 else "-" if g.strand == -1 else ".",
+                                Locus_Tag=g.locus_tag, Gene=g.gene, Type="gene"))
+    return pd.DataFrame(out, columns=FRAME_COLUMNS)
 
 
 class CRISPRiLibrary:

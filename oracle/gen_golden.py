@@ -19,6 +19,10 @@ Outputs
   cn32_spacers.txt.gz         the `spacer` column of CN-32-zmo.tsv (library of config 1)
   pam_guidefinder.json.gz     GuideFinder.find_guides_from_pam outputs on the plasmids
   plasmid_genes.tsv           gene features of the 4 plasmids (SnapGene feature table: reference DATA)
+  crispri.json.gz             CRISPRiLibrary (CRISPRiLibrary.py:4-120) + PAMFinder (PAMProcessor.py:60-97) run on
+                              the hit x feature frame of the shipped CN-32 spacers on the plasmids: the frame
+                              (input) and every view the class derives from it (outputs), for three PAM settings.
+                              `Bio.Seq` (an import the class never uses, CRISPRiLibrary.py:1) gets a stand-in module.
 """
 import contextlib
 import gzip
@@ -45,11 +49,23 @@ def import_reference():
     b.numbers = bn
     sys.modules.setdefault("babel", b)
     sys.modules.setdefault("babel.numbers", bn)
+    # CRISPRiLibrary.py:1 imports Bio.Seq.Seq and never touches it
+    bio, bioseq = types.ModuleType("Bio"), types.ModuleType("Bio.Seq")
+    bioseq.Seq = type("Seq", (), {})
+    bio.Seq = bioseq
+    sys.modules.setdefault("Bio", bio)
+    sys.modules.setdefault("Bio.Seq", bioseq)
     sys.path.insert(0, REF)
     import heuristicount
     import mismatch
     import PAMProcessor
     return heuristicount, mismatch, PAMProcessor
+
+
+def gz_write(name, text):
+    """gzip with a zeroed header timestamp: regenerating the fixtures reproduces them byte for byte"""
+    with open(os.path.join(OUT, name), "wb") as raw, gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as f:
+        f.write(text.encode())
 
 
 def rand_seq(rng, n, alphabet="ACGT"):
@@ -322,8 +338,7 @@ def pam_cases(P):
     for pam, L in (("NGG", 20), ("NGNC", 32), ("TTTN", 23), ("GGGGGGG", 20)):
         for direction in ("downstream", "upstream"):
             out[f"{pam}_{L}_{direction}"] = P.GuideFinder(recs, pam, direction, L).find_guides_from_pam()
-    with gzip.open(os.path.join(OUT, "pam_guidefinder.json.gz"), "wt") as f:
-        json.dump(out, f)
+    gz_write("pam_guidefinder.json.gz", json.dumps(out))
     # rows of the shipped library that lie on these plasmids (known-answer table)
     rows, spacers = [], []
     with open(os.path.join(REF, "Example_Libraries", "CN-32-zmo.tsv")) as f:
@@ -338,21 +353,104 @@ def pam_cases(P):
     with open(os.path.join(OUT, "cn32_plasmid_rows.tsv"), "w") as f:
         f.write(header)
         f.writelines(rows)
-    with gzip.open(os.path.join(OUT, "cn32_spacers.txt.gz"), "wt") as f:
-        f.write("\n".join(spacers) + "\n")
+    gz_write("cn32_spacers.txt.gz", "\n".join(spacers) + "\n")
     return len(rows), len(spacers), len(set(spacers))
+
+
+# ----------------------------------------------------------------------------- CRISPRiLibrary views
+class SliceRec:
+    """Duck-typed record for PAMFinder: .seq slices to an object with .reverse_complement() and str()."""
+
+    class _S(str):
+        def __getitem__(self, key):
+            return SliceRec._S(str.__getitem__(self, key))
+
+        def reverse_complement(self):
+            return SliceRec._S(rc(self))
+
+    def __init__(self, s):
+        self.seq = SliceRec._S(s)
+
+
+def crispri_cases(P):
+    """testing_grounds.py:20-43 with the stages that cannot run here written out as plain data: the hit table
+    (PySamParser.py:38-46 columns) = every exact placement of the shipped CN-32 spacers on either strand of the four
+    linear plasmid records (what `bowtie -a -v 0` reports for them), joined with the `source` and per-part `gene`
+    features (GenBankParser.py:69-103 columns, a strand-agnostic overlap join like `PyRanges.join`).  The class and
+    PAMFinder are the reference's own, imported unmodified."""
+    import pandas as pd
+    import CRISPRiLibrary as C
+    seqs = {}
+    with open(os.path.join(OUT, "plasmids.fasta")) as f:
+        for line in f:
+            if line.startswith(">"):
+                name = line[1:].split()[0]
+                seqs[name] = []
+            else:
+                seqs[name].append(line.strip())
+    seqs = {k: "".join(v) for k, v in seqs.items()}
+    feats = {k: [("source", 0, len(s), "+", None, None)] for k, s in seqs.items()}  # record.features: source first
+    with open(os.path.join(OUT, "plasmid_genes.tsv")) as f:
+        next(f)
+        for line in f:
+            c, parts, strand, lt, gn = line.rstrip("\n").split("\t")
+            for part in parts.split(";"):
+                a, b = (int(x) for x in part.split("-"))
+                feats[c].append(("gene", a, b, "+" if strand == "1" else "-" if strand == "-1" else ".",
+                                 None if lt == "None" else lt, None if gn == "None" else gn))
+    spacers = []
+    with open(os.path.join(OUT, "cn32_plasmid_rows.tsv")) as f:
+        cols = f.readline().rstrip("\n").split("\t")
+        for line in f:
+            spacers.append(line.split("\t")[cols.index("spacer")])
+    spacers = list(dict.fromkeys(spacers))
+    hits = []
+    for sp in spacers:
+        for c, s in seqs.items():
+            for strand, pat in (("+", sp), ("-", rc(sp))):
+                at = s.find(pat)
+                while at >= 0:
+                    hits.append((c, at, at + len(sp), strand, sp))
+                    at = s.find(pat, at + 1)
+    hits.sort()
+    frame = []
+    for c, a, b, strand, sp in hits:
+        for typ, fa, fb, fs, lt, gn in feats[c]:
+            if fa < b and fb > a:
+                frame.append({"Chromosome": c, "Start": a, "End": b, "Mapped": True, "Strand": strand, "Barcode": sp,
+                              "Mismatches": 0, "Start_b": fa, "End_b": fb, "Strand_b": fs, "Locus_Tag": lt, "Gene": gn,
+                              "Type": typ})
+    recs = {k: SliceRec(s) for k, s in seqs.items()}
+
+    def records(df):
+        return json.loads(df.to_json(orient="records"))
+
+    out = {"frame": frame, "cases": []}
+    for pam, direction in (("NGNC", "downstream"), ("NGG", "downstream"), ("NGNC", "upstream")):
+        lib = C.CRISPRiLibrary(pd.DataFrame(frame), P.PAMFinder(recs, pam, direction))
+        out["cases"].append({
+            "pam": pam, "direction": direction,
+            "PAM": list(lib.targets_df["PAM"]), "Targeting": [bool(x) for x in lib.targets_df["Targeting"]],
+            "source_unique_targets": records(lib.source_unique_targets),
+            "mapped_targets": records(lib.mapped_targets),
+            "unique_targets": records(lib.unique_targets),
+            "unambiguous_targets": records(lib.unambiguous_targets),
+            "unambiguous_index": [int(i) for i in lib.unambiguous_targets.index],
+        })
+    gz_write("crispri.json.gz", json.dumps(out))
+    return len(hits), len(frame), [(len(c["mapped_targets"]), len(c["unique_targets"]), len(c["unambiguous_targets"]),
+                                   sum(c["Targeting"])) for c in out["cases"]]
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     h, mm, P = import_reference()
-    with gzip.open(os.path.join(OUT, "heuristicount_chunks.json.gz"), "wt") as f:
-        json.dump(chunk_scenarios(h), f)
-    with gzip.open(os.path.join(OUT, "heuristicount_main.json.gz"), "wt") as f:
-        json.dump(main_scenarios(h), f)
+    gz_write("heuristicount_chunks.json.gz", json.dumps(chunk_scenarios(h)))
+    gz_write("heuristicount_main.json.gz", json.dumps(main_scenarios(h)))
     with open(os.path.join(OUT, "mismatch.json"), "w") as f:
         json.dump(mismatch_cases(mm), f)
     print("plasmid rows / spacers / unique:", pam_cases(P))
+    print("crispri hits / frame rows / (mapped, unique, unambiguous, targeting) per case:", crispri_cases(P))
 
 
 if __name__ == "__main__":

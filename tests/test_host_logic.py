@@ -614,3 +614,38 @@ def test_native_flanks_on_worker_threads(tmp_path):
     assert smp.offset1 == want[1] == 14 and smp.n_valid1 == len(want[3]) > 24576
     assert tuple(smp.flanks(0, smp.offset1, k)) == tuple(H.find_flanks(want[3], want[1], k)) == ("CCGGATTCAG", "GTTTTAGAGC")
     smp.close()
+
+
+def test_crispri_views_match_reference_class():
+    """`crispri.CRISPRiLibrary` + `pam.PAMFinder` + `crispri.joined_frame` against the views the reference's own
+    CRISPRiLibrary (CRISPRiLibrary.py:4-120) and PAMFinder (PAMProcessor.py:60-97) computed from the same hit x
+    feature frame (tests/golden/crispri.json.gz, oracle/gen_golden.py).  The hits come from the fixture here; the
+    GPU twin (tests/test_targets_gpu.py) gets them from `targets.find_hits`."""
+    import gzip
+    import json
+    from barcoder_amd import targets as T
+    from barcoder_amd.crispri import CRISPRiLibrary, joined_frame
+    from barcoder_amd.library import read_fasta_records
+    from barcoder_amd.pam import PAMFinder
+    with gzip.open(os.path.join(GOLDEN, "crispri.json.gz"), "rt") as f:
+        gold = json.load(f)
+    names = ["CP023716.1", "CP023717.1", "CP023718.1", "CP023719.1"]
+    seqs = dict(zip(names, read_fasta_records(os.path.join(GOLDEN, "plasmids.fasta"))))
+    lens = {k: len(v) for k, v in seqs.items()}
+    parts = T.read_genes_tsv(os.path.join(GOLDEN, "plasmid_genes.tsv"))
+    hits = {}
+    for fr in gold["frame"]:
+        hits[(fr["Chromosome"], fr["Start"], fr["Strand"], fr["Barcode"])] = {
+            "chr": fr["Chromosome"], "tar_start": fr["Start"], "len": fr["End"] - fr["Start"],
+            "sp_dir": "F" if fr["Strand"] == "+" else "R", "spacer": fr["Barcode"], "mismatches": fr["Mismatches"]}
+    rows = list(hits.values())[::-1] + [{"name": "x", "spacer": "ACGT", "len": 4}]  # any order; bare rows join nothing
+    df = joined_frame(rows, parts, lens)
+    rec = lambda d: json.loads(d.to_json(orient="records"))
+    assert rec(df) == gold["frame"]
+    for case in gold["cases"]:
+        lib = CRISPRiLibrary(df.copy(), PAMFinder(seqs, case["pam"], case["direction"]))
+        assert list(lib.targets_df["PAM"]) == case["PAM"]
+        assert [bool(x) for x in lib.targets_df["Targeting"]] == case["Targeting"]
+        for view in ("source_unique_targets", "mapped_targets", "unique_targets", "unambiguous_targets"):
+            assert rec(getattr(lib, view)) == case[view], (case["pam"], view)
+        assert [int(i) for i in lib.unambiguous_targets.index] == case["unambiguous_index"]

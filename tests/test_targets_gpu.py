@@ -173,43 +173,35 @@ def test_annotated_table_matches_shipped_tsv(gpu_device, plasmids):
 
 
 def test_crispri_library_on_gpu_hits(gpu_device, plasmids):
-    """testing_grounds.py:20-43 with the Bowtie / pysam / pyranges stages replaced: hits from the GPU,
-    CRISPRiLibrary views checked against a direct restatement on plain rows.  (The reference's class
-    needs pyranges + Biopython, absent here: this adapter's parity is unpinned by the reference.)"""
+    """testing_grounds.py:20-43 with the Bowtie / pysam / pyranges stages replaced: hits from the GPU, joined with
+    the feature table, through `crispri.CRISPRiLibrary` + `pam.PAMFinder` — held against what the REFERENCE'S OWN
+    `CRISPRiLibrary` (CRISPRiLibrary.py:4-120) and `PAMFinder` (PAMProcessor.py:60-97) computed from the same
+    frame (tests/golden/crispri.json.gz, written by oracle/gen_golden.py with the reference imported unmodified;
+    the frame there is built by plain string search, independently of this package)."""
+    import gzip
+    import json
     from barcoder_amd import targets as T
     from barcoder_amd.crispri import CRISPRiLibrary, joined_frame
     from barcoder_amd.pam import PAMFinder
-    gold = _golden_rows()
-    lens = {c.name: len(c.seq) for c in plasmids}
-    genes = T.read_genes_tsv(os.path.join(GOLDEN, "plasmid_genes.tsv"), lens)
-    spacers = list(dict.fromkeys(r["spacer"] for r in gold))[:200]
-    rows = T.find_hits(spacers, plasmids, pam="", num_mismatches=1, device=gpu_device)
-    df = joined_frame(rows, genes, lens)
-    assert {"Type", "Targeting", "Mapped", "Barcode", "Start", "End", "Start_b", "End_b", "Strand_b", "Chromosome"} - {"Targeting"} <= set(df.columns)
-    records = {c.name: c.seq + c.seq[:100] for c in plasmids}
-    lib = CRISPRiLibrary(df, PAMFinder(records, "NGNC", "downstream"))
-    # restatement on plain rows
-    targeting = {}
-    for r in rows:
-        a = r["tar_start"] % lens[r["chr"]]
-        topo = records[r["chr"]]
-        pam = topo[a + 32:a + 36] if r["sp_dir"] == "F" else T.rev_comp(topo[a - 4:a] if a >= 4 else topo[a - 4:a])
-        ok = len(pam) == 4 and pam[1] == "G" and pam[3] == "C" and set(pam) <= set("ACGT")
-        targeting[(r["spacer"], r["chr"], a, r["sp_dir"])] = ok
-    good_hits = [k for k, v in targeting.items() if v]
-    assert set(lib.source_unique_targets.Barcode) == {k[0] for k in good_hits}
-    assert len(lib.source_unique_targets) == len({k[0] for k in good_hits})
-    mt = lib.mapped_targets
-    assert (mt["Type"] == "gene").all() and (mt["Overlap"] > 0).all()
-    exp_pairs = 0
-    for (sp, ch, a, sd) in good_hits:
-        exp_pairs += sum(1 for g in genes if g.chrom == ch and g.start < a + 32 and g.end > a)
-    assert len(mt) == exp_pairs
-    r0 = mt.iloc[0]
-    assert r0.Offset == (r0.Start - r0.Start_b if r0.Strand_b == "+" else r0.End_b - r0.End)
-    assert list(lib.unique_targets.sort_values(["Chromosome", "Start", "End"]).index) == list(lib.unique_targets.index)
-    assert not lib.unambiguous_targets.duplicated(subset=["Barcode"]).any()
-    assert len(lib.unambiguous_targets) <= len(lib.unique_targets) <= len(mt)
+    with gzip.open(os.path.join(GOLDEN, "crispri.json.gz"), "rt") as f:
+        gold = json.load(f)
+    linear = [T.Chromosome(c.name, c.seq, False) for c in plasmids]  # BowtieRunner.make_fasta writes the bare records
+    lens = {c.name: len(c.seq) for c in linear}
+    parts = T.read_genes_tsv(os.path.join(GOLDEN, "plasmid_genes.tsv"))  # per part, like GenBankParser.ranges
+    spacers = list(dict.fromkeys(r["spacer"] for r in _golden_rows()))
+    rows = T.find_hits(spacers, linear, pam="", num_mismatches=0, device=gpu_device)
+    df = joined_frame(rows, parts, lens)
+    as_records = lambda d: json.loads(d.to_json(orient="records"))
+    assert as_records(df) == gold["frame"] and len(df) == 1540
+    records = {c.name: c.seq for c in linear}
+    for case in gold["cases"]:
+        lib = CRISPRiLibrary(df.copy(), PAMFinder(records, case["pam"], case["direction"]))
+        assert list(lib.targets_df["PAM"]) == case["PAM"]
+        assert [bool(x) for x in lib.targets_df["Targeting"]] == case["Targeting"]
+        for view in ("source_unique_targets", "mapped_targets", "unique_targets", "unambiguous_targets"):
+            assert as_records(getattr(lib, view)) == case[view], (case["pam"], case["direction"], view)
+        assert [int(i) for i in lib.unambiguous_targets.index] == case["unambiguous_index"]
+    assert 0 < sum(gold["cases"][1]["Targeting"]) < sum(gold["cases"][0]["Targeting"])  # NGG turns most sites away
 
 
 def test_design_guides_pipeline(gpu_device, plasmids, oracle):
