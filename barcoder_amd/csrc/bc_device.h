@@ -51,16 +51,17 @@ struct SeedParams {
 // neither an offset lookup nor a separate index lookup.  The last entry of a
 // slab is a link {next slab, LINK} to an overflow slab appended after the
 // primaries.  Requires 2*(k - slen) <= 32 so that the rest fits one dword.
-// Entry = {rest, giw}: giw = guide index (22 bits) | isolation flags.  With d = the table's max_mismatch and nn =
-// distance to the guide's nearest other guide (k_nn_dist): SLAB_F_ISO = nn > 2*d, SLAB_F_ISO1 = nn > 2*(d-1).
-// A read whose best guide g lies at distance e <= d has no second guide within e when nn(g) > 2*e, so the flags
-// prove n_best = 1 without looking any further.
+// Entry = {rest, giw}: giw = guide index (22 bits) | isolation class << 22.  With d = the table's max_mismatch and nn =
+// distance to the guide's nearest other guide (k_nn_dist), the class c = the number of e in 1..d with nn > 2e, i.e.
+// the largest e <= d with nn > 2e.  A read whose best guide g lies at distance e has no second guide within e when
+// nn(g) > 2e (triangle inequality), so `e <= c` proves n_best = 1 without looking any further — one compare on the
+// key (distance << 24 | giw); c == d says "isolated at the table's full budget".  (Rounds 1-3 kept two flag bits,
+// nn > 2d and nn > 2(d-1), and picked one by the distance: eight instructions per test in the wave matcher.)
 constexpr uint32_t SLAB_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t SLAB_LINK = 0xFFFFFFFEu;
 constexpr int SLAB_GIDX_BITS = 22;
 constexpr uint32_t SLAB_GIDX_MASK = (1u << SLAB_GIDX_BITS) - 1u;
-constexpr uint32_t SLAB_F_ISO1 = 1u << 22;
-constexpr uint32_t SLAB_F_ISO = 1u << 23;
+constexpr int SLAB_CLASS_SHIFT = 22;
 struct SlabTable {
     const uint2* slabs;
     uint32_t start, slen, half;   // seed position / length; half = bit distance of the rest's two planes inside an
@@ -83,25 +84,9 @@ constexpr uint32_t NBR_OVER = 0xFFFFFFFEu;  // more than NBR_CAP of them: take t
 // 128-bit sets — the (hashed) values the bucket's guides show in the halves 0a, 0b, 1a, 1b; a read whose own values
 // miss (0a and 0b) or (1a and 1b) has no candidate in the bucket and need not fetch its slabs at all.
 BC_HD static inline uint32_t flt_hash7(uint32_t v) { return (v * 0x9E3779B1u) >> 25; }
-// Second form of tables 0 and 1 for k_match_wq (8-byte entries, 64-byte slabs): the primary slab holds EIGHT entries
-// (no link slot) and a bucket's next seven sit at an implied address — slab `bucket` of a second region, 7 entries +
-// link from there on — so a read learns "there is more" from slot 7 being occupied, needs no link to follow, and a
-// size-biased 27 % of the visits continue instead of 41 %.  The exact path and the quad kernels keep reading t[].
-// Measured (1e8 reads, 1e5 guides, d <= 2): matcher 1.067 -> 1.054 ms, L2 requests 1.79 -> 1.72 per read, but the sparse
-// secondary regions cost L2 capacity (misses +20 %, HBM traffic 1.87 -> 2.07 GB per pass) and rocprofv3's average over a
-// run does not move: built only with BC_FAST01=1.  One allocation and 32-bit offsets: a per-lane choice between four 64-bit base pointers costs registers the kernel
-// does not have (80 VGPRs and scratch against 53).
-struct FastTables {
-    const char* base;     // one allocation: [table 0 primary | table 0 secondary | table 1 primary | table 1 secondary]
-    uint32_t prim[2];     // byte offsets of the primary regions: (buckets + 1) slabs each, the last one empty
-    uint32_t sec[2];      // byte offsets of the secondary regions: slab `buckets` is empty, chained slabs behind it
-    uint32_t empty;       // = buckets (number of the empty slab in every region)
-    uint32_t ok;          // built (only with BC_FAST01=1)
-};
 struct SlabParams {
     int nseg;
     SlabTable t[MAX_SEG];
-    FastTables fast;
     const uint32_t* nbr_slot;  // [G] list number, NBR_NONE or NBR_OVER (NULL = no lists)
     const uint4* nbr;          // [lists][NBR_CAP]
     const uint32_t* flt;       // [table-2 buckets][16] filter lines, NULL = none
@@ -203,7 +188,6 @@ struct bc_lib {
     std::vector<uint32_t> pair_slabs;          // slabs of each pair table (64 bytes each): the second stage groups by size
     const bc::PairParams* d_pairs = nullptr;   // 3-mismatch pair index (NULL: not built yet, or k outside 8..25)
     bool pairs_tried = false;                  // under ws_mutex
-    std::vector<uint2> fast_stage[4];          // library creation only: regions of SlabParams::fast before upload
     bc::Knobs knobs;
     // geometry of the record tally (ranges, records per line), fixed by the library size: computed once at creation
     uint32_t part_nr = 0, part_R = 0, part_magic = 0, part_cap_log2 = 0;

@@ -223,22 +223,22 @@ struct WaveKargs {
 };
 static_assert(offsetof(WaveKargs, o) == 56, "k_match_wq kernel-argument layout");
 
-// is the best candidate provably the only guide at its distance?
-__device__ __forceinline__ bool key_unique(uint32_t key, uint32_t max_mm) {
-    const uint32_t d = key >> 24;
-    return d == 0u || (key & (d == max_mm ? SLAB_F_ISO : SLAB_F_ISO1)) != 0u;
-}
+// is the best candidate provably the only guide at its distance?  The index word of an entry carries the guide's
+// isolation class c (SLAB_CLASS_*, bc_device.h): the largest e <= the table's budget with nn(guide) > 2e.  A best key at
+// distance d <= c has no other guide within d of the read (triangle inequality) — and d <= c implies d <= max_mm.
+// (Empty and link slots: 0xFFFFFFFx, distance 255 > any class.)
+__device__ __forceinline__ bool key_unique(uint32_t key) { return (key >> 24) <= ((key >> SLAB_CLASS_SHIFT) & 3u); }
 
+// rotation inside a DPP quad: lane s takes the value of lane (s + I + 1) & 3 (I = 3: its own)
+template <int I>
+__device__ __forceinline__ uint32_t quad_rot(uint32_t v) {
+    if constexpr (I == 0) return quad_perm<0x39>(v);       // quad_perm:[1,2,3,0]
+    else if constexpr (I == 1) return quad_perm<0x4E>(v);  // quad_perm:[2,3,0,1]
+    else if constexpr (I == 2) return quad_perm<0x93>(v);  // quad_perm:[3,0,1,2]
+    else return v;
+}
 template <int J>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return quad_perm<J * 0x55>(v); }
-
-// lane s of every quad returns min over the quad's lanes of their a[s]
-__device__ __forceinline__ uint32_t quad_tmin(const uint32_t (&a)[4], int s) {
-    const bool odd = (s & 1) != 0, hi = (s & 2) != 0;
-    const uint32_t b0 = min(odd ? a[1] : a[0], quad_perm<0xB1>(odd ? a[0] : a[1]));
-    const uint32_t b1 = min(odd ? a[3] : a[2], quad_perm<0xB1>(odd ? a[2] : a[3]));
-    return min(hi ? b1 : b0, quad_perm<0x4E>(hi ? b0 : b1));
-}
 
 // 16-byte load, global address space (the table pointer comes out of a descriptor in memory; a generic pointer
 // would make this a flat load that also waits on the LDS counter), uniform base + 32-bit lane offset
@@ -246,6 +246,22 @@ typedef const u32x4 __attribute__((address_space(1)))* gquarter_t;
 __device__ __forceinline__ uint4 load16(const char* base, uint32_t off) {
     const u32x4 t = *(gquarter_t)(uintptr_t)(base + off);
     return make_uint4(t.x, t.y, t.z, t.w);
+}
+// ... piece PIECE (a constant) of the slab at `off`: the piece's 16 * PIECE bytes are added to the 64-bit address, so
+// they end up in the instruction's immediate offset (added to the 32-bit lane offset they cost a v_add per load)
+template <int PIECE>
+__device__ __forceinline__ uint4 load16p(const char* base, uint32_t off) {
+    const u32x4 t = ((gquarter_t)(uintptr_t)(base + off))[PIECE];
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+// wave-wide vote on a lane predicate, straight from the compare's lane mask (HIP's __ballot takes an int: the
+// predicate is first turned into 0 / 1 and compared again, two VALU instructions per vote)
+__device__ __forceinline__ unsigned long long vote(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(p);
+#else
+    return p ? 1ull : 0ull;
+#endif
 }
 // the same for the filter lines and neighbour lists (pointers out of the same descriptor)
 typedef const uint32_t __attribute__((address_space(1)))* gword_t;
@@ -285,52 +301,105 @@ __device__ __forceinline__ uint32_t planes_dist(uint32_t x) {
 }
 // best key (distance << 24 | giw) among the entries of one 16-byte piece
 template <bool WIDE>
-__device__ __forceinline__ uint32_t piece_min(const uint4& w, uint32_t rl, uint32_t rh, uint32_t half, uint32_t hmask) {
+__device__ __forceinline__ uint32_t piece_min(const uint4& w, uint32_t rl, uint32_t rh) {
     if constexpr (WIDE) {
         return ((uint32_t)__popc((rl ^ w.x) | (rh ^ w.z)) << 24) | w.y;
     } else {
-        (void)half; (void)hmask;
+        (void)rh;
         return min((planes_dist(rl ^ w.x) << 24) | w.y, (planes_dist(rl ^ w.z) << 24) | w.w);
     }
 }
 template <bool WIDE>
 __device__ __forceinline__ uint32_t link_word(const uint4& last_piece) { return WIDE ? last_piece.x : last_piece.z; }
 
-// request the slabs of the quad's four reads, NQ quarters per lane and read (1: 64-byte slabs, 2: 128, 4: 256).
-// off = byte offset of the slab wanted by the read this lane owns (FROM3: by read j, held in lane 3 as off4[j]).
-// A read that wants nothing is pointed at its table's all-empty slab: skipping the load instead (exec-masked
-// branches per read, results masked afterwards) measured 6 % slower once the kernel had become VALU-bound.
-template <int NQ, bool FROM3>
-__device__ __forceinline__ void visit_issue(const char* base, uint32_t off, const uint32_t (&off4)[4], int s,
-                                            uint4 (&w)[4][NQ]) {
+// Quad-cooperative visit: the four lanes of a quad own one read each; load j (0..3) brings the slab wanted by the read
+// of the quad's lane j, lane s taking piece s (+ 4h for longer slabs) — the quad's four 16-byte accesses of one
+// instruction fall into ONE 64-byte line: one vector-L1 tag look-up per slab.  (Round 4 tried the rotated form — in
+// slot i lane s fetches piece i of the slab of lane (s + i + 1) & 3, which makes the transposed minimum three DPP
+// instructions and hands the link slot to its owner for free: VALU 1 284 -> 1 077 per tile, but every instruction then
+// touches 64 lines instead of 16: L1 accesses 2.8 -> 6.3 per read and the kernel 1.00 -> 1.52 ms.  The L1's tag rate is
+// the third wall; it was not visible in the instruction counts.)
+// off = byte offset of the slab wanted by the read this lane owns; s16 = 16 * (lane & 3).  A read that wants nothing
+// is pointed at its table's all-empty slab: skipping the load instead (exec-masked branches per read, results masked
+// afterwards) measured 6 % slower once the kernel had become VALU-bound.
+// (v_add_u32_dpp written as inline assembly would make this one instruction everywhere — the compiler fuses the
+// broadcast into the add in some places and emits v_mov_dpp + v_add in others — but the hazard recogniser does not look
+// into inline assembly: a DPP operand read within two wait states of the VALU write that produced it returns stale
+// data.  Round 4 measured exactly that: 0.6 % wrong results at d = 1 until the assembly was taken out again.)
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast_add(uint32_t v, uint32_t add) { return quad_perm<J * 0x55>(v) + add; }
+template <int NQ>
+__device__ __forceinline__ void visit_issue(const char* base, uint32_t off, uint32_t s16, uint4 (&w)[4][NQ]) {
     auto one = [&](auto jt) {
         constexpr int j = decltype(jt)::value;
-        const uint32_t oj = FROM3 ? quad_bcast<3>(off4[j]) : quad_bcast<j>(off);
-#pragma unroll
-        for (int h = 0; h < NQ; ++h) w[j][h] = load16(base, oj + (uint32_t)(s + 4 * h) * 16u);
+        const uint32_t oj = quad_bcast_add<j>(off, s16);
+        w[j][0] = load16p<0>(base, oj);
+        if constexpr (NQ > 1) w[j][1] = load16p<4>(base, oj);
+        static_assert(NQ <= 2, "table 0/1 slabs: one or two pieces per lane");
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
 }
 
-// scan them: kmin = min(kmin, best key of the read this lane owns); l[j] = last slot's first word of read j's
-// slab as seen by this lane — in lane 3 that is the overflow link (0 = none: the slot is link-or-empty)
+// The transposed reduction of a visit — every owner needs the minimum over the quad's four lanes of THEIR partial
+// minimum for its slab, and the link word that sits in lane 3 — goes through LDS when BC_WQ_LDS_REDUCE is set: lane
+// 4q + t writes its four partial minima a[j] to rows[68 j + 4q + t] (two ds_write2_b32), owner 4q + s reads the four
+// partials of its slab back as one ds_read_b128 at rows[68 s + 4q] (row pitch 68 dwords: the 64 16-byte reads fall
+// evenly on the banks) and takes v_min3 + v_min: two VALU instructions instead of the ten of the DPP butterfly
+// (four selects, two v_min_dpp, a select, a DPP move, a select, a min); lane 3 of a quad writes the four link words to
+// lk[4q + j], the owner reads lk[lane]: no VALU instead of four broadcasts and three selects.  The data movement
+// leaves the VALU (the wall) for the LDS pipe (idle in phase 1), at the price of two LDS round trips per visit.
+#ifndef BC_WQ_LDS_REDUCE
+#define BC_WQ_LDS_REDUCE 1
+#endif
+constexpr int TR_PITCH = 68;
+constexpr int TR_WORDS = 4 * TR_PITCH + 64;  // transposition rows + link words
+
+// lane s of every quad returns min over the quad's lanes of their a[s] (DPP butterfly)
+__device__ __forceinline__ uint32_t quad_tmin(const uint32_t (&a)[4], int s) {
+    const bool odd = (s & 1) != 0, hi = (s & 2) != 0;
+    const uint32_t b0 = min(odd ? a[1] : a[0], quad_perm<0xB1>(odd ? a[0] : a[1]));
+    const uint32_t b1 = min(odd ? a[3] : a[2], quad_perm<0xB1>(odd ? a[2] : a[3]));
+    return min(hi ? b1 : b0, quad_perm<0x4E>(hi ? b0 : b1));
+}
+
+// scan them: kmin = min(kmin, best key of the read this lane owns); link = first word of the last slot of the lane's
+// own slab (0 = none: the slot is link-or-empty).  tr: TR_WORDS dwords of LDS private to the wave, 16-byte aligned
 template <int NQ, bool WIDE = false>
-__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], RestW rest, uint32_t half, uint32_t hmask, int s,
-                                           uint32_t& kmin, uint32_t (&l)[4]) {
-    uint32_t a[4];
+__device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], RestW rest, uint32_t lane, uint32_t* tr,
+                                           uint32_t& kmin, uint32_t& link) {
+    const int s = (int)(lane & 3u);
+    uint32_t a[4], l[4];
     auto one = [&](auto jt) {
         constexpr int j = decltype(jt)::value;
         const uint32_t rl = quad_bcast<j>(rest.lo), rh = WIDE ? quad_bcast<j>(rest.hi) : 0u;
         uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-        for (int h = 0; h < NQ; ++h) m = min(m, piece_min<WIDE>(w[j][h], rl, rh, half, hmask));
+        for (int h = 0; h < NQ; ++h) m = min(m, piece_min<WIDE>(w[j][h], rl, rh));
         a[j] = m;
         l[j] = link_word<WIDE>(w[j][NQ - 1]);
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
-    kmin = min(kmin, quad_tmin(a, s));
+    if (BC_WQ_LDS_REDUCE) {
+        uint32_t* lk = tr;          // [64] link words (first: every offset below fits the 8-bit dword offsets of ds_write2_b32)
+        uint32_t* rows = tr + 64;   // [4][TR_PITCH]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rows[TR_PITCH * j + (int)lane] = a[j];
+        if (s == 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lk[(int)lane - 3 + j] = l[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint4 t = *reinterpret_cast<const uint4*>(rows + TR_PITCH * s + (int)(lane & ~3u));
+        link = lk[lane];
+        kmin = min(min(kmin, t.x), min(t.y, min(t.z, t.w)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next visit overwrites the rows)
+    } else {
+        kmin = min(kmin, quad_tmin(a, s));
+        const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
+        link = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner's overflow link
+    }
 }
 
 // the best guide g (at distance d1) may tie with close neighbours: count them from g's neighbour list.
@@ -441,12 +510,12 @@ __device__ __forceinline__ void slab_slow_wide(const SlabParams& sp, uint32_t rl
 constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 64 drains first when fewer are free
 
 // (amdgpu_waves_per_eu(6) is a register-budget floor — at least six waves per SIMD, i.e. at most 80 VGPRs — not the
-// occupancy: the kernel uses 55 VGPRs and 5.5 KiB of LDS per single-wave workgroup, so 29 workgroups fit a CU's 160 KiB:
-// seven waves per SIMD run.)
+// occupancy: the kernel uses about 50 VGPRs and 5.5 KiB of LDS per single-wave workgroup, so 29 workgroups fit a CU's
+// 160 KiB: seven waves per SIMD run.)
 // LIST: the first stage of a cascade — the reads left without a hit also go on the second stage's list (MatchOut::miss_*).
 // Its own instantiation: the default kernel carries none of it (the list entry kept for a miss, the ballots at the end:
 // +0.03 ms per 1e8 reads when they sat in the one kernel).
-template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01, bool FAST = false, bool LIST = false>
+template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01, bool LIST = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wq(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,
                                                    const uint8_t* __restrict__ flags, uint64_t n, int k,
@@ -456,23 +525,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     // (16 narrow entries for buckets above 16 guides, or 8 wide entries)
     static_assert(NQ01 == 1 || NQ01 == 2, "table 0/1 slabs are 64 or 128 bytes");
     static_assert(!WIDE || NQ01 == 2, "wide entries: 8-entry slabs of 128 bytes");
-    // FAST: tables 0/1 in their second form (FastTable): primary slabs of eight entries, the next seven at an implied
-    // address; an item's slab number then counts in the secondary region, item code 3 = a primary slab of table 1
-    static_assert(!FAST || (!WIDE && NQ01 == 1), "the second form exists for 64-byte slabs of 8-byte entries");
     static_assert(!LIST || (!WIDE && NQ01 == 1), "the list form is instantiated for 64-byte slabs of 8-byte entries");
     constexpr uint32_t S01 = NQ01 == 2 ? 7u : 6u;     // log2 of that slab's bytes
     (void)o_arg;  // read from the kernel-argument segment in the last phase, see there
-    __shared__ uint64_t q_read[WAVE_T];                                 // listed read; later its result
-    __shared__ __attribute__((aligned(16))) uint32_t q_key[WAVE_T];     // its best key so far (LDS atomic min)
-    __shared__ uint32_t wl[WL_CAP];                                     // items: list entry | table << 8 | slab << 10
-    // q_aux: until the listed reads' decisions, the table-0 overflow link of each listed read (its item is pushed only
-    // if table 1's primary slab does not settle the read); from then on two 16-bit lists
-    __shared__ __attribute__((aligned(16))) uint32_t q_aux[WAVE_T];
-    uint32_t* const q_lnk = q_aux;
-    uint16_t* const l_t2 = reinterpret_cast<uint16_t*>(q_aux);  // list entries that need table 2
-    uint16_t* const l_slow = l_t2 + WAVE_T;  // list entries whose best guide may tie with a neighbour; then (compacted in
-                                             // place, behind the position being read) those that need the exact path
-    uint16_t* const l_tie = l_slow;
+    // The list of the tile's unsettled reads: one 16-byte entry per listed read — {read lo, read hi, best key so far
+    // (LDS atomic min), aux} — written with one ds_write_b128 in phase 1 and read back with one ds_read_b128 (round 3
+    // kept three arrays: three address computations per push and per visit).  aux: until the listed reads' decisions
+    // the table-0 overflow link (its item is pushed only if table 1's primary slab does not settle the read); from
+    // then on two 16-bit lists threaded through the same words (low half: list entries that need table 2; high half:
+    // entries whose best guide may tie with a neighbour, then — compacted in place behind the position being read —
+    // those that need the exact path).  Once a read is decided, words 0-1 of its entry hold its result record.
+    __shared__ __attribute__((aligned(16))) uint32_t q_ent[WAVE_T * 4];
+    // items: list entry | table << 8 | slab << 10.  Phase 1 and table 1's batch use the same words as the rows of their
+    // transposed reduction (visit_scan): no item exists before the batch has been scanned
+    __shared__ __attribute__((aligned(16))) uint32_t wl[WL_CAP];
+    static_assert(WL_CAP >= TR_WORDS, "the item stack doubles as the transposition rows");
+    auto e_read = [&](uint32_t qi) -> uint64_t& { return *reinterpret_cast<uint64_t*>(q_ent + 4u * qi); };
+    auto e_key = [&](uint32_t qi) -> uint32_t& { return q_ent[4u * qi + 2u]; };
+    auto e_all = [&](uint32_t qi) -> uint4& { return *reinterpret_cast<uint4*>(q_ent + 4u * qi); };
+    auto l_t2 = [&](uint32_t t) -> uint16_t& { return reinterpret_cast<uint16_t*>(q_ent)[8u * t + 6u]; };
+    auto l_tie = [&](uint32_t t) -> uint16_t& { return reinterpret_cast<uint16_t*>(q_ent)[8u * t + 7u]; };
     const SlabParams& sp = *spp;
     const uint32_t max_mm = (uint32_t)max_mm_ & 0xFFu;
 #ifdef BC_DIAG_BUILD  // `make diag` only (build/libbarcoder_hip_diag.so, profiles/diag.sh): stages switched off for timing
@@ -487,18 +559,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     const SlabTable& T0 = sp.t[0];
     const SlabTable& T1 = sp.t[1];
     const SlabTable& T2 = sp.t[NSEG - 1];
-    // FAST: one base for tables 0/1, the region (primary / secondary, table) is a 32-bit offset
-    const char* const b0 = FAST ? sp.fast.base + sp.fast.prim[0] : reinterpret_cast<const char*>(T0.slabs);   // primary slabs
-    const char* const b1 = FAST ? sp.fast.base + sp.fast.prim[1] : reinterpret_cast<const char*>(T1.slabs);
+    const char* const b0 = reinterpret_cast<const char*>(T0.slabs);
+    const char* const b1 = reinterpret_cast<const char*>(T1.slabs);
     const char* const b2 = reinterpret_cast<const char*>(T2.slabs);
     const uint32_t lane = threadIdx.x;
-    const uint32_t half0 = T0.half, hm0 = (1u << half0) - 1u;
-    const uint32_t half1 = T1.half, hm1 = (1u << half1) - 1u;  // (the masks are not used by the wide format)
-    const uint32_t half2 = T2.half, hm2 = (1u << half2) - 1u, sh2 = T2.log2S + (WIDE ? 4u : 3u);
-    const uint32_t empty0 = (FAST ? sp.fast.empty : T0.empty) << S01, empty1 = (FAST ? sp.fast.empty : T1.empty) << S01,
-                   empty2 = T2.empty << sh2;  // what idle lanes fetch (same slab number in every region of the fast tables)
+    const uint32_t half0 = T0.half, half1 = T1.half, half2 = T2.half, sh2 = T2.log2S + (WIDE ? 4u : 3u);
+    const uint32_t empty0 = T0.empty << S01, empty1 = T1.empty << S01, empty2 = T2.empty << sh2;  // what idle lanes fetch
     const int s = (int)(lane & 3u);
-    const uint32_t none4[4] = {0u, 0u, 0u, 0u};
+    const uint32_t s16 = (lane & 3u) * 16u;
     unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull, t_acc[4] = {0ull, 0ull, 0ull, 0ull};
     auto phase_mark = [&](int ph) {
         if (PROF) {
@@ -511,27 +579,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
     auto put = [&](uint32_t qi, uint32_t idx, uint32_t dist, uint32_t nb) {
-        q_read[qi] = (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)(nb > 255u ? 255u : nb) << 40);
+        e_read(qi) = (uint64_t)idx | ((uint64_t)dist << 32) | ((uint64_t)(nb > 255u ? 255u : nb) << 40);
     };
     // no guide within the budget.  LIST: up to 31 bases the listed read stays where it is with bit 63 set (free: the
     // planes end below it, and a result record has zeros there) — the second stage gets the read from there; a
     // 32-mer has no free bit and takes the plain record
     auto put_miss = [&](uint32_t qi) {
         if (!LIST || k > 31) put(qi, (uint32_t)BC_IDX_MISS, BC_DIST_NONE, 0u);
-        else __hip_atomic_fetch_or(&q_read[qi], 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else __hip_atomic_fetch_or(&e_read(qi), 1ull << 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     uint32_t qn = 0, t2n = 0, sn = 0, wn = 0, tien = 0;  // wave-uniform list lengths
 
-    // a best key in range whose guide has no neighbour that close is final whatever has not been visited yet: any
-    // other guide h lies further than 2e from it, hence further than e from the read (key_unique, triangle inequality)
-    auto settled = [&](uint32_t key) { return (key >> 24) <= max_mm && key_unique(key, max_mm); };
+    // a best key whose guide has no neighbour that close is final whatever has not been visited yet: any other guide h
+    // lies further than 2e from it, hence further than e from the read (key_unique: class test, triangle inequality)
+    auto settled = [&](uint32_t key) { return key_unique(key); };
     auto push_items = [&](bool has, uint32_t item) {
-        const unsigned long long m = __ballot(has);
+        const unsigned long long m = vote(has);
         if (has) wl[wn + rank_of(m)] = item;
         wn += (uint32_t)__popcll(m);
     };
 
-    // sixteen items per step, one quad each; tables 0 and 1 (64-byte slabs)
+    // sixteen items per step, one quad each (lane s: piece s); tables 0 and 1
     auto drain01 = [&]() {
         while (wn) {
             wave_lds_sync();
@@ -542,35 +610,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const uint32_t item = act ? wl[wn + q] : 0u;
             const uint32_t qi = item & 255u, slab = item >> 10;
             const bool t1 = (item & 0x100u) != 0u;
-            const bool prim1 = FAST && (item & 0x300u) == 0x300u;  // a primary slab of table 1 (listed reads beyond 64)
-            const uint64_t r = q_read[qi];
+            const uint64_t r = e_read(qi);
             const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
             // the rest of the read with the table picked per lane
             const uint32_t st = t1 ? T1.start : 0u, sh = t1 ? T1.start + T1.slen : T0.slen;  // (table 0's seed starts at base 0)
-            const uint32_t hf = t1 ? half1 : half0, hm = t1 ? hm1 : hm0;
-            const RestW rest = rest_of<WIDE>(st, sh, hf, rlo, rhi);
-            const char* base = FAST ? sp.fast.base : (t1 ? b1 : b0);
-            const uint32_t region = FAST ? (prim1 ? sp.fast.prim[1] : t1 ? sp.fast.sec[1] : sp.fast.sec[0]) : 0u;
-            const uint32_t off = region + (act ? (slab << S01) : empty0);
+            const RestW rest = rest_of<WIDE>(st, sh, t1 ? half1 : half0, rlo, rhi);
+            const char* base = t1 ? b1 : b0;
+            const uint32_t off = act ? (slab << S01) : empty0;
             uint4 w[NQ01];
 #pragma unroll
             for (int h = 0; h < NQ01; ++h) w[h] = load16(base, off + (uint32_t)(s + 4 * h) * 16u);
             uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-            for (int h = 0; h < NQ01; ++h) m = min(m, piece_min<WIDE>(w[h], rest.lo, rest.hi, hf, hm));
+            for (int h = 0; h < NQ01; ++h) m = min(m, piece_min<WIDE>(w[h], rest.lo, rest.hi));
             m = min(m, quad_perm<0xB1>(m));
             m = min(m, quad_perm<0x4E>(m));
-            uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ01 - 1]));  // the slab's last slot: link or empty (0)
-            uint32_t next = (item & 0x3FFu) | (lnk << 10);
-            if (FAST) {  // a primary slab has no link: an occupied last slot means the bucket goes on in its secondary slab
-                const uint32_t more = quad_bcast<3>(w[0].w) != SLAB_EMPTY ? 1u : 0u;
-                lnk = prim1 ? more : lnk;
-                next = prim1 ? ((item & 0xFFu) | 0x100u | (slab << 10)) : next;
-            }
+            const uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ01 - 1]));  // the slab's last slot: link or empty (0)
             const bool lead = act && s == 0;
             uint32_t now = 0xFFFFFFFFu;
-            if (lead) now = min(m, atomicMin(&q_key[qi], m));
-            push_items(lead && lnk != 0u && !settled(now), next);  // a settled read's chain ends here
+            if (lead) now = min(m, atomicMin(&e_key(qi), m));
+            push_items(lead && lnk != 0u && !settled(now), (item & 0x3FFu) | (lnk << 10));  // a settled read's chain ends here
         }
         wave_lds_sync();
     };
@@ -585,7 +644,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const bool act = q < take;
             const uint32_t item = act ? wl[wn + q] : 0u;
             const uint32_t qi = item & 255u, slab = item >> 10;
-            const uint64_t r = q_read[qi];
+            const uint64_t r = e_read(qi);
             const RestW rest = rest_of<WIDE>(T2.start, T2.start + T2.slen, half2, (uint32_t)r, (uint32_t)(r >> 32));
             const uint32_t off = act ? (slab << sh2) : empty2;
             uint4 w[NQ2];
@@ -593,29 +652,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             for (int h = 0; h < NQ2; ++h) w[h] = load16(b2, off + (uint32_t)(s + 4 * h) * 16u);
             uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-            for (int h = 0; h < NQ2; ++h) m = min(m, piece_min<WIDE>(w[h], rest.lo, rest.hi, half2, hm2));
+            for (int h = 0; h < NQ2; ++h) m = min(m, piece_min<WIDE>(w[h], rest.lo, rest.hi));
             m = min(m, quad_perm<0xB1>(m));
             m = min(m, quad_perm<0x4E>(m));
             const uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ2 - 1]));
             const bool lead = act && s == 0;
             uint32_t now = 0xFFFFFFFFu;
-            if (lead) now = min(m, atomicMin(&q_key[qi], m));
+            if (lead) now = min(m, atomicMin(&e_key(qi), m));
             push_items(lead && lnk != 0u && !settled(now), (item & 0x3FFu) | (lnk << 10));
         }
         wave_lds_sync();
     };
 
     // hit / tie / miss decision for the lane's read once every guide that can matter has been seen.  A best guide
-    // whose isolation flag does not rule out a second guide at the same distance goes on the tie list (resolved by
+    // whose isolation class does not rule out a second guide at the same distance goes on the tie list (resolved by
     // quads from the guide's neighbour list after all decisions: one pass per tile instead of one per decision batch)
     auto decide = [&](bool mine, bool final_miss, uint32_t qi, uint32_t kmin) {
         const uint32_t d = kmin >> 24;
         const bool inrange = mine && d <= max_mm;
-        const bool tie = inrange && !key_unique(kmin, max_mm) && !(diag & 4u);
+        const bool tie = inrange && !key_unique(kmin) && !(diag & 4u);
         if (inrange && !tie) put(qi, kmin & SLAB_GIDX_MASK, d, 1u);
         if (mine && !inrange && final_miss) put_miss(qi);
-        const unsigned long long m = __ballot(tie);
-        if (tie) l_tie[tien + rank_of(m)] = (uint16_t)qi;
+        const unsigned long long m = vote(tie);
+        if (tie) l_tie(tien + rank_of(m)) = (uint16_t)qi;
         tien += (uint32_t)__popcll(m);
         return inrange;
     };
@@ -675,52 +734,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         // table 0's seed starts at base 0 (build_seed_index; checked when the launch is chosen): with the start a
         // constant the seed value is two and-s and a shift-or, the rest a shift per plane — phase 1 runs for every read
         auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), 0, T0.slen) << S01) : 0u; };
-        // myoff: the byte offset the read's own slab was fetched from (FAST: the secondary slab has the bucket's number)
-        auto finish = [&](int j, const uint4 (&w)[4][NQ01], uint32_t myoff) {
-            uint32_t l[4], key = 0xFFFFFFFFu;
-            visit_scan<NQ01, WIDE>(w, rest_of<WIDE>(0u, T0.slen, half0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)),
-                                   half0, hm0, s, key, l);
-            if (FAST) {  // no link slot: slot 7's index word says whether the bucket goes on
-#pragma unroll
-                for (int u = 0; u < 4; ++u) l[u] = w[u][0].w;
-            }
-            const uint32_t t0 = quad_bcast<3>(l[0]), t1 = quad_bcast<3>(l[1]), t2 = quad_bcast<3>(l[2]), t3 = quad_bcast<3>(l[3]);
-            uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;  // the owner's overflow link
-            if (FAST) lnk = lnk != SLAB_EMPTY ? ((myoff >> S01) | 0x80000000u) : 0u;
-            const uint32_t d = key >> 24;
-            const bool fin = ok[j] && d <= max_mm && key_unique(key, max_mm);
+        auto finish = [&](int j, const uint4 (&w)[4][NQ01]) {
+            uint32_t lnk, key = 0xFFFFFFFFu;
+            visit_scan<NQ01, WIDE>(w, rest_of<WIDE>(0u, T0.slen, half0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), lane, wl, key, lnk);
+            const bool fin = ok[j] && key_unique(key);
             idx[j] = !ok[j] ? BC_IDX_SKIP : fin ? (int32_t)(key & SLAB_GIDX_MASK) : BC_IDX_MISS;
-            dist4 |= (fin ? d : 0u) << (8 * j);
+            dist4 |= (fin ? (key >> 24) : 0u) << (8 * j);
             const bool push = ok[j] && !fin;
-            const unsigned long long m = __ballot(push);
+            const unsigned long long m = vote(push);
             at[j] = push ? qn + rank_of(m) : 0xFFFFFFFFu;
-            if (push) {
-                q_read[at[j]] = r[j];
-                q_key[at[j]] = key;
-                q_lnk[at[j]] = lnk;  // table 0's overflow slab: visited only if table 1 does not settle the read
-            }
+            // lnk: table 0's overflow slab, visited only if table 1 does not settle the read
+            if (push) e_all(at[j]) = make_uint4((uint32_t)r[j], (uint32_t)(r[j] >> 32), key, lnk);
             qn += (uint32_t)__popcll(m);
         };
         if constexpr (NQ01 == 1) {
             uint4 wa[4][1], wb[4][1];  // two rounds (2 x 4 reads per quad) in flight
-            const uint32_t o0 = off0(0), o1 = off0(1);
-            visit_issue<1, false>(b0, o0, none4, s, wa);
-            visit_issue<1, false>(b0, o1, none4, s, wb);
-            finish(0, wa, o0);
-            const uint32_t o2 = off0(2);
-            visit_issue<1, false>(b0, o2, none4, s, wa);
-            finish(1, wb, o1);
-            const uint32_t o3 = off0(3);
-            visit_issue<1, false>(b0, o3, none4, s, wb);
-            finish(2, wa, o2);
-            finish(3, wb, o3);
+            visit_issue<1>(b0, off0(0), s16, wa);
+            visit_issue<1>(b0, off0(1), s16, wb);
+            finish(0, wa);
+            visit_issue<1>(b0, off0(2), s16, wa);
+            finish(1, wb);
+            visit_issue<1>(b0, off0(3), s16, wb);
+            finish(2, wa);
+            finish(3, wb);
         } else {
             uint4 wa[4][2];  // 128-byte slabs: one round in flight (two would take 64 registers)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t oj = off0(j);
-                visit_issue<2, false>(b0, oj, none4, s, wa);
-                finish(j, wa, oj);
+                visit_issue<2>(b0, off0(j), s16, wa);
+                finish(j, wa);
             }
         }
     }
@@ -737,47 +779,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (qn && !(diag & 2u)) {
         const uint32_t qi = lane;
         const bool mine = qi < qn;
-        uint32_t kmin = 0xFFFFFFFFu, off1 = empty1;
+        uint32_t kmin = 0xFFFFFFFFu, off1 = empty1, lnk0 = 0;
         RestW rest1{0u, 0u};
         if (mine) {
-            const uint64_t r = q_read[qi];
-            const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
-            kmin = q_key[qi];
-            rest1 = rest_of<WIDE>(T1.start, T1.start + T1.slen, half1, rlo, rhi);
-            off1 = seed_value(rlo, rhi, T1.start, T1.slen) << S01;
+            const uint4 e = e_all(qi);
+            kmin = e.z;
+            lnk0 = e.w;
+            rest1 = rest_of<WIDE>(T1.start, T1.start + T1.slen, half1, e.x, e.y);
+            off1 = seed_value(e.x, e.y, T1.start, T1.slen) << S01;
         }
         uint4 wa[4][NQ01];
-        uint32_t l1[4];
-        visit_issue<NQ01, false>(b1, off1, none4, s, wa);
-        visit_scan<NQ01, WIDE>(wa, rest1, half1, hm1, s, kmin, l1);
-        if (FAST) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) l1[u] = wa[u][0].w;
-        }
-        const uint32_t t0 = quad_bcast<3>(l1[0]), t1 = quad_bcast<3>(l1[1]), t2 = quad_bcast<3>(l1[2]), t3 = quad_bcast<3>(l1[3]);
-        uint32_t lnk = s == 0 ? t0 : s == 1 ? t1 : s == 2 ? t2 : t3;
-        if (FAST) lnk = lnk != SLAB_EMPTY ? ((off1 >> S01) | 0x80000000u) : 0u;
+        uint32_t lnk;
+        visit_issue<NQ01>(b1, off1, s16, wa);
+        visit_scan<NQ01, WIDE>(wa, rest1, lane, wl, kmin, lnk);
+        // (the item stack shares its words with the transposition rows: the visit above is complete — it ends on its
+        // own LDS wait — before the first push below)
         // a read that table 1's primary slab settles (a third of the listed ones) needs neither overflow slab
         const bool more = mine && !settled(kmin);
-        uint32_t lnk0 = 0;
-        if (mine) {
-            q_key[qi] = kmin;
-            lnk0 = q_lnk[qi];
-        }
-        push_items(more && lnk0 != 0u, qi | ((lnk0 & 0x3FFFFFu) << 10));  // (FAST: bit 31 marks "there is more", the rest is the bucket)
-        push_items(more && lnk != 0u, qi | 0x100u | ((lnk & 0x3FFFFFu) << 10));
+        if (mine) e_key(qi) = kmin;
+        push_items(more && lnk0 != 0u, qi | (lnk0 << 10));
+        push_items(more && lnk != 0u, qi | 0x100u | (lnk << 10));
         for (uint32_t qb = 64; qb < qn; qb += 64) {
             if (wn > WL_CAP - 128) drain01();
             const uint32_t qj = qb + lane;
             const bool mj = qj < qn;
             uint32_t sv = 0, lj = 0;
             if (mj) {
-                const uint64_t r = q_read[qj];
-                sv = seed_value((uint32_t)r, (uint32_t)(r >> 32), T1.start, T1.slen);
-                lj = q_lnk[qj];
+                const uint4 e = e_all(qj);
+                sv = seed_value(e.x, e.y, T1.start, T1.slen);
+                lj = e.w;
             }
-            push_items(mj, qj | (FAST ? 0x300u : 0x100u) | (sv << 10));
-            push_items(mj && lj != 0u, qj | ((lj & 0x3FFFFFu) << 10));
+            push_items(mj, qj | 0x100u | (sv << 10));
+            push_items(mj && lj != 0u, qj | (lj << 10));
         }
     }
     if (!(diag & 2u)) drain01();
@@ -792,9 +825,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         const bool mine = qi < qn;
         uint32_t rlo = 0, rhi = 0, kmin = 0xFFFFFFFFu;
         if (mine) {
-            const uint64_t r = q_read[qi];
-            rlo = (uint32_t)r; rhi = (uint32_t)(r >> 32);
-            kmin = q_key[qi];
+            const uint4 e = e_all(qi);
+            rlo = e.x; rhi = e.y;
+            kmin = e.z;
         }
         const bool inrange = decide(mine, NSEG != 3, qi, kmin);
         if (NSEG == 3) {
@@ -811,8 +844,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
                 pass = ((hit[0] | hit[1]) & (hit[2] | hit[3])) != 0u;
             }
             if (mine && !inrange && !pass) put_miss(qi);
-            const unsigned long long m = __ballot(pass);
-            if (pass) l_t2[t2n + rank_of(m)] = (uint16_t)qi;
+            const unsigned long long m = vote(pass);
+            if (pass) l_t2(t2n + rank_of(m)) = (uint16_t)qi;
             t2n += (uint32_t)__popcll(m);
             push_items(pass, qi | 0x200u | (sv << 10));
         }
@@ -829,8 +862,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const bool mine = ti < t2n;
             uint32_t qi = 0, kmin = 0xFFFFFFFFu;
             if (mine) {
-                qi = l_t2[ti];
-                kmin = q_key[qi];
+                qi = l_t2(ti);
+                kmin = e_key(qi);
             }
             decide(mine, true, qi, kmin);
         }
@@ -841,10 +874,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     for (uint32_t tb = 0; tb < tien; tb += 16) {
         const uint32_t ti = tb + (lane >> 2);
         const bool act = ti < tien;
-        const uint32_t qi = act ? l_tie[ti] : 0u;
-        const uint64_t r = q_read[qi];
-        const uint32_t rlo = (uint32_t)r, rhi = (uint32_t)(r >> 32);
-        const uint32_t kmin = q_key[qi];
+        const uint32_t qi = act ? l_tie(ti) : 0u;
+        const uint4 e = e_all(qi);
+        const uint32_t rlo = e.x, rhi = e.y, kmin = e.z;
         const uint32_t d1 = kmin >> 24, g0 = kmin & SLAB_GIDX_MASK;
         uint32_t slot = NBR_NONE;
         if (act && sp.nbr_slot) slot = gload32(sp.nbr_slot, g0);
@@ -861,9 +893,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         best = min(best, quad_perm<0xB1>(best)); best = min(best, quad_perm<0x4E>(best));
         // without lists (or with more neighbours than a list holds) the exact path decides
         const bool slow = act && (!sp.nbr_slot || slot == NBR_OVER);
+        // (the list of exact-path entries is compacted into the tie list's own words: position sn + rank <= ti, and
+        // every quad has read its l_tie word above — LDS operations of one wave execute in order)
+        const unsigned long long m = vote(slow && s == 0);
+        if (slow && s == 0) l_tie(sn + rank_of(m)) = (uint16_t)qi;
         if (act && !slow && s == 0) put(qi, best, d1, 1u + cnt);
-        const unsigned long long m = __ballot(slow && s == 0);
-        if (slow && s == 0) l_slow[sn + rank_of(m)] = (uint16_t)qi;
         sn += (uint32_t)__popcll(m);
     }
     wave_lds_sync();
@@ -873,8 +907,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     if (sn) {
         const int last_lane = (int)(lane | 3u);
         for (uint32_t si = lane >> 2; si < sn; si += 16) {
-            const uint32_t qi = l_slow[si];
-            const uint64_t r = q_read[qi];
+            const uint32_t qi = l_tie(si);
+            const uint64_t r = e_read(qi);
             uint32_t key, nb;
             if constexpr (WIDE) slab_slow_wide<NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), max_mm, s, key, nb);
             else slab_slow<4, NSEG>(sp, (uint32_t)r, (uint32_t)(r >> 32), (int)max_mm, s, last_lane, key, nb);
@@ -908,7 +942,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             dist[j] = idx[j] >= 0 ? ((dist4 >> (8 * j)) & 0xFFu) : (uint32_t)BC_DIST_NONE;
             nb[j] = idx[j] >= 0 ? 1u : 0u;
             if (at[j] != 0xFFFFFFFFu) {
-                const uint64_t e = q_read[at[j]];
+                const uint64_t e = e_read(at[j]);
                 idx[j] = (int32_t)(uint32_t)e; dist[j] = (uint32_t)(e >> 32) & 0xFFu; nb[j] = (uint32_t)(e >> 40) & 0xFFu;
                 if (LIST && k <= 31 && (e >> 63)) { idx[j] = BC_IDX_MISS; dist[j] = (uint32_t)BC_DIST_NONE; nb[j] = 0u; mr[j] = e & ~(1ull << 63); }
             }
@@ -939,11 +973,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         for (int j = 0; j < 4; ++j)
             if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
         if (o.part.rec) {
-            // the lists are dead (every lane has its results in registers): q_read becomes the record staging area
-            // (2 KiB = PART_SLOTS two-byte slots), the item stack the range counters
-            static_assert(sizeof(q_read) >= PART_SLOTS * sizeof(uint16_t) && WL_CAP >= PART_MAX_NR, "record staging");
+            // the lists are dead (every lane has its results in registers): the list entries become the record staging
+            // area (the first 2 KiB = PART_SLOTS two-byte slots), the item stack the range counters
+            static_assert(sizeof(q_ent) >= PART_SLOTS * sizeof(uint16_t) && WL_CAP >= PART_MAX_NR, "record staging");
             wave_lds_sync();
-            part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_read), wl);
+            part_emit(o.part, blockIdx.x, idx, lane, reinterpret_cast<uint16_t*>(q_ent), wl);
         }
         if (LIST && o.miss_cnt) {
             // first stage of a cascade: the reads left without a hit go on the second stage's list (position, read), in
@@ -954,7 +988,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 ms[j] = p0 + j < tn && idx[j] == BC_IDX_MISS;
-                const unsigned long long m = __ballot(ms[j]);
+                const unsigned long long m = vote(ms[j]);
                 off[j] = mtot + rank_of(m);
                 mtot += (uint32_t)__popcll(m);
             }
@@ -1376,12 +1410,14 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
                 cur = nxt;
                 pos = 0;
             }
-            // isolation flags ride in the index word (see bc_device.h)
+            // the isolation class rides in the index word (see bc_device.h): how many of the radii 2, 4 .. 2d the
+            // guide's nearest neighbour lies beyond
             uint32_t fl = 0;
             if (!lib->h_nn.empty()) {
                 const int nn = lib->h_nn[gidx[j]];
-                if (nn > 2 * d) fl |= SLAB_F_ISO;
-                if (nn > 2 * (d - 1)) fl |= SLAB_F_ISO1;
+                uint32_t c = 0;
+                for (int e = 1; e <= d; ++e) c += nn > 2 * e ? 1u : 0u;
+                fl = c << SLAB_CLASS_SHIFT;
             }
             put_entry((cur << log2S) + pos++, keys[j], gidx[j] | fl, false, 0);
         }
@@ -1398,57 +1434,6 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     T.log2S = (uint32_t)log2S;
     for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
         T.dmask[t] = (t < s) ? (((1u << cs.slen[t]) - 1u) << cs.start[t]) : 0u;
-    if (s == 0) { sl.fast = FastTables{}; for (auto& v : lib->fast_stage) v.clear(); }
-    if (s < 2 && !wide && log2S == 3 && (cs.nseg == 2 || cs.nseg == 3) && env_int("BC_FAST01", 0)) {  // see FastTables: measured, not the default
-        std::vector<uint2> prim((size_t)(nb + 1) * 8, make_uint2(0u, SLAB_EMPTY)), sec((size_t)(nb + 1) * 8, make_uint2(0u, SLAB_EMPTY));
-        for (uint32_t b = 0; b < nb; ++b) {
-            size_t cur = b;      // slab of `sec` being filled
-            uint32_t pos = 0;    // entries of the bucket placed so far
-            for (uint32_t j = off[b]; j < off[b + 1]; ++j, ++pos) {
-                uint32_t fl = 0;
-                if (!lib->h_nn.empty()) {
-                    const int nn = lib->h_nn[gidx[j]];
-                    if (nn > 2 * d) fl |= SLAB_F_ISO;
-                    if (nn > 2 * (d - 1)) fl |= SLAB_F_ISO1;
-                }
-                const uint32_t lo = (uint32_t)keys[j], hi = (uint32_t)(keys[j] >> 32);
-                const uint32_t lo_r = (lo & below) | ((sh >= 32 ? 0u : (lo >> sh)) << start);
-                const uint32_t hi_r = (hi & below) | ((sh >= 32 ? 0u : (hi >> sh)) << start);
-                const uint2 e = make_uint2(lo_r | (hi_r << 16), gidx[j] | fl);
-                if (pos < 8) { prim[(size_t)b * 8 + pos] = e; continue; }
-                uint32_t p2 = (pos - 8) % 7;
-                if (pos > 8 && p2 == 0) {  // the secondary slab is full: chain another
-                    const size_t nxt = sec.size() / 8;
-                    sec.resize(sec.size() + 8, make_uint2(0u, SLAB_EMPTY));
-                    sec[cur * 8 + 7] = make_uint2((uint32_t)nxt, SLAB_LINK);
-                    cur = nxt;
-                }
-                sec[cur * 8 + p2] = e;
-            }
-        }
-        if ((sec.size() / 8) < (1u << 22)) {
-            lib->fast_stage[2 * s] = std::move(prim);
-            lib->fast_stage[2 * s + 1] = std::move(sec);
-        }
-        if (s == 1 && !lib->fast_stage[0].empty() && !lib->fast_stage[2].empty() &&
-            lib->fast_stage[0].size() == lib->fast_stage[2].size()) {  // (equal bucket counts: one empty-slab number)
-            std::vector<uint2> arena;
-            uint32_t offs[4];
-            for (int r = 0; r < 4; ++r) {
-                offs[r] = (uint32_t)(arena.size() * sizeof(uint2));
-                arena.insert(arena.end(), lib->fast_stage[r].begin(), lib->fast_stage[r].end());
-            }
-            if ((arena.size() * sizeof(uint2)) >> 31 == 0) {
-                uint2* d_arena;
-                if ((rc = dev_upload(lib, arena, &d_arena)) != BC_OK) return rc;
-                sl.fast.base = reinterpret_cast<const char*>(d_arena);
-                sl.fast.prim[0] = offs[0]; sl.fast.sec[0] = offs[1]; sl.fast.prim[1] = offs[2]; sl.fast.sec[1] = offs[3];
-                sl.fast.empty = nb;
-                sl.fast.ok = 1u;
-            }
-        }
-        if (s == 1) for (auto& v : lib->fast_stage) { v.clear(); v.shrink_to_fit(); }
-    }
     if (s == cs.nseg - 1) {  // descriptor block for the kernel (read through scalar loads)
         sl.nbr_slot = lib->h_nn.empty() ? nullptr : lib->d_nbr_slot;
         sl.nbr = lib->h_nn.empty() ? nullptr : lib->d_nbr;
@@ -2032,16 +2017,13 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
-#define BC_WAVE_FAST(NSEG_, NQ2_)                                                                                    \
+#define BC_WAVE_LIST(NSEG_, NQ2_)                                                                                    \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
-#define BC_WAVE_LIST(NSEG_, NQ2_, FAST_)                                                                             \
-    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, FAST_, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
-                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
 #ifdef BC_DIAG_BUILD
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (listing && hp.fast.ok) BC_WAVE_LIST(NSEG_, NQ2_, true); else if (listing) BC_WAVE_LIST(NSEG_, NQ2_, false); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (listing) BC_WAVE_LIST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
 #else
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (listing && hp.fast.ok) BC_WAVE_LIST(NSEG_, NQ2_, true); else if (listing) BC_WAVE_LIST(NSEG_, NQ2_, false); else if (hp.fast.ok) BC_WAVE_FAST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (listing) BC_WAVE_LIST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
 #endif
                     if (!wide && nq01 == 1) {
                         if (nseg == 2) BC_WAVE_P(2, 1);
@@ -2059,7 +2041,6 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     }
 #undef BC_WAVE_P
 #undef BC_WAVE_LIST
-#undef BC_WAVE_FAST
 #undef BC_WAVE_LAUNCH
                     note_kernel(lib, "k_match_wq");
                     BC_HIP(hipGetLastError());
@@ -2420,6 +2401,13 @@ int bc_lib_release_stream(bc_lib* lib, void* stream) {
         lib->ws.erase(it);
         break;
     }
+    return BC_OK;
+}
+
+int bc_lib_workspace_count(bc_lib* lib, uint32_t* n_streams) {
+    if (!lib || !n_streams) { set_error("bc_lib_workspace_count: null"); return BC_EINVAL; }
+    std::lock_guard<std::mutex> g(lib->ws_mutex);
+    *n_streams = (uint32_t)lib->ws.size();
     return BC_OK;
 }
 

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
                     p1 = l1 ? reinterpret_cast<const uint4*>(T1.slabs + ((size_t)l1 << 3)) : nullptr;
                 } else {
                     const uint32_t km = grp_min<LPR>(kmin);
-                    const bool settled = (km >> 24) <= (uint32_t)max_mm && (km & SLAB_F_ISO) &&
+                    const bool settled = (km >> 24) <= (uint32_t)max_mm && ((km >> SLAB_CLASS_SHIFT) & 3u) == (uint32_t)max_mm &&
                                          (grp_max<LPR>(kmax) - bias) == km;
                     if (NSEG > 2 && (km >> 24) > 1u && !settled) {
                         const uint4* b = reinterpret_cast<const uint4*>(
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) void k_match_fused(const SlabParams* __restr
             kmin = grp_min<LPR>(kmin);
             // a single candidate so far that is isolated at radius 2*max_mm is the answer: nothing else can be
             // within max_mm of this read (k_nn_dist), so the remaining tables are not visited
-            const bool settled = (kmin >> 24) <= (uint32_t)max_mm && (kmin & SLAB_F_ISO) &&
+            const bool settled = (kmin >> 24) <= (uint32_t)max_mm && ((kmin >> SLAB_CLASS_SHIFT) & 3u) == (uint32_t)max_mm &&
                                  (grp_max<LPR>(kmax) - bias) == kmin;
             if (NSEG > 2 && (kmin >> 24) > 1u && !settled) {
                 // round B: the remaining tables can only add guides at distance >= 2

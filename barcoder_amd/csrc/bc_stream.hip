@@ -370,15 +370,20 @@ struct Slot {  // one worker's buffers
 
 struct OddOut { uint64_t key; std::string text; };
 
-// run-wide list of undocumented windows (word, key): touched only under `m`.  A worker collects a chunk's misses
-// into buffers of its own and appends them — growing the list first when it has to — once its stream has finished
-// the chunk.  (Round 2 let every worker's kernel append to the shared list and grew it under a lock the launches
-// did not take: a worker past its capacity check could launch with pointers another one was swapping out.)
+// run-wide list of undocumented windows (word, key).  A worker collects a chunk's misses into buffers of its own and
+// appends them once its stream has finished the chunk: it RESERVES a range of the list under the short mutex `m`,
+// then copies into it on its own stream while holding only the SHARED side of `rw` — eight workers' copies and their
+// two stream waits overlap (round 3 held one mutex across both hipStreamSynchronize calls: workers serialised there on
+// miss-heavy files).  Growing takes the exclusive side: every reserved range has been copied by then (a copier
+// waits for its stream before it lets go of the shared side), so the old buffers can move.  (Round 2 let every
+// worker's kernel append to the shared list and grew it under a lock the launches did not take: a worker past its
+// capacity check could launch with pointers another one was swapping out.)
 struct MissList {
     DevBuf words, keys, texts;
     int text_k = 0;  // > 0: every entry also carries its window's text (barcodes of more than 32 nt)
     uint64_t cap = 0, used = 0;
-    std::mutex m;
+    std::mutex m;             // used / cap
+    std::shared_mutex rw;     // shared: copying into a reserved range; exclusive: growing
     int reserve(uint64_t n) {
         int rc;
         if ((rc = words.reserve(n * 8)) != BC_OK) return rc;
@@ -387,31 +392,48 @@ struct MissList {
         cap = n;
         return BC_OK;
     }
-    // append n entries from device buffers; the copies run on `st` and are complete on return
-    int append(const void* w, const void* k, const void* t, uint64_t n, hipStream_t st) {
-        std::lock_guard<std::mutex> lk(m);
-        if (used + n > cap) {
-            const uint64_t ncap = std::max<uint64_t>(cap * 2, used + n + 65536);
-            DevBuf nw, nk, nt;
-            int rc;
-            if ((rc = nw.reserve(ncap * 8)) != BC_OK) return rc;
-            if ((rc = nk.reserve(ncap * 8)) != BC_OK) return rc;
-            if (text_k && (rc = nt.reserve(ncap * (uint64_t)text_k)) != BC_OK) return rc;
+    int grow(uint64_t need, hipStream_t st) {  // caller holds the exclusive side of rw
+        if (need <= cap) return BC_OK;         // somebody else grew it meanwhile
+        const uint64_t ncap = std::max<uint64_t>(cap * 2, need + 65536);
+        DevBuf nw, nk, nt;
+        int rc;
+        if ((rc = nw.reserve(ncap * 8)) != BC_OK) return rc;
+        if ((rc = nk.reserve(ncap * 8)) != BC_OK) return rc;
+        if (text_k && (rc = nt.reserve(ncap * (uint64_t)text_k)) != BC_OK) return rc;
+        if (used) {
             BC_HIP(hipMemcpyAsync(nw.p, words.p, used * 8, hipMemcpyDeviceToDevice, st));
             BC_HIP(hipMemcpyAsync(nk.p, keys.p, used * 8, hipMemcpyDeviceToDevice, st));
-            if (text_k && used) BC_HIP(hipMemcpyAsync(nt.p, texts.p, used * (uint64_t)text_k, hipMemcpyDeviceToDevice, st));
-            BC_HIP(hipStreamSynchronize(st));  // before the old buffers are freed (nw / nk / nt leave scope)
-            std::swap(nw.p, words.p); std::swap(nw.cap, words.cap);
-            std::swap(nk.p, keys.p); std::swap(nk.cap, keys.cap);
-            std::swap(nt.p, texts.p); std::swap(nt.cap, texts.cap);
-            cap = ncap;
+            if (text_k) BC_HIP(hipMemcpyAsync(nt.p, texts.p, used * (uint64_t)text_k, hipMemcpyDeviceToDevice, st));
         }
-        BC_HIP(hipMemcpyAsync((uint64_t*)words.p + used, w, n * 8, hipMemcpyDeviceToDevice, st));
-        BC_HIP(hipMemcpyAsync((uint64_t*)keys.p + used, k, n * 8, hipMemcpyDeviceToDevice, st));
-        if (text_k) BC_HIP(hipMemcpyAsync((char*)texts.p + used * (uint64_t)text_k, t, n * (uint64_t)text_k, hipMemcpyDeviceToDevice, st));
-        BC_HIP(hipStreamSynchronize(st));  // complete before anybody else may grow (and copy) the list
-        used += n;
+        BC_HIP(hipStreamSynchronize(st));  // before the old buffers are freed (nw / nk / nt leave scope)
+        std::swap(nw.p, words.p); std::swap(nw.cap, words.cap);
+        std::swap(nk.p, keys.p); std::swap(nk.cap, keys.cap);
+        std::swap(nt.p, texts.p); std::swap(nt.cap, texts.cap);
+        cap = ncap;
         return BC_OK;
+    }
+    // append n entries from device buffers; the copies run on `st` and are complete on return
+    int append(const void* w, const void* k, const void* t, uint64_t n, hipStream_t st) {
+        for (;;) {
+            {
+                std::shared_lock<std::shared_mutex> copying(rw);
+                uint64_t at = ~0ull;
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    if (used + n <= cap) { at = used; used += n; }
+                }
+                if (at != ~0ull) {
+                    BC_HIP(hipMemcpyAsync((uint64_t*)words.p + at, w, n * 8, hipMemcpyDeviceToDevice, st));
+                    BC_HIP(hipMemcpyAsync((uint64_t*)keys.p + at, k, n * 8, hipMemcpyDeviceToDevice, st));
+                    if (text_k) BC_HIP(hipMemcpyAsync((char*)texts.p + at * (uint64_t)text_k, t, n * (uint64_t)text_k, hipMemcpyDeviceToDevice, st));
+                    BC_HIP(hipStreamSynchronize(st));  // complete before anybody may grow (and move) the list
+                    return BC_OK;
+                }
+            }
+            std::unique_lock<std::shared_mutex> growing(rw);  // nobody copies now; `used` is stable under rw + m
+            int rc = grow(used + n, st);
+            if (rc != BC_OK) return rc;
+        }
     }
 };
 
@@ -579,6 +601,12 @@ int run_file(FileJob& J) {
                 if ((rc2 = s.tmp.reserve((n_words / 1024 + 2) * 4)) != BC_OK) return rc2;
                 if ((rc2 = s.odd.reserve((size_t)odd_cap * sizeof(OddRec))) != BC_OK) return rc2;
                 std::shared_lock<std::shared_mutex> window_lock;
+                // leaving this chunk early (an error below) with kernels in flight: wait for them BEFORE the window lock
+                // goes (declared after it, destroyed before it) — another worker may grow, i.e. move, the arrays they write
+                struct DrainOnExit {
+                    hipStream_t st; bool armed = true;
+                    ~DrainOnExit() { if (armed) (void)hipStreamSynchronize(st); }
+                } drain{s.st};
                 uint64_t* d_packed;
                 uint8_t* d_status;
                 if (store) {  // the windows go to the run-wide arrays, at the reads' own indices
@@ -645,8 +673,13 @@ int run_file(FileJob& J) {
                 prof_us[3] += since(t_a);
                 t_a = tick();
                 BC_HIP(hipStreamSynchronize(s.st));
+                drain.armed = false;
                 if (window_lock.owns_lock()) window_lock.unlock();  // this chunk's writes into the run-wide arrays are done
                 prof_us[4] += since(t_a);
+                if (fl[1] == 2u) {  // k_lines_to_windows: the newline list was cut short — a sizing bug here, not bad input
+                    set_error("%s: internal error: newline list overflow (%llu entries)", path, (unsigned long long)nl_cap);
+                    return BC_ECAP;
+                }
                 if (fl[1]) { set_error("%s: a line longer than %llu bytes", path, (unsigned long long)SLACK); return BC_EINVAL; }
                 const uint64_t n_m = (uint64_t)fl[2] | ((uint64_t)fl[3] << 32);
                 if (n_m && (rc2 = J.misses->append(s.mw.p, s.mk.p, s.mt.p, n_m, s.st)) != BC_OK) return rc2;
@@ -660,10 +693,18 @@ int run_file(FileJob& J) {
                         J.odd_all.push_back(OddOut{o.key, std::string((const char*)s.h_text + o.begin, o.len)});
                 }
             }
-            BC_HIP(hipStreamSynchronize(s.st));
-            return bc_lib_release_stream(J.lib, s.st);  // the stream dies with the slot: its workspace on the library goes first
+            return BC_OK;
         };
-        const int code = body();
+        int code = body();
+        // On EVERY exit — the normal one, an error of this worker, or `return BC_OK` because another worker failed — the
+        // stream dies with the slot, so its workspace on the library (tally records, cascade buffers: keyed by the
+        // stream handle) goes first; a later stream that reuses the handle value must not inherit it.
+        if (s.st) {
+            const hipError_t e = hipStreamSynchronize(s.st);
+            const int rr = bc_lib_release_stream(J.lib, s.st);
+            if (code == BC_OK && e != hipSuccess) { set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e)); code = BC_EHIP; }
+            if (code == BC_OK) code = rr;
+        }
         if (code != BC_OK) fail(code);
     };
     const auto t_workers = std::chrono::steady_clock::now();
@@ -1011,6 +1052,12 @@ int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_b
                                const char* R_rev, int R_rev_len, int max_mismatch, int algo, uint64_t key_base, int n_threads,
                                uint64_t* h_counts, uint64_t* h_first_seen, bc_stream_result** out) {
     if (!lib || !path_fwd || !path_rev || !out) { set_error("bc_stream_count_pair: null argument"); return BC_EINVAL; }
+    if (lib->text_k != 0) {
+        // a text-hash library (bc_lib_attach_text): its guides are hashes of barcodes of more than 32 nt, not k-mers —
+        // pairing packed 32-base windows against them would count nothing, silently
+        set_error("bc_stream_count_pair: barcodes of more than 32 nt are not paired on the device (library with attached texts)");
+        return BC_EINVAL;
+    }
     uint32_t G = 0; int k = 0, device = 0;
     bc_lib_info(lib, &G, &k, &device);
     const auto t_begin = std::chrono::steady_clock::now();

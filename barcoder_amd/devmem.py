@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -18,38 +19,65 @@ _POOL_MAX_ITEM = 256 << 20       # larger buffers are returned to the runtime at
 _dev_pool: dict[int, list] = {}  # device -> [(cap, ptr value)]
 _pin_pool: list = []             # [(cap, ptr value)]
 _idle = {"dev": 0, "pin": 0}
+_lock = threading.RLock()        # the pools and _idle (a PinnedBlock can be finalised on any thread)
 
 
 def _take(pool: list, nbytes: int, kind: str):
-    best = -1
-    for i, (cap, _p) in enumerate(pool):
-        if nbytes <= cap <= max(2 * nbytes, 1 << 16) and (best < 0 or cap < pool[best][0]):
-            best = i
-    if best < 0:
-        return None
-    cap, p = pool.pop(best)
-    _idle[kind] -= cap
-    return cap, p
+    with _lock:
+        best = -1
+        for i, (cap, _p) in enumerate(pool):
+            if nbytes <= cap <= max(2 * nbytes, 1 << 16) and (best < 0 or cap < pool[best][0]):
+                best = i
+        if best < 0:
+            return None
+        cap, p = pool.pop(best)
+        _idle[kind] -= cap
+        return cap, p
 
 
-def _drain():
+def _give(pool: list, cap: int, p: int, kind: str) -> bool:
+    """Back to the pool if it has room; False = the caller returns the buffer to the runtime."""
+    with _lock:
+        if cap <= _POOL_MAX_ITEM and _idle[kind] + cap <= _POOL_MAX_BYTES:
+            pool.append((cap, p))
+            _idle[kind] += cap
+            return True
+    return False
+
+
+def drain():
+    """Return every idle pooled buffer (HBM and page-locked host memory) to the runtime.  The C side allocates on
+    its own (stream slots, cascade workspace, window stores): callers that are about to start a large job —
+    `heuristicount.count_barcodes` before its bulk pass — drain first, and an allocation that fails here drains and
+    retries once, so a job near the HBM limit does not fail on memory this package is only holding idle."""
     try:
         L = N.load()
     except Exception:
         return
-    for dev, pool in _dev_pool.items():
-        if pool:
-            L.bc_dev_set(dev)
-        for _cap, p in pool:
-            L.bc_dev_free(N.vp(p))
-        pool.clear()
-    for _cap, p in _pin_pool:
-        L.bc_host_free_pinned(N.vp(p))
-    _pin_pool.clear()
-    _idle["dev"] = _idle["pin"] = 0
+    with _lock:
+        for dev, pool in _dev_pool.items():
+            if pool:
+                L.bc_dev_set(dev)
+            for _cap, p in pool:
+                L.bc_dev_free(N.vp(p))
+            pool.clear()
+        for _cap, p in _pin_pool:
+            L.bc_host_free_pinned(N.vp(p))
+        _pin_pool.clear()
+        _idle["dev"] = _idle["pin"] = 0
 
 
-atexit.register(_drain)
+_drain = drain
+atexit.register(drain)
+
+
+def _alloc_retry(fn, out, cap):
+    """fn(byref(out), cap); on failure drain the pools and try once more"""
+    rc = fn(C.byref(out), cap)
+    if rc != 0:
+        drain()
+        rc = fn(C.byref(out), cap)
+    N.check(rc)
 
 
 class DevBuf:
@@ -59,13 +87,15 @@ class DevBuf:
         self.nbytes = int(nbytes)
         self.device = device
         want = max(self.nbytes, 16)
-        got = _take(_dev_pool.setdefault(device, []), want, "dev")
+        with _lock:
+            pool = _dev_pool.setdefault(device, [])
+        got = _take(pool, want, "dev")
         if got:
             self._cap, self._p = got[0], N.vp(got[1])
         else:
             self._cap = want if want > (1 << 16) else 1 << 16
             self._p = N.vp()
-            N.check(L.bc_dev_alloc(C.byref(self._p), self._cap))
+            _alloc_retry(L.bc_dev_alloc, self._p, self._cap)
 
     @property
     def ptr(self):
@@ -93,12 +123,11 @@ class DevBuf:
 
     def free(self):
         if self._p:
-            if self._cap <= _POOL_MAX_ITEM and _idle["dev"] + self._cap <= _POOL_MAX_BYTES:
-                # (every entry point that filled this buffer has synchronised before returning to Python; the next
-                # user's work is ordered behind it on the device anyway)
-                _dev_pool.setdefault(self.device, []).append((self._cap, self._p.value))
-                _idle["dev"] += self._cap
-            else:
+            # (every entry point that filled this buffer has synchronised before returning to Python; the next
+            # user's work is ordered behind it on the device anyway)
+            with _lock:
+                pool = _dev_pool.setdefault(self.device, [])
+            if not _give(pool, self._cap, self._p.value, "dev"):
                 N.load().bc_dev_free(self._p)
             self._p = N.vp()
 
@@ -128,7 +157,7 @@ class PinnedBlock:
         else:
             self._cap = want if want > (1 << 16) else 1 << 16
             self._p = N.vp()
-            N.check(N.load().bc_host_alloc_pinned(C.byref(self._p), self._cap))
+            _alloc_retry(N.load().bc_host_alloc_pinned, self._p, self._cap)
 
     @property
     def ptr(self):
@@ -142,10 +171,7 @@ class PinnedBlock:
     def __del__(self):
         try:
             if self._p:
-                if self._cap <= _POOL_MAX_ITEM and _idle["pin"] + self._cap <= _POOL_MAX_BYTES:
-                    _pin_pool.append((self._cap, self._p.value))
-                    _idle["pin"] += self._cap
-                else:
+                if not _give(_pin_pool, self._cap, self._p.value, "pin"):
                     N.load().bc_host_free_pinned(self._p)
                 self._p = N.vp()
         except Exception:

@@ -46,17 +46,27 @@ def free_port() -> int:
     return p
 
 
-def launch_workers(argv, nproc: int, env=None, timeout=None) -> int:
+DEFAULT_LAUNCH_TIMEOUT = 24 * 3600.0  # seconds; BC_LAUNCH_TIMEOUT overrides
+
+
+def launch_workers(argv, nproc: int, env=None, timeout=-1) -> int:
     """Start `nproc` ranks of `python argv...` on this node (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment) and wait for
     them.  Rank 0 inherits stdout; the other ranks' stdout goes to stderr, so a
     caller that prints one result line on rank 0 keeps a clean stdout.  Returns
     the first non-zero exit status (the remaining ranks are terminated), else 0.
 
+    timeout (seconds; default BC_LAUNCH_TIMEOUT or 24 h — always finite): a rank that
+    HANGS (in RCCL initialisation, in a collective a peer never joins) does not fail, so
+    nothing else would end the job: when the time is up every rank still alive is
+    terminated, killed five seconds later if it ignores that, and the status is 124.
+
     The calling process must not have initialised the GPU: the children are
     fresh interpreters (no fork of a HIP context, no exec from a GPU process)."""
     if nproc < 1:
         raise ValueError("launch_workers: nproc must be >= 1")
+    if timeout is None or timeout < 0:
+        timeout = float(os.environ.get("BC_LAUNCH_TIMEOUT", DEFAULT_LAUNCH_TIMEOUT))
     base = dict(os.environ if env is None else env)
     base.setdefault("MASTER_ADDR", "127.0.0.1")
     base["MASTER_PORT"] = str(free_port())
@@ -71,6 +81,7 @@ def launch_workers(argv, nproc: int, env=None, timeout=None) -> int:
         rc = 0
         import time
         t0 = time.monotonic()
+        kill_at = None
         alive = list(procs)
         while alive:
             for p in list(alive):
@@ -83,11 +94,17 @@ def launch_workers(argv, nproc: int, env=None, timeout=None) -> int:
                     for q in alive:  # a failed rank would leave the others waiting in a collective
                         q.terminate()
             if alive:
-                if timeout is not None and time.monotonic() - t0 > timeout:
+                now = time.monotonic()
+                if kill_at is None and now - t0 > timeout:
                     rc = rc or 124
+                    print(f"launch_workers: {len(alive)} of {nproc} ranks still running after {timeout:.0f} s: terminating them",
+                          file=sys.stderr)
                     for q in alive:
                         q.terminate()
-                    timeout = None
+                    kill_at = now + 5.0
+                elif kill_at is not None and now > kill_at:
+                    for q in alive:
+                        q.kill()
                 time.sleep(0.05)
         return rc
     finally:

@@ -31,6 +31,8 @@ def pack_kmers(seqs, k: int | None = None):
 def unpack_kmers(packed, k: int):
     packed = np.ascontiguousarray(packed, np.uint64)
     n = packed.size
+    if n == 0:
+        return []
     out = np.empty(n * k, np.uint8)
     N.check(N.load().bc_unpack_kmers(N.ptr(packed), n, k, N.ptr(out)))
     s = out.tobytes().decode("ascii")

@@ -323,6 +323,8 @@ def window_labels(words, k: int):
     """Undocumented windows as strings: packed words (k <= 32) or rows of text (a 1-D array of k-byte void items:
     barcodes of more than 32 nt)."""
     words = np.asarray(words)
+    if words.size == 0:
+        return []
     if words.dtype.kind == "V":
         raw = words.tobytes().decode("ascii", errors="replace")
         return [raw[i * k:(i + 1) * k] for i in range(words.size)]
@@ -614,13 +616,15 @@ def process_chunk(chunk, bcs_with_flanks_fwd, bcs_with_flanks_rev, L_fwd_start, 
 
 
 # ------------------------------------------------------------------------------ driver
-def merge_undocumented(tables):
+def merge_undocumented(tables, bc_len: int = 0):
     """[(words, counts, first), ...] -> one table: unique packed windows with summed counts and
-    the smallest first index (any order of the input tables: ranks, chunks)."""
+    the smallest first index (any order of the input tables: ranks, chunks).  bc_len > 32 names the
+    width of the text rows the empty table has then (a rank that owned no chunk, an empty input):
+    packed-word code must never see it as k-mers."""
     tables = [t for t in tables if t[0] is not None and t[0].size]
     if not tables:
         z = np.zeros(0, np.uint64)
-        return z, z, z
+        return (np.zeros(0, np.dtype((np.void, bc_len))) if bc_len > 32 else z), z, z
     if np.asarray(tables[0][0]).dtype.kind == "V":  # windows of more than 32 nt: rows of text instead of packed words
         w = np.concatenate([t[0] for t in tables])
         c = np.concatenate([t[1] for t in tables]).astype(np.uint64)
@@ -842,13 +846,15 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
         return counts, first_seen
 
     n_units = os.path.getsize(file1) if plan == "bytes" else world
+    from . import devmem
+    devmem.drain()  # the bulk pass allocates on the C side (stream slots, window stores): idle pooled buffers go first
     counts, first_seen = D.count_sharded(n_units, bulk, G + 1, rank, world, device=device)
     total_reads = int(counts[G])
     counts, first_seen = counts[:G], first_seen[:G]
-    mine_u = merge_undocumented(undoc_tables)
+    mine_u = merge_undocumented(undoc_tables, bc_len)
     if world > 1:  # variable-length leftovers: undocumented windows (padded tensors) and the few odd string events
         if bc_len > 32:  # rows of text: few enough to pickle
-            mine_u = merge_undocumented(D.gather_objects(mine_u))
+            mine_u = merge_undocumented(D.gather_objects(mine_u), bc_len)
         else:
             mine_u = merge_undocumented(D.gather_tables(mine_u, device=device))
         odd_events = [e for part in D.gather_objects(odd_events) for e in part]
@@ -943,6 +949,8 @@ def _cli():
     p.add_argument("--chunk-reads", type=int, default=1 << 20, help="reads per device pass (default 1048576)")
     p.add_argument("--gpus", type=int, default=1,
                    help="ranks (one per GPU) the bulk pass is sharded over; replaces the reference's Pool fan-out")
+    p.add_argument("--timeout", type=float, default=-1.0,
+                   help="with --gpus N: seconds after which ranks still running are ended (default BC_LAUNCH_TIMEOUT or 24 h)")
     a = p.parse_args()
     logging.basicConfig(level=logging.INFO, stream=sys.stderr, format="%(levelname)s %(message)s")
     from . import dist as D
@@ -951,7 +959,7 @@ def _cli():
         env = dict(os.environ)
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-        raise SystemExit(D.launch_workers(["-m", "barcoder_amd.heuristicount"] + sys.argv[1:], a.gpus, env=env))
+        raise SystemExit(D.launch_workers(["-m", "barcoder_amd.heuristicount"] + sys.argv[1:], a.gpus, env=env, timeout=a.timeout))
     if D.under_launcher():
         import contextlib
         import io

@@ -302,7 +302,9 @@ def main():
     # ---- self-launch: N ranks as fresh child processes, before this process imports torch or touches the GPU
     if args.gpus > 1 and not ("WORLD_SIZE" in os.environ and "RANK" in os.environ):
         launcher = _dist_module_without_package()
-        raise SystemExit(launcher.launch_workers([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        # a rank that hangs (RCCL initialisation, a collective a peer never joins) must not hold the job: bounded wait
+        raise SystemExit(launcher.launch_workers([os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                                 timeout=float(os.environ.get("BC_LAUNCH_TIMEOUT", 1800))))
 
     K = args.k
     from barcoder_amd import dist as D

@@ -249,6 +249,10 @@ int bc_lib_info(const bc_lib *lib, uint32_t *n_guides, int *k, int *device);
  * that launches on it.  A caller that creates and destroys streams releases a
  * stream's workspace before destroying the stream (waits for the stream). */
 int bc_lib_release_stream(bc_lib *lib, void *stream);
+/* How many streams hold a workspace on the library right now (at most 1024).  The
+ * ingest entry points (bc_stream_count_*) release their worker streams on every exit,
+ * failed runs included: the count is back where it was when they return. */
+int bc_lib_workspace_count(bc_lib *lib, uint32_t *n_streams);
 /* Barcodes of 33 ... 1000 nt: the library was created with k = 32 over bc_hash_kmers of the texts; attaching the
  * texts (n_guides x text_k characters) lets bc_stream_count_file take such a library: windows are hashed on the
  * device, every hit is verified against the text there, the undocumented table carries texts. */

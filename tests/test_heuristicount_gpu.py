@@ -252,3 +252,7 @@ def test_long_barcode_entry_points_refuse_what_they_cannot_do(gpu_device, tmp_pa
         stream_count_file(long_lib.handle, str(rd), 0, os.path.getsize(rd), 5, "", "", False, 1, "auto", 0, c64, f64)
     sr = stream_count_file(long_lib.handle, str(rd), 0, os.path.getsize(rd), 5, "", "", False, 0, "auto", 0, c64, f64)
     assert sr.n_reads == len(seqs) and int(c64.sum()) == len(seqs) and sr.u_words.size == 0
+    # the paired entry point pairs packed windows of at most 32 bases: a library of text hashes is refused there
+    from barcoder_amd.ingest import stream_count_pair
+    with pytest.raises(ValueError, match="more than 32 nt"):
+        stream_count_pair(long_lib.handle, str(rd), str(rd), 5, "", "", 2, "", "", 0, "auto", 0, c64, f64)

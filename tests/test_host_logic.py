@@ -558,6 +558,17 @@ def test_merge_undocumented_any_order():
         assert w.tolist() == [1, 5, 7, 9] and c.tolist() == [6, 3, 1, 5] and f.tolist() == [2, 10, 8, 1]
     w, c, f = H.merge_undocumented([])
     assert w.size == c.size == f.size == 0
+    # barcodes of more than 32 nt: the empty table has text rows of that width (a rank that owned no chunk), it merges
+    # with a filled one, and nothing treats it as packed k-mers
+    w, c, f = H.merge_undocumented([], 40)
+    assert w.size == 0 and w.dtype == np.dtype((np.void, 40)) and H.window_labels(w, 40) == []
+    rows = np.frombuffer(b"A" * 40 + b"C" * 40, np.dtype((np.void, 40)))
+    filled = (rows, np.array([2, 3], u), np.array([7, 5], u))
+    w2, c2, f2 = H.merge_undocumented([(w, c, f), filled, filled], 40)
+    assert H.window_labels(w2, 40) == ["A" * 40, "C" * 40] and c2.tolist() == [4, 6] and f2.tolist() == [7, 5]
+    assert H.window_labels(np.zeros(0, u), 20) == []
+    from barcoder_amd.encoding import unpack_kmers
+    assert unpack_kmers(np.zeros(0, u), 40) == []
     assert H.shard_plan("a.reads", None, 1) == "stride" and H.shard_plan("a.reads", None, 4) == "bytes"
     assert H.shard_plan("a.reads.gz", None, 4) == "stride" and H.shard_plan("a.fastq", "b.fastq", 4) == "stride"
 
@@ -585,6 +596,36 @@ def test_launch_workers_starts_ranks_and_reports_failure(tmp_path):
     assert "rank 1 of 3" in ok.stderr and "rank 2 of 3" in ok.stderr
     bad = subprocess.run([sys.executable, "-c", drv, "2"], capture_output=True, text=True, env=env)
     assert bad.returncode == 7
+
+
+def test_launch_workers_ends_a_rank_that_hangs(tmp_path):
+    """A rank that hangs (it does not fail: RCCL initialisation, a collective a peer never joins) must not hold the job
+    for ever: launch_workers' wait is bounded — by default too — and ends the ranks still alive with status 124; one
+    that ignores SIGTERM is killed."""
+    import subprocess
+    import sys
+    import time
+    script = tmp_path / "h.py"
+    script.write_text("\n".join([
+        "import os, signal, sys, time",
+        "r = int(os.environ['RANK'])",
+        "if r == 1:",
+        "    signal.signal(signal.SIGTERM, signal.SIG_IGN)",
+        "    time.sleep(600)",
+        "print('rank', r, 'done')", ""]))
+    drv = ("import sys; sys.path.insert(0, %r); import importlib.util as u; "
+           "s = u.spec_from_file_location('d', %r); m = u.module_from_spec(s); s.loader.exec_module(m); "
+           "assert 0 < m.DEFAULT_LAUNCH_TIMEOUT < float('inf'); "
+           "sys.exit(m.launch_workers([%r], 2, timeout=float(sys.argv[1]) if len(sys.argv) > 1 else -1))") % (
+        ROOT, os.path.join(ROOT, "barcoder_amd", "dist.py"), str(script))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BC_LAUNCH_TIMEOUT")}
+    t0 = time.monotonic()
+    hung = subprocess.run([sys.executable, "-c", drv, "1.5"], capture_output=True, text=True, env=env, timeout=120)
+    assert hung.returncode == 124 and "rank 0 done" in hung.stdout and "still running" in hung.stderr
+    assert time.monotonic() - t0 < 60
+    # the default comes from BC_LAUNCH_TIMEOUT (24 h without it): finite either way
+    hung = subprocess.run([sys.executable, "-c", drv], capture_output=True, text=True, env=dict(env, BC_LAUNCH_TIMEOUT="1"), timeout=120)
+    assert hung.returncode == 124
 
 
 def test_native_flanks_on_worker_threads(tmp_path):

@@ -48,13 +48,12 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
                                  {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4", "BC_SINGLE_SLAB": "1"},
                                  {"BC_SLAB_LOG2S": "3,3,3,3"}, {"BC_SLAB_LOG2S": "5,5,5,5"}, {"BC_SLAB_LOG2S": "4,3,5,4"},
                                  {"BC_SINGLE_SLAB": "1"}, {"BC_LANE": "0"}, {"BC_LANE": "0", "BC_PHASE2_SM": "0"},
-                                 {"BC_T2_FILTER": "0"}, {"BC_CASCADE": "0"}, {"BC_CASCADE": "2"}, {"BC_FAST01": "1"}, {"BC_PREFETCH": "0"}, {"BC_PREFETCH": "1"},
+                                 {"BC_T2_FILTER": "0"}, {"BC_CASCADE": "0"}, {"BC_CASCADE": "2"}, {"BC_PREFETCH": "0"}, {"BC_PREFETCH": "1"},
                                  {"BC_HASH_SLOTS_PCT": "120"}, {"BC_HASH_SLOTS_PCT": "3000"},
                                  # the cascades' second stage from a list (large launches take it by default): written by the
-                                 # wave matcher's list form (also in its second table form), packed, passes over table groups;
+                                 # wave matcher's list form, packed, passes over table groups;
                                  # d = 2 as a cascade too (then d = 3 is a cascade over a cascade and gathers its own list)
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_GROUP_KB": "64"},
-                                 {"BC_PAIR_PASS_MIN_READS": "0", "BC_FAST01": "1"},
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_CHUNK_LOG2": "13"},  # (very long inputs: several launches)
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1"}, {"BC_CASCADE2_MIN_G": "1"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):

@@ -155,6 +155,60 @@ def test_undocumented_list_grows_under_concurrent_workers(gpu_device, tmp_path):
         np.testing.assert_array_equal(r.u_first[order], first_keys.astype(np.uint64))
 
 
+def test_failed_run_releases_its_streams_and_the_library_lives_on(gpu_device, tmp_path):
+    """A chunk that fails in the middle of a file (a line longer than the 1 MiB slack, in the third of four chunks, six
+    workers) ends the call with the long-line error — and every worker's stream workspace on the library is released on
+    the way out, whichever worker failed and whichever left because another one had (round 3 released it on the success
+    path only: the entries leaked, counted against the 1 024-stream cap, and a later stream reusing a handle value
+    inherited one).  Seventy failed runs later the library holds no workspace and counts a good file as before."""
+    import ctypes as C
+    from barcoder_amd import DeviceLibrary, _native as N, encoding as E, ingest as I, synth as S
+    k = 20
+    lib = S.library(2000, k)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    lib_s = E.unpack_kmers(lib, k)
+    rng = np.random.default_rng(5)
+    picks = rng.integers(0, lib.size, 60_000)
+    good = str(tmp_path / "good.reads")
+    with open(good, "w") as f:
+        f.write("".join("AC" + lib_s[i] + "GT\n" for i in picks))
+    want = np.bincount(picks, minlength=lib.size).astype(np.uint64)
+    # five chunks of 16 MiB; the over-long line starts just before the end of the third and runs past that chunk's
+    # 1 MiB of slack (a long line that ends inside the slack is an ordinary, if odd, line)
+    line = ("AC" + lib_s[0] + "GT\n").encode()
+    chunk = 16 << 20
+    n_before = (3 * chunk - 100) // len(line)
+    bad = str(tmp_path / "bad.reads")
+    with open(bad, "wb") as f:
+        f.write(line * n_before)
+        f.write(b"A" * ((1 << 20) + 4096) + b"\n")
+        f.write(line * (chunk // len(line) + 1000))
+    assert 4 * chunk < os.path.getsize(bad) < 5 * chunk
+    L = N.load()
+
+    def held():
+        n = C.c_uint32()
+        N.check(L.bc_lib_workspace_count(dl.handle, C.byref(n)))
+        return n.value
+
+    def run(path, threads):
+        c, f = np.zeros(lib.size, np.uint64), np.full(lib.size, np.iinfo(np.uint64).max, np.uint64)
+        r = I.stream_count_file(dl.handle, path, 0, os.path.getsize(path), 2, "", "", False, 1, "auto", 0, c, f, n_threads=threads)
+        return r, c
+
+    r, c = run(good, 3)
+    np.testing.assert_array_equal(c, want)
+    base = held()
+    for i in range(70):
+        with pytest.raises(ValueError, match="a line longer than"):
+            run(bad, 6 if i % 2 else 2)
+        assert held() == base, i
+    r, c = run(good, 6)
+    assert r.n_reads == picks.size and r.u_words.size == 0
+    np.testing.assert_array_equal(c, want)
+    assert held() == base
+
+
 def _make_pair_files(tmp_path, n, k, fastq, rng, lib_s, swapped):
     """Mates: read 1 carries L + barcode + R, read 2 the reverse complement of that stretch; with N reads, mates that
     disagree, short reads, odd characters (in one mate, or mirrored in both so that the pair still agrees), blank
