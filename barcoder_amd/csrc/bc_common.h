@@ -114,7 +114,13 @@ BC_HD static inline uint64_t synth_read(uint64_t seed, uint64_t i, uint64_t guid
         if (c < 58982u) return guide;
         return sm_draw(seed, i, 2) & kmask;
     }
-    if (c < 39322u) nsub = 0;
+    if (mixture >= 100) {
+        // read-mix sweep: mixture = 100 + J gives J % uniform-random reads (they match nothing, but for chance); the
+        // others carry 0 / 1 / 2 substitutions in the proportion 6 : 2 : 1 of the standard stream
+        const uint32_t T = (65536u * (uint32_t)(200 - mixture)) / 100u;
+        if (c >= T) return sm_draw(seed, i, 2) & kmask;
+        nsub = c < (T * 6u) / 9u ? 0 : c < (T * 8u) / 9u ? 1 : 2;
+    } else if (c < 39322u) nsub = 0;
     else if (c < 52429u) nsub = 1;
     else if (c < 58982u) nsub = 2;
     else if (c < 62259u) nsub = 3;

@@ -84,9 +84,29 @@ constexpr uint32_t NBR_OVER = 0xFFFFFFFEu;  // more than NBR_CAP of them: take t
 // 128-bit sets — the (hashed) values the bucket's guides show in the halves 0a, 0b, 1a, 1b; a read whose own values
 // miss (0a and 0b) or (1a and 1b) has no candidate in the bucket and need not fetch its slabs at all.
 BC_HD static inline uint32_t flt_hash7(uint32_t v) { return (v * 0x9E3779B1u) >> 25; }
+// Second form of tables 0 and 1, read by k_match_wq alone (8-byte entries of k-mers whose rest leaves three spare bits per
+// plane, 64-byte slabs): EIGHT entries per slab and no link slot.  The low byte of an entry's index word is spare
+// (giw8 = giw << 8 | byte; the key comes out of v_alignbyte_b32(distance, giw8, 1) — the same one instruction as
+// distance << 24 | giw); slots 6 and 7 keep the two bytes of link16 = 1 + (number of the bucket's next slab - buckets),
+// 0 = none; overflow slabs have the same form.  An empty slot's rest has the three spare bits of both planes set: at
+// least three "mismatches" against any read, so it never comes within a budget of two.  A size-biased 27 % of the
+// bucket visits continue into an overflow slab instead of 41 % with seven entries + link, and there are fewer overflow
+// slabs to keep in the L2 (round 2's FAST01 experiment got the eighth entry by putting the bucket's next entries at an
+// implied address in a sparse second region: requests 1.79 -> 1.72 per read, but the region cost L2 capacity and time
+// did not move; here the form needs no extra footprint).  The exact path and the quad kernels keep reading t[].
+struct EightTables {
+    const char* base[2];   // [buckets primaries | overflow slabs | one all-empty slab]
+    uint32_t nb[2];        // buckets = number of the first overflow slab
+    uint32_t empty[2];     // number of the all-empty slab
+    uint32_t ok;           // both tables built
+};
+constexpr uint32_t E8_EMPTY_REST = 0xE000E000u;
+// ... and its index word: class 0 (a key at distance >= 3 with class 0 is neither in range nor "settled"), index all ones
+constexpr uint32_t E8_EMPTY_GIW8 = SLAB_GIDX_MASK << 8;
 struct SlabParams {
     int nseg;
     SlabTable t[MAX_SEG];
+    EightTables e8;
     const uint32_t* nbr_slot;  // [G] list number, NBR_NONE or NBR_OVER (NULL = no lists)
     const uint4* nbr;          // [lists][NBR_CAP]
     const uint32_t* flt;       // [table-2 buckets][16] filter lines, NULL = none
@@ -131,6 +151,7 @@ struct Knobs {
     int pair_grid = 16384;     // BC_PAIR_GRID: workgroups of a second-stage pass at most (2 048 = 8 per CU fill the chip; more balance the tail: 226 -> 210 us)
     int pair_chunk_log2 = 27;  // BC_PAIR_CHUNK_LOG2: reads per launch of a cascade in its list form (workspace: 32 bytes per read)
     int pair_pass_min = 65536; // BC_PAIR_PASS_MIN_READS: launches below that take the one-kernel form (tests: 0)
+    int e8 = 1;           // BC_E8=0: k_match_wq on the classic tables 0/1 (seven entries + link) instead of the eight-entry form
     int cascade = 1;      // BC_CASCADE=0: d = 3 by the four-segment index over every read (round 1's path); 2: the pair
                           // index over every read (no d <= 2 pass first); 1: cascade
 };

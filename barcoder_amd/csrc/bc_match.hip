@@ -311,6 +311,25 @@ __device__ __forceinline__ uint32_t piece_min(const uint4& w, uint32_t rl, uint3
 }
 template <bool WIDE>
 __device__ __forceinline__ uint32_t link_word(const uint4& last_piece) { return WIDE ? last_piece.x : last_piece.z; }
+// the eight-entry form of tables 0/1 (EightTables): the index word keeps a spare low byte, the key comes out of one
+// v_alignbyte_b32; link16 (slots 6 and 7: the last piece of the slab) = 1 + overflow slab number - buckets, 0 = none
+__device__ __forceinline__ uint32_t key8(uint32_t dist, uint32_t giw8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(dist, giw8, 1u);
+#else
+    return (dist << 24) | (giw8 >> 8);
+#endif
+}
+__device__ __forceinline__ uint32_t piece_min8(const uint4& w, uint32_t rl) {
+    return min(key8(planes_dist(rl ^ w.x), w.y), key8(planes_dist(rl ^ w.z), w.w));
+}
+__device__ __forceinline__ uint32_t link16_of(const uint4& last_piece) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(last_piece.w, last_piece.y, 0x0C0C0400u);  // byte 0 of slot 6's index word | byte 0 of slot 7's << 8
+#else
+    return (last_piece.y & 0xFFu) | ((last_piece.w & 0xFFu) << 8);
+#endif
+}
 
 // Quad-cooperative visit: the four lanes of a quad own one read each; load j (0..3) brings the slab wanted by the read
 // of the quad's lane j, lane s taking piece s (+ 4h for longer slabs) — the quad's four 16-byte accesses of one
@@ -365,7 +384,7 @@ __device__ __forceinline__ uint32_t quad_tmin(const uint32_t (&a)[4], int s) {
 
 // scan them: kmin = min(kmin, best key of the read this lane owns); link = first word of the last slot of the lane's
 // own slab (0 = none: the slot is link-or-empty).  tr: TR_WORDS dwords of LDS private to the wave, 16-byte aligned
-template <int NQ, bool WIDE = false>
+template <int NQ, bool WIDE = false, bool E8 = false>
 __device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], RestW rest, uint32_t lane, uint32_t* tr,
                                            uint32_t& kmin, uint32_t& link) {
     const int s = (int)(lane & 3u);
@@ -375,9 +394,9 @@ __device__ __forceinline__ void visit_scan(const uint4 (&w)[4][NQ], RestW rest, 
         const uint32_t rl = quad_bcast<j>(rest.lo), rh = WIDE ? quad_bcast<j>(rest.hi) : 0u;
         uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-        for (int h = 0; h < NQ; ++h) m = min(m, piece_min<WIDE>(w[j][h], rl, rh));
+        for (int h = 0; h < NQ; ++h) m = min(m, E8 ? piece_min8(w[j][h], rl) : piece_min<WIDE>(w[j][h], rl, rh));
         a[j] = m;
-        l[j] = link_word<WIDE>(w[j][NQ - 1]);
+        l[j] = E8 ? link16_of(w[j][NQ - 1]) : link_word<WIDE>(w[j][NQ - 1]);
     };
     one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
     one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
@@ -515,7 +534,7 @@ constexpr int WL_CAP = 384;  // work items a wave can hold; a step that may add 
 // LIST: the first stage of a cascade — the reads left without a hit also go on the second stage's list (MatchOut::miss_*).
 // Its own instantiation: the default kernel carries none of it (the list entry kept for a miss, the ballots at the end:
 // +0.03 ms per 1e8 reads when they sat in the one kernel).
-template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01, bool LIST = false>
+template <int NSEG, int NQ2, bool PROF, bool WIDE, int NQ01, bool LIST = false, bool E8 = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_wq(const SlabParams* __restrict__ spp,
                                                    const uint64_t* __restrict__ reads,
                                                    const uint8_t* __restrict__ flags, uint64_t n, int k,
@@ -526,6 +545,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     static_assert(NQ01 == 1 || NQ01 == 2, "table 0/1 slabs are 64 or 128 bytes");
     static_assert(!WIDE || NQ01 == 2, "wide entries: 8-entry slabs of 128 bytes");
     static_assert(!LIST || (!WIDE && NQ01 == 1), "the list form is instantiated for 64-byte slabs of 8-byte entries");
+    // E8: tables 0/1 in their eight-entry form (EightTables): links are 16-bit numbers relative to the table's first
+    // overflow slab (lnk_abs makes a slab number of one), list entries and items keep slab numbers
+    static_assert(!E8 || (!WIDE && NQ01 == 1), "the eight-entry form exists for 64-byte slabs of 8-byte entries");
     constexpr uint32_t S01 = NQ01 == 2 ? 7u : 6u;     // log2 of that slab's bytes
     (void)o_arg;  // read from the kernel-argument segment in the last phase, see there
     // The list of the tile's unsettled reads: one 16-byte entry per listed read — {read lo, read hi, best key so far
@@ -559,12 +581,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     const SlabTable& T0 = sp.t[0];
     const SlabTable& T1 = sp.t[1];
     const SlabTable& T2 = sp.t[NSEG - 1];
-    const char* const b0 = reinterpret_cast<const char*>(T0.slabs);
-    const char* const b1 = reinterpret_cast<const char*>(T1.slabs);
+    const char* const b0 = E8 ? sp.e8.base[0] : reinterpret_cast<const char*>(T0.slabs);
+    const char* const b1 = E8 ? sp.e8.base[1] : reinterpret_cast<const char*>(T1.slabs);
+    const uint32_t nbm1_0 = E8 ? sp.e8.nb[0] - 1u : 0u, nbm1_1 = E8 ? sp.e8.nb[1] - 1u : 0u;  // slab = link16 + buckets - 1
     const char* const b2 = reinterpret_cast<const char*>(T2.slabs);
     const uint32_t lane = threadIdx.x;
     const uint32_t half0 = T0.half, half1 = T1.half, half2 = T2.half, sh2 = T2.log2S + (WIDE ? 4u : 3u);
-    const uint32_t empty0 = T0.empty << S01, empty1 = T1.empty << S01, empty2 = T2.empty << sh2;  // what idle lanes fetch
+    const uint32_t empty0 = (E8 ? sp.e8.empty[0] : T0.empty) << S01, empty1 = (E8 ? sp.e8.empty[1] : T1.empty) << S01,
+                   empty2 = T2.empty << sh2;  // what idle lanes fetch
     const int s = (int)(lane & 3u);
     const uint32_t s16 = (lane & 3u) * 16u;
     unsigned long long t_prev = PROF ? (unsigned long long)clock64() : 0ull, t_acc[4] = {0ull, 0ull, 0ull, 0ull};
@@ -616,16 +640,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const uint32_t st = t1 ? T1.start : 0u, sh = t1 ? T1.start + T1.slen : T0.slen;  // (table 0's seed starts at base 0)
             const RestW rest = rest_of<WIDE>(st, sh, t1 ? half1 : half0, rlo, rhi);
             const char* base = t1 ? b1 : b0;
-            const uint32_t off = act ? (slab << S01) : empty0;
+            const uint32_t off = act ? (slab << S01) : (t1 ? empty1 : empty0);
             uint4 w[NQ01];
 #pragma unroll
             for (int h = 0; h < NQ01; ++h) w[h] = load16(base, off + (uint32_t)(s + 4 * h) * 16u);
             uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-            for (int h = 0; h < NQ01; ++h) m = min(m, piece_min<WIDE>(w[h], rest.lo, rest.hi));
+            for (int h = 0; h < NQ01; ++h) m = min(m, E8 ? piece_min8(w[h], rest.lo) : piece_min<WIDE>(w[h], rest.lo, rest.hi));
             m = min(m, quad_perm<0xB1>(m));
             m = min(m, quad_perm<0x4E>(m));
-            const uint32_t lnk = quad_bcast<3>(link_word<WIDE>(w[NQ01 - 1]));  // the slab's last slot: link or empty (0)
+            uint32_t lnk = quad_bcast<3>(E8 ? link16_of(w[NQ01 - 1]) : link_word<WIDE>(w[NQ01 - 1]));  // the slab's last slot(s): link or none (0)
+            if (E8) lnk = lnk ? lnk + (t1 ? nbm1_1 : nbm1_0) : 0u;
             const bool lead = act && s == 0;
             uint32_t now = 0xFFFFFFFFu;
             if (lead) now = min(m, atomicMin(&e_key(qi), m));
@@ -736,7 +761,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         auto off0 = [&](int j) { return ok[j] ? (seed_value((uint32_t)r[j], (uint32_t)(r[j] >> 32), 0, T0.slen) << S01) : 0u; };
         auto finish = [&](int j, const uint4 (&w)[4][NQ01]) {
             uint32_t lnk, key = 0xFFFFFFFFu;
-            visit_scan<NQ01, WIDE>(w, rest_of<WIDE>(0u, T0.slen, half0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), lane, wl, key, lnk);
+            visit_scan<NQ01, WIDE, E8>(w, rest_of<WIDE>(0u, T0.slen, half0, (uint32_t)r[j], (uint32_t)(r[j] >> 32)), lane, wl, key, lnk);
             const bool fin = ok[j] && key_unique(key);
             idx[j] = !ok[j] ? BC_IDX_SKIP : fin ? (int32_t)(key & SLAB_GIDX_MASK) : BC_IDX_MISS;
             dist4 |= (fin ? (key >> 24) : 0u) << (8 * j);
@@ -791,14 +816,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         uint4 wa[4][NQ01];
         uint32_t lnk;
         visit_issue<NQ01>(b1, off1, s16, wa);
-        visit_scan<NQ01, WIDE>(wa, rest1, lane, wl, kmin, lnk);
+        visit_scan<NQ01, WIDE, E8>(wa, rest1, lane, wl, kmin, lnk);
         // (the item stack shares its words with the transposition rows: the visit above is complete — it ends on its
         // own LDS wait — before the first push below)
         // a read that table 1's primary slab settles (a third of the listed ones) needs neither overflow slab
         const bool more = mine && !settled(kmin);
         if (mine) e_key(qi) = kmin;
-        push_items(more && lnk0 != 0u, qi | (lnk0 << 10));
-        push_items(more && lnk != 0u, qi | 0x100u | (lnk << 10));
+        // (E8: the links are 16-bit numbers relative to the table's first overflow slab — the entry kept table 0's as it
+        // came: three quarters of the listed reads never turn it into a slab number)
+        push_items(more && lnk0 != 0u, qi | ((lnk0 + nbm1_0) << 10));
+        push_items(more && lnk != 0u, qi | 0x100u | ((lnk + nbm1_1) << 10));
         for (uint32_t qb = 64; qb < qn; qb += 64) {
             if (wn > WL_CAP - 128) drain01();
             const uint32_t qj = qb + lane;
@@ -810,7 +837,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
                 lj = e.w;
             }
             push_items(mj, qj | 0x100u | (sv << 10));
-            push_items(mj && lj != 0u, qj | (lj << 10));
+            push_items(mj && lj != 0u, qj | ((lj + nbm1_0) << 10));
         }
     }
     if (!(diag & 2u)) drain01();
@@ -1434,6 +1461,51 @@ int build_slab_table(bc_lib* lib, int d, int s, const std::vector<uint32_t>& off
     T.log2S = (uint32_t)log2S;
     for (int t = 0; t < MAX_SEG; ++t)  // earlier seeds lie below this one: same bit positions in `rest`
         T.dmask[t] = (t < s) ? (((1u << cs.slen[t]) - 1u) << cs.start[t]) : 0u;
+    // tables 0 and 1 once more in the eight-entry form for k_match_wq (EightTables, bc_device.h): narrow entries,
+    // 64-byte slabs, three spare bits per plane of the rest (the empty slot's sentinel), a budget of at most two
+    if (s == 0) sl.e8 = EightTables{};
+    if (s < 2 && !wide && log2S == 3 && (cs.nseg == 2 || cs.nseg == 3) && lib->k - slen <= 13 && d <= 2 && lib->knobs.e8 &&
+        !lib->h_nn.empty()) {
+        std::vector<uint2> e8((size_t)nb * 8, make_uint2(E8_EMPTY_REST, E8_EMPTY_GIW8));
+        uint64_t n_ovf = 0;
+        auto set_link = [&](size_t slab, uint32_t link16) {
+            e8[slab * 8 + 6].y = (e8[slab * 8 + 6].y & 0xFFFFFF00u) | (link16 & 0xFFu);
+            e8[slab * 8 + 7].y = (e8[slab * 8 + 7].y & 0xFFFFFF00u) | (link16 >> 8);
+        };
+        for (uint32_t b = 0; b < nb; ++b) {
+            size_t cur = b;
+            uint32_t pos = 0;
+            for (uint32_t j = off[b]; j < off[b + 1]; ++j) {
+                if (pos == 8) {  // chain an overflow slab
+                    const size_t nxt = e8.size() / 8;
+                    e8.resize(e8.size() + 8, make_uint2(E8_EMPTY_REST, E8_EMPTY_GIW8));
+                    ++n_ovf;
+                    set_link(cur, (uint32_t)(nxt - nb + 1));
+                    cur = nxt;
+                    pos = 0;
+                }
+                const int nn = lib->h_nn[gidx[j]];
+                uint32_t c = 0;
+                for (int e = 1; e <= d; ++e) c += nn > 2 * e ? 1u : 0u;
+                const uint32_t lo = (uint32_t)keys[j], hi = (uint32_t)(keys[j] >> 32);
+                const uint32_t lo_r = (lo & below) | ((sh >= 32 ? 0u : (lo >> sh)) << start);
+                const uint32_t hi_r = (hi & below) | ((sh >= 32 ? 0u : (hi >> sh)) << start);
+                uint2& slot = e8[cur * 8 + pos++];
+                slot.x = lo_r | (hi_r << 16);
+                slot.y = ((gidx[j] | (c << SLAB_CLASS_SHIFT)) << 8) | (slot.y & 0xFFu);
+            }
+        }
+        const size_t empty8 = e8.size() / 8;
+        e8.resize(e8.size() + 8, make_uint2(E8_EMPTY_REST, E8_EMPTY_GIW8));
+        if (n_ovf + 1 < 65535 && empty8 < (1u << 22) && ((e8.size() * sizeof(uint2)) >> 32) == 0) {
+            uint2* d_e8;
+            if ((rc = dev_upload(lib, e8, &d_e8)) != BC_OK) return rc;
+            sl.e8.base[s] = reinterpret_cast<const char*>(d_e8);
+            sl.e8.nb[s] = nb;
+            sl.e8.empty[s] = (uint32_t)empty8;
+            if (s == 1 && sl.e8.base[0]) sl.e8.ok = 1u;
+        }
+    }
     if (s == cs.nseg - 1) {  // descriptor block for the kernel (read through scalar loads)
         sl.nbr_slot = lib->h_nn.empty() ? nullptr : lib->d_nbr_slot;
         sl.nbr = lib->h_nn.empty() ? nullptr : lib->d_nbr;
@@ -2017,13 +2089,16 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
-#define BC_WAVE_LIST(NSEG_, NQ2_)                                                                                    \
-    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
+#define BC_WAVE_LIST(NSEG_, NQ2_, E8_)                                                                               \
+    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true, E8_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
+                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
+#define BC_WAVE_E8(NSEG_, NQ2_)                                                                                      \
+    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, false, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
 #ifdef BC_DIAG_BUILD
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (listing) BC_WAVE_LIST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (prof) BC_WAVE_LAUNCH(NSEG_, NQ2_, true, false, 1); else if (listing && hp.e8.ok) BC_WAVE_LIST(NSEG_, NQ2_, true); else if (listing) BC_WAVE_LIST(NSEG_, NQ2_, false); else if (hp.e8.ok) BC_WAVE_E8(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
 #else
-#define BC_WAVE_P(NSEG_, NQ2_) do { if (listing) BC_WAVE_LIST(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
+#define BC_WAVE_P(NSEG_, NQ2_) do { if (listing && hp.e8.ok) BC_WAVE_LIST(NSEG_, NQ2_, true); else if (listing) BC_WAVE_LIST(NSEG_, NQ2_, false); else if (hp.e8.ok) BC_WAVE_E8(NSEG_, NQ2_); else BC_WAVE_LAUNCH(NSEG_, NQ2_, false, false, 1); } while (0)
 #endif
                     if (!wide && nq01 == 1) {
                         if (nseg == 2) BC_WAVE_P(2, 1);
@@ -2041,6 +2116,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     }
 #undef BC_WAVE_P
 #undef BC_WAVE_LIST
+#undef BC_WAVE_E8
 #undef BC_WAVE_LAUNCH
                     note_kernel(lib, "k_match_wq");
                     BC_HIP(hipGetLastError());
@@ -2318,6 +2394,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.tally = env_int("BC_TALLY", 0);
     lib->knobs.host_pin = env_int("BC_HOST_PIN", 1);
     lib->knobs.cascade = env_int("BC_CASCADE", 1);
+    lib->knobs.e8 = env_int("BC_E8", 1);
     lib->knobs.pair_group_kb = env_int("BC_PAIR_GROUP_KB", 3300);
     lib->knobs.pair_pass_min = env_int("BC_PAIR_PASS_MIN_READS", 65536);
     lib->knobs.cascade2_min_g = env_int("BC_CASCADE2_MIN_G", 0);
@@ -2737,7 +2814,7 @@ int bc_multi_gpu_match(bc_multi* m, const uint64_t* h_reads, const uint8_t* h_fl
 
 int bc_synth_reads_dev(bc_lib* lib, uint64_t seed, uint64_t first_index, uint64_t n, int mixture,
                        uint64_t* d_reads, void* stream) {
-    if (!lib || (n && !d_reads) || mixture < 0 || mixture > 1) { set_error("bc_synth_reads_dev: bad argument"); return BC_EINVAL; }
+    if (!lib || (n && !d_reads) || mixture < 0 || (mixture > 1 && (mixture < 100 || mixture > 200))) { set_error("bc_synth_reads_dev: bad argument"); return BC_EINVAL; }
     if (n == 0) return BC_OK;
     BC_HIP(hipSetDevice(lib->device));
     hipLaunchKernelGGL(k_synth_reads, dim3(grid_for(n)), dim3(BLOCK), 0, (hipStream_t)stream, lib->d_guides,

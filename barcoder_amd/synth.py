@@ -49,7 +49,8 @@ def guide_index(seed: int, i, G: int):
 def reads(lib: np.ndarray, k: int, seed: int, first: int, n: int, mixture: int) -> np.ndarray:
     """n packed reads starting at global index `first`.
     mixture 0: 90 % library reads, 10 % random; mixture 1: 60/20/10/5 % with
-    0/1/2/3 substitutions at distinct positions, 5 % random."""
+    0/1/2/3 substitutions at distinct positions, 5 % random; mixture 100 + J (read-mix
+    sweep): J % random reads, the others with 0/1/2 substitutions in the proportion 6:2:1."""
     i = np.arange(first, first + n, dtype=np.uint64)
     G = lib.size
     g = lib[guide_index(seed, i, G).astype(np.int64)]
@@ -57,7 +58,11 @@ def reads(lib: np.ndarray, k: int, seed: int, first: int, n: int, mixture: int) 
     rnd = draw(seed, i, 2) & _kmask(k)
     if mixture == 0:
         return np.where(c < 58982, g, rnd)
-    nsub = np.select([c < 39322, c < 52429, c < 58982, c < 62259], [0, 1, 2, 3], default=-1)
+    if mixture >= 100:
+        T = (65536 * (200 - mixture)) // 100
+        nsub = np.select([c < (T * 6) // 9, c < (T * 8) // 9, c < T], [0, 1, 2], default=-1)
+    else:
+        nsub = np.select([c < 39322, c < 52429, c < 58982, c < 62259], [0, 1, 2, 3], default=-1)
     u3 = draw(seed, i, 3)
     u4 = draw(seed, i, 4)
     r = g.copy()

@@ -57,7 +57,7 @@ def ascii_from_packed(packed, k):
     return out
 
 
-def cpu_baseline(lib_packed, n_sample, seed, max_mm):
+def cpu_baseline(lib_packed, n_sample, seed, max_mm, mixture=1):
     """The CPU port of the same job on the first reads of the same stream: oracle.c's pigeonhole-indexed best-hit
     search (strings, OpenMP, all host cores), sized from a probe to ~10 s of CPU work; the brute-force sweep the
     oracle is defined by runs on a prefix (~5 s) and must agree with it."""
@@ -65,7 +65,7 @@ def cpu_baseline(lib_packed, n_sample, seed, max_mm):
     from barcoder_amd import synth as S
     from oracle import oracle as orc
     la = ascii_from_packed(lib_packed, K)
-    probe = ascii_from_packed(S.reads(lib_packed, K, seed, 0, 200_000, 1), K)
+    probe = ascii_from_packed(S.reads(lib_packed, K, seed, 0, 200_000, mixture), K)
     t0 = time.perf_counter()
     orc.best_hit_arrays(la, probe, max_mm, indexed=True)
     rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
@@ -74,7 +74,7 @@ def cpu_baseline(lib_packed, n_sample, seed, max_mm):
     brate = 2000 / max(time.perf_counter() - t0, 1e-6)
     if n_sample <= 0:
         n_sample = int(min(40_000_000, max(200_000, rate * 10)))
-    reads = S.reads(lib_packed, K, seed, 0, n_sample, 1)
+    reads = S.reads(lib_packed, K, seed, 0, n_sample, mixture)
     ra = ascii_from_packed(reads, K)
     t0 = time.perf_counter()
     ref = orc.best_hit_arrays(la, ra, max_mm, indexed=True)
@@ -292,7 +292,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = ~15 s worth)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads after the timed region")
-    ap.add_argument("--mixture", type=int, default=1, help="synthetic stream: 1 = SURVEY cfg3 mismatch mix (default), 0 = cfg2 exact mix")
+    ap.add_argument("--mixture", type=int, default=1, help="synthetic stream: 1 = SURVEY cfg3 mismatch mix (default), 0 = cfg2 exact mix, 100 + J = read-mix sweep: J %% random "
+                         "(unmatched) reads, the others with 0/1/2 substitutions 6:2:1")
     args = ap.parse_args()
 
     if args.reads is None:
@@ -482,7 +483,7 @@ def run(args):
             except Exception as e:  # noqa: BLE001
                 out["roofline"]["traffic_source"] = f"none (profiles/traffic.json unreadable: {e})"
         if world == 1 and not args.no_cpu:
-            ref, sample_reads, cb = cpu_baseline(lib_packed, args.cpu_sample, seed, args.max_mismatch)
+            ref, sample_reads, cb = cpu_baseline(lib_packed, args.cpu_sample, seed, args.max_mismatch, args.mixture)
             m_ = len(sample_reads)
             cb["parity_on_sample"] = bool(np.array_equal(best_idx[:m_].cpu().numpy(), ref["best_idx"]) and
                                           np.array_equal(best_dist[:m_].cpu().numpy(), ref["best_dist"]) and

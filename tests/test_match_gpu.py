@@ -48,7 +48,8 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
                                  {"BC_SLAB_LPR": "8", "BC_SLAB_MIN_LOG2S": "4", "BC_SINGLE_SLAB": "1"},
                                  {"BC_SLAB_LOG2S": "3,3,3,3"}, {"BC_SLAB_LOG2S": "5,5,5,5"}, {"BC_SLAB_LOG2S": "4,3,5,4"},
                                  {"BC_SINGLE_SLAB": "1"}, {"BC_LANE": "0"}, {"BC_LANE": "0", "BC_PHASE2_SM": "0"},
-                                 {"BC_T2_FILTER": "0"}, {"BC_CASCADE": "0"}, {"BC_CASCADE": "2"}, {"BC_PREFETCH": "0"}, {"BC_PREFETCH": "1"},
+                                 {"BC_T2_FILTER": "0"}, {"BC_CASCADE": "0"}, {"BC_CASCADE": "2"}, {"BC_PREFETCH": "0"}, {"BC_PREFETCH": "1"}, {"BC_E8": "0"},
+                                 {"BC_PAIR_PASS_MIN_READS": "0", "BC_E8": "0"},
                                  {"BC_HASH_SLOTS_PCT": "120"}, {"BC_HASH_SLOTS_PCT": "3000"},
                                  # the cascades' second stage from a list (large launches take it by default): written by the
                                  # wave matcher's list form, packed, passes over table groups;
@@ -345,7 +346,7 @@ def test_synth_device_matches_numpy(gpu_device):
     d = N.vp()
     N.check(L.bc_dev_alloc(C.byref(d), n * 8))
     try:
-        for mix in (0, 1):
+        for mix in (0, 1, 105, 150):  # 100 + J: the read-mix sweep's streams (J % unmatched reads)
             GpuMatcher(dl).synth_reads_dev(seed=2 + mix, first=1000, n=n, mixture=mix, d_reads=d)
             out = np.empty(n, np.uint64)
             N.check(L.bc_dev_d2h(N.ptr(out), d, n * 8, None))
@@ -483,6 +484,53 @@ def test_bucket_size_boundaries(gpu_device, oracle, which):
     nsub = rng.choice([0, 1, 2, 3], size=n, p=[0.3, 0.3, 0.3, 0.1])
     rd = _mutate(rng, codes[rng.integers(0, G, size=n)], nsub)
     rd[rng.random(n) < 0.05] = rng.integers(0, 4, size=k)
+    reads_s = ["".join(letters[r]) for r in rd]
+    lib, _ = E.pack_kmers(lib_s, k)
+    reads, _ = E.pack_kmers(reads_s, k)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    for d in (1, 2, 3):
+        _check(GpuMatcher(dl).match(reads, None, max_mismatch=d, algo="seed", first_index=0), oracle.best_hit(lib_s, reads_s, d))
+        assert dl.last_kernel == ("k_match_wq" if d < 3 else "cascade3:d2+k_match_pairs"), dl.last_kernel
+
+
+@pytest.mark.parametrize("e8", ["1", "0"])
+def test_empty_slots_of_the_eight_entry_slabs(gpu_device, oracle, e8, monkeypatch):
+    """Tables 0/1 of the wave matcher in their eight-entry form mark an empty slot by a rest with the three spare bits of
+    both planes set (at least three mismatches against any read) and class 0.  Reads whose rest is a run of A / C / G / T
+    (planes all zeros / all ones: the nearest a read's rest gets to the sentinel), behind seeds that lead to partly
+    empty, exactly full (8) and chained (9, 17) buckets and to buckets that do not exist, with 0 ... 3 substitutions —
+    against the oracle, with the form on and off (BC_E8=0: seven entries + link)."""
+    monkeypatch.setenv("BC_E8", e8)
+    k = 20
+    rng = np.random.default_rng(23)
+    letters = np.array(list("ACGT"))
+    rows = []
+    for size in (1, 2, 7, 8, 9, 16, 17):
+        for base in range(4):
+            shared = rng.integers(0, 4, size=7)
+            grp = rng.integers(0, 4, size=(size, k))
+            grp[:, :7] = shared
+            grp[0, 7:] = base          # the bucket's first guide ends in a run of one base
+            rows.append(grp)
+    codes = np.unique(np.concatenate(rows + [rng.integers(0, 4, size=(3000, k))]), axis=0)
+    codes = codes[rng.permutation(codes.shape[0])]
+    lib_s = ["".join(letters[r]) for r in codes]
+    rd = []
+    for grp in rows:
+        for base in range(4):
+            r = grp[0].copy()
+            r[7:] = base               # the bucket's seed + a run of `base`
+            rd.append(r)
+            for nsub in (1, 2, 3):
+                rd.append(_mutate(rng, r[None, :], np.array([nsub]))[0])
+    for base in range(4):              # runs of one base over the whole read: mostly buckets that hold nothing like them
+        rd.append(np.full(k, base))
+        for _ in range(40):
+            r = np.full(k, base)
+            r[:7] = rng.integers(0, 4, size=7)
+            rd.append(r)
+    rd = np.array(rd)
+    rd = np.concatenate([rd, _mutate(rng, codes[rng.integers(0, codes.shape[0], size=5000)], rng.integers(0, 4, size=5000))])
     reads_s = ["".join(letters[r]) for r in rd]
     lib, _ = E.pack_kmers(lib_s, k)
     reads, _ = E.pack_kmers(reads_s, k)
