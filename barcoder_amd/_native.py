@@ -87,6 +87,8 @@ SIGNATURES = {
     "bc_lib_last_kernel": (C.c_char_p, [vp]),
     "bc_lib_release_stream": (C.c_int, [vp, vp]),
     "bc_lib_workspace_count": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
+    "bc_pcie_probe": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double)]),
     "bc_lib_attach_text": (C.c_int, [vp, vp, C.c_int]),
     "bc_stream_result_text_info": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "bc_stream_result_undoc_text": (C.c_int, [vp, vp, vp, vp]),

@@ -2173,7 +2173,7 @@ namespace bc {
 int cascade_workspace(bc_lib* lib, hipStream_t st, uint64_t n, TallyWs** out) { return cascade_workspace_impl(lib, st, n, out); }
 }  // namespace bc
 
-constexpr int HOST_WORKERS = 6;  // worker threads (and staging slots) of bc_match_host
+constexpr int HOST_WORKERS = 8;  // worker threads of bc_match_host (two buffer sets each)
 struct HostSlot {
     uint64_t cap = 0;
     uint64_t* d_r = nullptr;
@@ -2242,28 +2242,44 @@ struct Events {
     }
 };
 
+// is this host pointer page-locked memory the runtime knows (hipHostMalloc / hipHostRegister)?  Then DMA can use it as
+// it is; pageable memory goes through the worker's page-locked staging buffers
+static bool host_pinned(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
 // Host buffers in, per-read results out to the host; counts / first-seen are left ON THE DEVICE (d_c: uint32[G],
-// d_fs: uint64[G], accumulated over the chunks).  The call is cut into chunks that worker threads take in turn, each
-// with its own HIP stream, device slot and PAGE-LOCKED staging buffers (kept in the library object between calls):
-// a worker copies its chunk of the caller's (pageable) reads into the staging buffer, uploads, launches, downloads
-// into staging and copies the results out to the caller — so several cores do the host-side copies that the runtime
-// would otherwise do on one, and every DMA runs at the link's rate; while one worker copies, another's transfer and
-// a third one's kernels run (PCIe is full duplex).  Round 2 registered the caller's buffers (hipHostRegister) for the
-// duration of a large call instead: 0.68 G reads/s, most of it the page pinning.  BC_HOST_PIN=0: no staging, plain
-// copies from the caller's memory.  The caller holds lib->host_mutex.
+// d_fs: uint64[G], accumulated over the chunks).  The call is cut into chunks of 1M reads that worker threads take in
+// turn.  Each worker owns TWO buffer sets (device buffers, page-locked staging, a stream each) and keeps one chunk in
+// flight on the link / the device while it copies the results of the chunk before it out and the reads of the chunk
+// after it in — round 3 had one set per worker: copy in, upload, kernels, download, wait, copy out, one after the
+// other, and only the other workers to fill the link meanwhile (0.54 G reads/s = 7.6 GB/s over a link that carries
+// several times that).  Staging is per buffer and only for PAGEABLE memory: a caller buffer that is page-locked
+// (bc_host_alloc_pinned, hipHostRegister; barcoder_amd.GpuMatcher hands out its result arrays that way) is the DMA's
+// source / target as it is.  h_best_idx == NULL is the counts-only mode (what heuristicount's semantics need,
+// heuristicount.py:535-538): 8 bytes per read cross the link once, nothing per read comes back.
+// BC_HOST_PIN=0: no staging at all, plain copies from the caller's memory.  The caller holds lib->host_mutex.
 int match_host_chunks(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, uint64_t n, int max_mismatch,
                       int algo, int32_t* h_best_idx, uint8_t* h_best_dist, uint8_t* h_n_best, uint32_t* d_c,
                       uint64_t* d_fs, uint64_t first_index_base) {
-    const bool stage = lib->knobs.host_pin != 0 && n >= (1ull << 18);
-    // staged: 1M reads per chunk (8 MB up, 6 MB down: 14 MB of page-locked memory per worker); direct: 8M
-    const uint64_t CH = stage ? (1ull << 20) : (1ull << 23);
+    const bool staging = lib->knobs.host_pin != 0 && n >= (1ull << 18);
+    // which of the caller's buffers need the page-locked detour
+    const bool st_r = staging && !host_pinned(h_reads), st_f = staging && h_flags && !host_pinned(h_flags);
+    const bool st_bi = staging && h_best_idx && !host_pinned(h_best_idx), st_bd = staging && h_best_dist && !host_pinned(h_best_dist);
+    const bool st_nb = staging && h_n_best && !host_pinned(h_n_best);
+    const bool any_stage = st_r || st_f || st_bi || st_bd || st_nb;
+    // 1M reads per chunk (8 MB up, 6 MB down: 14 MB of page-locked memory per buffer set); without staging: 8M
+    const uint64_t CH = staging ? (1ull << 20) : (1ull << 23);
     const uint64_t n_chunks = (n + CH - 1) / CH;
-    const int workers = (int)std::min<uint64_t>(stage ? HOST_WORKERS : 3, n_chunks);
-    if (!lib->host_slots) lib->host_slots = new HostSlot[HOST_WORKERS];
+    const int workers = (int)std::min<uint64_t>(staging ? HOST_WORKERS : 3, (n_chunks + 1) / 2);
+    if (!lib->host_slots) lib->host_slots = new HostSlot[2 * HOST_WORKERS];
     HostSlot* slots = (HostSlot*)lib->host_slots;
-    for (int w = 0; w < workers; ++w) {
+    for (int w = 0; w < 2 * workers; ++w) {
         int rc = slot_reserve(slots[w], std::min(n, CH));
-        if (rc == BC_OK && stage) rc = slot_reserve_pinned(slots[w], std::min(n, CH));
+        if (rc == BC_OK && any_stage) rc = slot_reserve_pinned(slots[w], std::min(n, CH));
         if (rc != BC_OK) return rc;
     }
     BC_HIP(hipDeviceSynchronize());
@@ -2272,7 +2288,6 @@ int match_host_chunks(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_fla
     std::string err;
     std::mutex err_mutex;
     auto work = [&](int w) {
-        HostSlot& s = slots[w];
         auto fail = [&](int rc) {
             int expect = BC_OK;
             if (first_rc.compare_exchange_strong(expect, rc)) {
@@ -2281,37 +2296,50 @@ int match_host_chunks(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_fla
             }
         };
         if (hipSetDevice(lib->device) != hipSuccess) { set_error("hipSetDevice failed in a worker"); fail(BC_EHIP); return; }
-        auto step = [&](uint64_t a, uint64_t m) -> int {
+        struct InFlight { bool busy = false; uint64_t a = 0, m = 0; } fl[2];
+        // wait for the chunk in buffer set b and hand its results to the caller
+        auto finish = [&](int b) -> int {
+            if (!fl[b].busy) return BC_OK;
+            HostSlot& s = slots[2 * w + b];
+            fl[b].busy = false;
+            BC_HIP(hipStreamSynchronize(s.st));
+            const uint64_t a = fl[b].a, m = fl[b].m;
+            if (st_bi) memcpy(h_best_idx + a, s.h_bi, m * 4);
+            if (st_bd) memcpy(h_best_dist + a, s.h_bd, m);
+            if (st_nb) memcpy(h_n_best + a, s.h_nb, m);
+            return BC_OK;
+        };
+        auto start = [&](int b, uint64_t a, uint64_t m) -> int {
+            HostSlot& s = slots[2 * w + b];
             const uint64_t* src_r = h_reads + a;
             const uint8_t* src_f = h_flags ? h_flags + a : nullptr;
-            if (stage) {
-                memcpy(s.h_r, h_reads + a, m * 8);
-                if (h_flags) memcpy(s.h_f, h_flags + a, m);
-                src_r = s.h_r; src_f = h_flags ? s.h_f : nullptr;
-            }
+            if (st_r) { memcpy(s.h_r, h_reads + a, m * 8); src_r = s.h_r; }
+            if (st_f) { memcpy(s.h_f, h_flags + a, m); src_f = s.h_f; }
             BC_HIP(hipMemcpyAsync(s.d_r, src_r, m * 8, hipMemcpyHostToDevice, s.st));
             if (h_flags) BC_HIP(hipMemcpyAsync(s.d_f, src_f, m, hipMemcpyHostToDevice, s.st));
             MatchOut o{s.d_bi, h_best_dist ? s.d_bd : nullptr, h_n_best ? s.d_nb : nullptr, d_c, d_fs, first_index_base + a, PartOut{}};
             int rc = launch_match(lib, s.d_r, h_flags ? s.d_f : nullptr, m, max_mismatch, algo, o, s.st);
             if (rc != BC_OK) return rc;
-            BC_HIP(hipMemcpyAsync(stage ? s.h_bi : h_best_idx + a, s.d_bi, m * 4, hipMemcpyDeviceToHost, s.st));
-            if (h_best_dist) BC_HIP(hipMemcpyAsync(stage ? s.h_bd : h_best_dist + a, s.d_bd, m, hipMemcpyDeviceToHost, s.st));
-            if (h_n_best) BC_HIP(hipMemcpyAsync(stage ? s.h_nb : h_n_best + a, s.d_nb, m, hipMemcpyDeviceToHost, s.st));
-            BC_HIP(hipStreamSynchronize(s.st));
-            if (stage) {
-                memcpy(h_best_idx + a, s.h_bi, m * 4);
-                if (h_best_dist) memcpy(h_best_dist + a, s.h_bd, m);
-                if (h_n_best) memcpy(h_n_best + a, s.h_nb, m);
-            }
+            if (h_best_idx) BC_HIP(hipMemcpyAsync(st_bi ? s.h_bi : h_best_idx + a, s.d_bi, m * 4, hipMemcpyDeviceToHost, s.st));
+            if (h_best_dist) BC_HIP(hipMemcpyAsync(st_bd ? s.h_bd : h_best_dist + a, s.d_bd, m, hipMemcpyDeviceToHost, s.st));
+            if (h_n_best) BC_HIP(hipMemcpyAsync(st_nb ? s.h_nb : h_n_best + a, s.d_nb, m, hipMemcpyDeviceToHost, s.st));
+            fl[b].busy = true; fl[b].a = a; fl[b].m = m;
             return BC_OK;
         };
+        int b = 0, rc = BC_OK;
         for (;;) {
             const uint64_t c = next.fetch_add(1);
             if (c >= n_chunks || first_rc.load() != BC_OK) break;
             const uint64_t a = c * CH, m = std::min(CH, n - a);
-            int rc = step(a, m);
-            if (rc != BC_OK) { fail(rc); break; }
+            if ((rc = finish(b)) != BC_OK) break;        // the chunk before last: its buffers are free again
+            if ((rc = start(b, a, m)) != BC_OK) break;   // ... and take this one, while the last chunk is still in flight
+            b ^= 1;
         }
+        for (int q = 0; q < 2; ++q) {  // drain, on every path (an error must not leave copies in flight)
+            const int r2 = finish(q);
+            if (rc == BC_OK) rc = r2;
+        }
+        if (rc != BC_OK) fail(rc);
     };
     if (workers == 1) {
         work(0);
@@ -2443,7 +2471,7 @@ int bc_lib_destroy(bc_lib* lib) {
                         (void*)w.casc_count, w.casc_scan_tmp}) if (p) (void)hipFree(p);
     if (lib->host_slots) {
         HostSlot* hs = (HostSlot*)lib->host_slots;
-        for (int w = 0; w < HOST_WORKERS; ++w) slot_release(hs[w]);
+        for (int w = 0; w < 2 * HOST_WORKERS; ++w) slot_release(hs[w]);
         delete[] hs;
     }
     delete lib;
@@ -2584,7 +2612,12 @@ int bc_match_host(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, 
                   int max_mismatch, int algo, int32_t* h_best_idx, uint8_t* h_best_dist,
                   uint8_t* h_n_best, uint64_t* h_counts, uint64_t* h_first_seen,
                   uint64_t first_index_base) {
-    if (!lib || (n && (!h_reads || !h_best_idx))) { set_error("bc_match_host: null argument"); return BC_EINVAL; }
+    if (!lib || (n && !h_reads)) { set_error("bc_match_host: null argument"); return BC_EINVAL; }
+    if (n && !h_best_idx && (h_best_dist || h_n_best || (!h_counts && !h_first_seen))) {
+        // counts-only mode: no per-read output at all, and a tally to return
+        set_error("bc_match_host: without h_best_idx (counts-only) pass neither h_best_dist nor h_n_best, and h_counts or h_first_seen");
+        return BC_EINVAL;
+    }
     if (n == 0) return BC_OK;
     BC_HIP(hipSetDevice(lib->device));
     if (n > (1ull << 31)) {  // keep the 32-bit device counters safe: split very long calls
@@ -2592,7 +2625,7 @@ int bc_match_host(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, 
         for (uint64_t a = 0; a < n; a += half) {
             const uint64_t m = std::min(half, n - a);
             int rc = bc_match_host(lib, h_reads + a, h_flags ? h_flags + a : nullptr, m, max_mismatch, algo,
-                                   h_best_idx + a, h_best_dist ? h_best_dist + a : nullptr,
+                                   h_best_idx ? h_best_idx + a : nullptr, h_best_dist ? h_best_dist + a : nullptr,
                                    h_n_best ? h_n_best + a : nullptr, h_counts, h_first_seen, first_index_base + a);
             if (rc != BC_OK) return rc;
         }
@@ -2624,6 +2657,52 @@ int bc_match_host(bc_lib* lib, const uint64_t* h_reads, const uint8_t* h_flags, 
         for (uint32_t g = 0; g < lib->G; ++g) h_first_seen[g] = std::min(h_first_seen[g], fs[g]);
     }
     return BC_OK;
+}
+
+// The host link's copy rates between page-locked memory and HBM: upload alone, download alone, and both at once on two
+// streams (PCIe is full duplex) — the roofline bench.py holds bc_match_host against (secondary.host_pcie.roofline).
+int bc_pcie_probe(int device, uint64_t bytes, int repeats, double* h2d_GBps, double* d2h_GBps, double* duplex_GBps) {
+    if (bytes < 4096 || repeats < 1) { set_error("bc_pcie_probe: bad argument"); return BC_EINVAL; }
+    BC_HIP(hipSetDevice(device));
+    struct Bufs {
+        void *h_up = nullptr, *h_dn = nullptr, *d_up = nullptr, *d_dn = nullptr;
+        hipStream_t s_up = nullptr, s_dn = nullptr;
+        ~Bufs() {
+            if (h_up) (void)hipHostFree(h_up);
+            if (h_dn) (void)hipHostFree(h_dn);
+            if (d_up) (void)hipFree(d_up);
+            if (d_dn) (void)hipFree(d_dn);
+            if (s_up) (void)hipStreamDestroy(s_up);
+            if (s_dn) (void)hipStreamDestroy(s_dn);
+        }
+    } B;
+    BC_HIP(hipHostMalloc(&B.h_up, bytes, hipHostMallocDefault));
+    BC_HIP(hipHostMalloc(&B.h_dn, bytes, hipHostMallocDefault));
+    BC_HIP(hipMalloc(&B.d_up, bytes));
+    BC_HIP(hipMalloc(&B.d_dn, bytes));
+    BC_HIP(hipStreamCreateWithFlags(&B.s_up, hipStreamNonBlocking));
+    BC_HIP(hipStreamCreateWithFlags(&B.s_dn, hipStreamNonBlocking));
+    memset(B.h_up, 1, bytes);
+    memset(B.h_dn, 2, bytes);
+    BC_HIP(hipMemset(B.d_dn, 3, bytes));
+    auto timed = [&](bool up, bool dn, double* out) -> int {
+        for (int warm = 0; warm < 2; ++warm) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < (warm ? repeats : 1); ++r) {
+                if (up) BC_HIP(hipMemcpyAsync(B.d_up, B.h_up, bytes, hipMemcpyHostToDevice, B.s_up));
+                if (dn) BC_HIP(hipMemcpyAsync(B.h_dn, B.d_dn, bytes, hipMemcpyDeviceToHost, B.s_dn));
+            }
+            BC_HIP(hipStreamSynchronize(B.s_up));
+            BC_HIP(hipStreamSynchronize(B.s_dn));
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (warm && out) *out = (double)bytes * repeats * ((up ? 1 : 0) + (dn ? 1 : 0)) / dt / 1e9;
+        }
+        return BC_OK;
+    };
+    int rc;
+    if ((rc = timed(true, false, h2d_GBps)) != BC_OK) return rc;
+    if ((rc = timed(false, true, d2h_GBps)) != BC_OK) return rc;
+    return timed(true, true, duplex_GBps);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

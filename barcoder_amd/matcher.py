@@ -38,22 +38,38 @@ class GpuMatcher:
 
     # -- host buffers ------------------------------------------------------------
     def match(self, reads, flags=None, max_mismatch: int = 0, algo: str = "auto", first_index: int = 0,
-              counts=None, first_seen=None) -> MatchResult:
+              counts=None, first_seen=None, per_read: bool = True) -> MatchResult:
+        """bc_match_host.  The per-read result arrays of a large call are views on page-locked memory (pooled,
+        devmem.PinnedBlock): the DMA writes them directly — no staging copy, no first-touch page faults — and they go
+        back to the pool when the result is dropped.  per_read=False is the counts-only mode: `best_idx`, `best_dist`
+        and `n_best` of the result are None, only the reads cross the link."""
         reads = np.ascontiguousarray(reads, np.uint64)
         n, G = reads.size, self.lib.size
         if flags is not None:
             flags = np.ascontiguousarray(flags, np.uint8)
             if flags.size != n:
                 raise ValueError("flags and reads differ in length")
-        bi = np.empty(n, np.int32)
-        bd = np.empty(n, np.uint8)
-        nb = np.empty(n, np.uint8)
+        bi = bd = nb = None
+        if per_read and n >= (1 << 18):
+            from .devmem import PinnedBlock
+            pad = (n + 63) & ~63
+            blk = PinnedBlock(pad * 6)
+            bi, bd, nb = blk.array(np.int32, n, 0), blk.array(np.uint8, n, pad * 4), blk.array(np.uint8, n, pad * 5)
+        elif per_read:
+            bi, bd, nb = np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(n, np.uint8)
         counts = np.zeros(G, np.uint64) if counts is None else counts
         first_seen = np.full(G, U64_MAX, np.uint64) if first_seen is None else first_seen
         N.check(N.load().bc_match_host(self.lib.handle, N.ptr(reads), N.ptr(flags), n, int(max_mismatch),
                                        N.ALGOS[algo], N.ptr(bi), N.ptr(bd), N.ptr(nb), N.ptr(counts),
                                        N.ptr(first_seen), int(first_index)))
         return MatchResult(bi, bd, nb, counts, first_seen)
+
+    @staticmethod
+    def pcie_probe(device: int = 0, nbytes: int = 256 << 20, repeats: int = 4) -> dict:
+        """Copy rates of the host link (page-locked memory <-> HBM), GB/s: bc_pcie_probe."""
+        up, dn, both = C.c_double(), C.c_double(), C.c_double()
+        N.check(N.load().bc_pcie_probe(device, nbytes, repeats, C.byref(up), C.byref(dn), C.byref(both)))
+        return {"h2d_GBps": up.value, "d2h_GBps": dn.value, "duplex_GBps": both.value}
 
     # -- device buffers (torch tensors or raw pointers) ------------------------------
     def match_dev(self, d_reads: int, n: int, d_best_idx: int, max_mismatch: int = 0, algo: str = "auto",

@@ -225,15 +225,48 @@ def secondary_workloads(torch, dev, local, stream, lib_packed, matcher, n, steps
         return res
 
     def host_pcie():  # bc_match_host: host buffers in, host results out (PCIe included), <= 2 mismatches
+        # held against the link's own copy rates, measured here (page-locked memory <-> HBM, bc_pcie_probe): 8 bytes per
+        # read go up and 6 come back, so the all-outputs path is priced against the duplex rate and the counts-only path
+        # (nothing per read comes back) against the upload rate
+        from barcoder_amd.devmem import PinnedBlock
         m = min(n, 20_000_000)
         reads = np.concatenate([S.reads(lib_packed, K, 2, a, min(5_000_000, m - a), 1) for a in range(0, m, 5_000_000)])
-        matcher.match(reads[:1_000_000], None, MAX_MM, "seed")
-        t0 = time.perf_counter()
-        res = matcher.match(reads, None, MAX_MM, "seed")
-        dt = time.perf_counter() - t0
-        return {"workload": f"bc_match_host, {m} reads from pageable host buffers, all outputs back to the host",
-                "Mreads_per_s": m / dt / 1e6, "GB_per_s_over_pcie": m * 14 / dt / 1e9,
-                "matched_fraction": float((res.best_idx >= 0).mean())}
+        probe = matcher.pcie_probe(local)
+        pin = PinnedBlock(m * 8)
+        preads = pin.array(np.uint64, m)
+        preads[:] = reads
+
+        def timed(fn, reps=3):
+            fn()  # untimed: staging buffers, pooled result blocks, first-touch of everything
+            best = None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                res = fn()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            return best, res
+
+        dt_page, res = timed(lambda: matcher.match(reads, None, MAX_MM, "seed"))
+        dt_pin, res_pin = timed(lambda: matcher.match(preads, None, MAX_MM, "seed"))
+        dt_cnt, res_cnt = timed(lambda: matcher.match(preads, None, MAX_MM, "seed", per_read=False))
+        same = bool(np.array_equal(res.best_idx, res_pin.best_idx) and np.array_equal(res.counts, res_pin.counts) and
+                    np.array_equal(res.counts, res_cnt.counts) and np.array_equal(res.first_seen, res_cnt.first_seen))
+        link = lambda dt, b: m * b / dt / 1e9
+        return {"workload": f"bc_match_host, {m} reads, <= {MAX_MM} mismatches; best of 3 calls after one untimed",
+                "Mreads_per_s": m / dt_page / 1e6, "GB_per_s_over_pcie": link(dt_page, 14),
+                "pageable": {"what": "reads in pageable memory (staged by worker threads), results in the wrapper's page-locked arrays",
+                             "Mreads_per_s": m / dt_page / 1e6, "GB_per_s_over_pcie": link(dt_page, 14),
+                             "frac_of_duplex": link(dt_page, 14) / probe["duplex_GBps"]},
+                "pinned": {"what": "reads and results in page-locked memory (no staging)",
+                           "Mreads_per_s": m / dt_pin / 1e6, "GB_per_s_over_pcie": link(dt_pin, 14),
+                           "frac_of_duplex": link(dt_pin, 14) / probe["duplex_GBps"]},
+                "counts_only": {"what": "page-locked reads up, per-guide counts / first-seen back once (per_read=False)",
+                                "Mreads_per_s": m / dt_cnt / 1e6, "GB_per_s_over_pcie": link(dt_cnt, 8),
+                                "frac_of_h2d": link(dt_cnt, 8) / probe["h2d_GBps"]},
+                "roofline": {"bound": "pcie", "unit": "GB/s", "peak": probe["duplex_GBps"], "h2d": probe["h2d_GBps"],
+                             "d2h": probe["d2h_GBps"], "achieved": link(dt_pin, 14), "frac": link(dt_pin, 14) / probe["duplex_GBps"],
+                             "source": "bc_pcie_probe in this run: 256 MiB each way between page-locked memory and HBM, 4 repeats"},
+                "modes_agree": same, "matched_fraction": float((res.best_idx >= 0).mean())}
 
     def from_file():  # heuristicount end to end from a .reads file (sampling + bulk pass + merge)
         import shutil

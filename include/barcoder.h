@@ -304,13 +304,24 @@ int bc_match_dev(bc_lib *lib, const uint64_t *d_reads, const uint8_t *d_flags, u
                  uint32_t *d_counts, uint64_t *d_first_seen, uint64_t first_index_base,
                  void *stream);
 
-/* Same with host buffers: H2D, match, D2H on the library's device (chunked so
- * any n fits).  h_counts (uint64[n_guides]) is ADDED to, h_first_seen
- * (uint64[n_guides]) is min'ed. */
+/* Same with host buffers: H2D, match, D2H on the library's device, in chunks of 1M
+ * reads that worker threads pipeline (two buffer sets each: one chunk on the link /
+ * the device while the one before it is copied out and the next one in), so any n
+ * fits.  Buffers in page-locked memory (bc_host_alloc_pinned, hipHostRegister) are
+ * the DMA's source / target as they are; pageable ones go through page-locked staging.
+ * h_counts (uint64[n_guides]) is ADDED to, h_first_seen (uint64[n_guides]) is min'ed.
+ * h_best_idx == NULL (then h_best_dist and h_n_best NULL too, and a tally wanted):
+ * counts-only — what heuristicount.py:535-538 needs of a chunk — 8 bytes per read go
+ * up the link, nothing per read comes back. */
 int bc_match_host(bc_lib *lib, const uint64_t *h_reads, const uint8_t *h_flags, uint64_t n,
                   int max_mismatch, int algo,
                   int32_t *h_best_idx, uint8_t *h_best_dist, uint8_t *h_n_best,
                   uint64_t *h_counts, uint64_t *h_first_seen, uint64_t first_index_base);
+/* Copy rates of the host link between page-locked memory and HBM, GB/s: upload alone,
+ * download alone, both at once (`bytes` each way, `repeats` times): the roofline of
+ * bc_match_host (measurement aid, bench.py secondary.host_pcie). */
+int bc_pcie_probe(int device, uint64_t bytes, int repeats, double *h2d_GBps, double *d2h_GBps,
+                  double *duplex_GBps);
 
 /* ---- several GPUs in one process --------------------------------------------
  * The data-parallel fan-out of heuristicount.py:703-737 (Pool.starmap over

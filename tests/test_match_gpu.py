@@ -336,6 +336,55 @@ def test_edge_sizes(gpu_device, oracle):
                 assert res.best_idx.size == 0 and res.counts.sum() == 0
 
 
+def test_host_streaming_modes_agree(gpu_device, oracle):
+    """bc_match_host over several chunks per worker (two buffer sets each, one chunk in flight while the neighbours are
+    copied): reads from pageable memory (staged) and from page-locked memory (DMA source as it is), results into the
+    wrapper's page-locked arrays and into plain numpy arrays handed to the C ABI (staged out), with and without skip
+    flags, and the counts-only mode — all identical, and equal to the oracle on a prefix.  Counts-only with a per-read
+    output is refused."""
+    import ctypes as C
+    from barcoder_amd import _native as N
+    from barcoder_amd.devmem import PinnedBlock
+    k, G, n = 20, 4000, 11_300_007
+    lib = S.library(G, k)
+    reads = np.concatenate([S.reads(lib, k, 9, a, min(4_000_000, n - a), 1) for a in range(0, n, 4_000_000)])
+    flags = (S.draw(5, np.arange(n, dtype=np.uint64), 7) % np.uint64(50) == 0).astype(np.uint8)
+    dl = DeviceLibrary(lib, k, gpu_device)
+    m = GpuMatcher(dl)
+    base = m.match(reads, flags, max_mismatch=2, algo="seed", first_index=3)
+    ref = oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads[:200_000] & E.kmer_mask(k), k), 2, skip=flags[:200_000], base=3)
+    for key in ("best_idx", "best_dist", "n_best"):
+        np.testing.assert_array_equal(getattr(base, key)[:200_000], ref[key])
+    pin = PinnedBlock(n * 8)
+    preads = pin.array(np.uint64, n)
+    preads[:] = reads
+    for r, f in ((preads, flags), (preads, None), (reads, None)):
+        want = base if f is not None else m.match(reads, None, max_mismatch=2, algo="seed", first_index=3)
+        got = m.match(r, f, max_mismatch=2, algo="seed", first_index=3)
+        cnt = m.match(r, f, max_mismatch=2, algo="seed", first_index=3, per_read=False)
+        assert cnt.best_idx is None and cnt.best_dist is None and cnt.n_best is None
+        for key in ("best_idx", "best_dist", "n_best", "counts", "first_seen"):
+            np.testing.assert_array_equal(getattr(got, key), getattr(want, key))
+        np.testing.assert_array_equal(cnt.counts, want.counts)
+        np.testing.assert_array_equal(cnt.first_seen, want.first_seen)
+    # plain numpy result arrays through the C ABI: staged out of the workers' page-locked buffers
+    bi, bd, nb = np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(n, np.uint8)
+    c, fs = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
+    L = N.load()
+    N.check(L.bc_match_host(dl.handle, N.ptr(reads), N.ptr(flags), n, 2, N.ALGOS["seed"], N.ptr(bi), N.ptr(bd), N.ptr(nb),
+                            N.ptr(c), N.ptr(fs), 3))
+    np.testing.assert_array_equal(bi, base.best_idx)
+    np.testing.assert_array_equal(bd, base.best_dist)
+    np.testing.assert_array_equal(nb, base.n_best)
+    np.testing.assert_array_equal(c, base.counts)
+    with pytest.raises(ValueError, match="counts-only"):
+        N.check(L.bc_match_host(dl.handle, N.ptr(reads), None, n, 2, N.ALGOS["seed"], None, N.ptr(bd), None, N.ptr(c), N.ptr(fs), 0))
+    with pytest.raises(ValueError, match="counts-only"):
+        N.check(L.bc_match_host(dl.handle, N.ptr(reads), None, n, 2, N.ALGOS["seed"], None, None, None, None, None, 0))
+    probe = GpuMatcher.pcie_probe(gpu_device, 32 << 20, 2)
+    assert probe["h2d_GBps"] > 1 and probe["d2h_GBps"] > 1 and probe["duplex_GBps"] > max(probe["h2d_GBps"], probe["d2h_GBps"]) * 0.8
+
+
 def test_synth_device_matches_numpy(gpu_device):
     import ctypes as C
     from barcoder_amd import _native as N
