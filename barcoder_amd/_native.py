@@ -58,6 +58,9 @@ SIGNATURES = {
     "bc_reader_close": (C.c_int, [vp]),
     "bc_stream_count_file": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_char_p, C.c_int, C.c_char_p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp, vp, C.POINTER(vp)]),
+    "bc_stream_count_file_part": (C.c_int, [vp, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int64, C.c_char_p, C.c_int, C.c_char_p,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp, vp, C.POINTER(vp)]),
+    "bc_reader_read_raw": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bc_stream_result_info": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "bc_stream_result_undoc": (C.c_int, [vp, vp, vp, vp]),

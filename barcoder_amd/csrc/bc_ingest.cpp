@@ -13,6 +13,7 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -227,6 +228,26 @@ int bc_reader_close(bc_reader* r) {
     if (r->fp) fclose(r->fp);
     if (r->zctx) g_zstd.freeDCtx(r->zctx);
     delete r;
+    return BC_OK;
+}
+
+// The decoded byte stream itself, sequentially: up to `cap` bytes into dst, *got = 0 at the end of the stream.  What the
+// device ingest (bc_stream_count_file on a .gz / .zst file) uploads in 16 MiB chunks: the line rules then run on the
+// device.  Not to be mixed with bc_reader_next on one reader.  A damaged or truncated stream is an error.
+int bc_reader_read_raw(bc_reader* r, char* dst, uint64_t cap, uint64_t* got) {
+    if (!r || !dst || !got) { set_error("bc_reader_read_raw: null argument"); return BC_EINVAL; }
+    uint64_t have = 0;
+    while (have < cap && !r->eof) {
+        const size_t n = r->fill(dst + have, (size_t)std::min<uint64_t>(cap - have, 1u << 30));
+        if (n == 0) { r->eof = true; break; }
+        have += n;
+    }
+    if (r->failed) {
+        *got = 0;
+        set_error("reads file: %s", r->fail_msg.c_str());
+        return BC_EINVAL;
+    }
+    *got = have;
     return BC_OK;
 }
 

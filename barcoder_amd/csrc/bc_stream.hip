@@ -34,6 +34,13 @@
 
 using namespace bc;
 
+extern "C" {
+typedef struct bc_reader bc_reader;
+int bc_reader_open(const char* path, bc_reader** out);
+int bc_reader_read_raw(bc_reader* r, char* dst, uint64_t cap, uint64_t* got);
+int bc_reader_close(bc_reader* r);
+}
+
 namespace {
 
 constexpr uint64_t CHUNK = 16ull << 20;   // bytes of file per device pass
@@ -338,6 +345,11 @@ static uint64_t count_nl(const uint8_t* p, uint64_t n) {
     return c;
 }
 
+static bool is_compressed(const char* path) {
+    const size_t n = strlen(path);
+    return (n >= 3 && strcmp(path + n - 3, ".gz") == 0) || (n >= 4 && strcmp(path + n - 4, ".zst") == 0);
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -469,6 +481,9 @@ struct FileJob {
     Geometry g{};
     int max_mismatch = 0, algo = 0, n_threads = 0;
     uint64_t key_base = 0;
+    // chunk c of the stream is this job's when c % n_parts == part (several ranks over one COMPRESSED file: every rank
+    // decodes the stream, the per-read work is split; byte ranges cannot cut a compressed stream)
+    uint32_t part = 0, n_parts = 1;
     // match mode (store == nullptr): per-chunk match, tallies accumulate on the device, misses join `misses`
     uint32_t* d_counts = nullptr;
     uint64_t* d_first = nullptr;
@@ -486,22 +501,45 @@ int run_file(FileJob& J) {
     bc_lib_info(J.lib, &G, &k, &device);
     const char* path = J.path;
     Geometry g = J.g;
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) { set_error("cannot open %s", path); return BC_EINVAL; }
-    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) { set_error("cannot stat %s", path); return BC_EINVAL; }
-    const uint64_t fsize = (uint64_t)sb.st_size;
-    const uint64_t byte_end = std::min(J.byte_end, fsize);
-    const uint64_t byte_begin = std::min(J.byte_begin, byte_end);
-    const uint64_t span = byte_end - byte_begin;
-    const uint64_t n_chunks = (span + CHUNK - 1) / CHUNK;
+    // A compressed file (.gz / .zst) is a sequential stream: whichever worker is next decodes the following 16 MiB
+    // (+ slack) into its own page-locked buffer under `src_m` — the decoder runs on one thread at a time, uploads and
+    // kernels of the chunks before it run meanwhile on the others' streams — and the stream's length is known at its end
+    // only.  A plain file is read with pread by every worker for itself, as before.
+    const bool compressed = is_compressed(path);
+    bc_reader* rd = nullptr;
+    struct ReaderCloser { bc_reader*& r; ~ReaderCloser() { if (r) bc_reader_close(r); } } rd_closer{rd};
+    int fd = -1;
+    struct Closer { int& fd; ~Closer() { if (fd >= 0) close(fd); } } closer{fd};
+    uint64_t fsize_plain = 0;
+    if (compressed) {
+        if (J.byte_begin != 0 || J.byte_end < (1ull << 62)) {
+            set_error("%s is compressed: byte ranges need a plain .fastq / .reads file (several ranks split it by chunk: part / n_parts)", path);
+            return BC_EINVAL;
+        }
+        int rc0 = bc_reader_open(path, &rd);
+        if (rc0 != BC_OK) return rc0;
+    } else {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) { set_error("cannot open %s", path); return BC_EINVAL; }
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) { set_error("cannot stat %s", path); return BC_EINVAL; }
+        fsize_plain = (uint64_t)sb.st_size;
+    }
+    const uint64_t byte_end = compressed ? ~0ull : std::min(J.byte_end, fsize_plain);
+    const uint64_t byte_begin = compressed ? 0 : std::min(J.byte_begin, byte_end);
+    const uint64_t span = compressed ? ~0ull : byte_end - byte_begin;
+    const uint64_t n_chunks = compressed ? ~0ull : (span + CHUNK - 1) / CHUNK;
+    std::mutex src_m;                       // compressed: the decoder, `src_next`, `src_done`, `carry`
+    uint64_t src_next = 0;
+    bool src_done = false;
+    std::vector<uint8_t> carry;             // compressed: decoded bytes from one before the next chunk's core on
     int T = J.n_threads;
     if (T <= 0) {  // default; BC_STREAM_THREADS overrides (tuning aid)
         const char* e = getenv("BC_STREAM_THREADS");
         T = e && atoi(e) > 0 ? atoi(e) : 8;  // measured, 4.6 GB file in the page cache: 4 / 8 / 12 / 16 threads -> 144-161 / 210 / 243 / 222 Mreads/s
     }
     T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)T, std::max<uint64_t>(n_chunks, 1)));
+    if (compressed) T = std::min(T, 4);  // one decodes, the others upload / launch / collect
     const uint64_t kmask = kmer_mask(k);
     WindowStore* const store = J.store;
 
@@ -541,20 +579,58 @@ int run_file(FileJob& J) {
                 return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - a).count();
             };
             for (;;) {
-                const uint64_t c = next_chunk.fetch_add(1);
-                if (c >= n_chunks || first_rc.load() != BC_OK) break;
+                uint64_t c, core_lo, core_hi, base, hi, nbytes, fsize;
+                int virt;
                 auto t_a = tick();
-                // ---- read: bytes [base, hi) of the file; the chunk owns newlines in [own_lo, own_hi)
-                const uint64_t core_lo = byte_begin + c * CHUNK, core_hi = std::min(byte_end, core_lo + CHUNK);
-                const int virt = (c == 0) ? 1 : 0;                 // the line at the start of the range
-                const uint64_t base = virt ? core_lo : core_lo - 1;
-                const uint64_t hi = std::min(fsize, core_hi + SLACK);
-                const uint64_t nbytes = hi - base;
-                uint64_t got = 0;
-                while (got < nbytes) {
-                    ssize_t n = pread(fd, s.h_text + got, nbytes - got, (off_t)(base + got));
-                    if (n <= 0) { set_error("read error in %s", path); return BC_EINVAL; }
-                    got += (uint64_t)n;
+                if (!compressed) {
+                    c = next_chunk.fetch_add(1);
+                    if (c >= n_chunks || first_rc.load() != BC_OK) break;
+                    // ---- read: bytes [base, hi) of the file; the chunk owns newlines in [own_lo, own_hi)
+                    fsize = fsize_plain;
+                    core_lo = byte_begin + c * CHUNK; core_hi = std::min(byte_end, core_lo + CHUNK);
+                    virt = (c == 0) ? 1 : 0;                 // the line at the start of the range
+                    base = virt ? core_lo : core_lo - 1;
+                    hi = std::min(fsize, core_hi + SLACK);
+                    nbytes = hi - base;
+                    uint64_t got = 0;
+                    while (got < nbytes) {
+                        ssize_t n = pread(fd, s.h_text + got, nbytes - got, (off_t)(base + got));
+                        if (n <= 0) { set_error("read error in %s", path); return BC_EINVAL; }
+                        got += (uint64_t)n;
+                    }
+                } else {
+                    // ---- decode: the same window [core_lo - 1, core_hi + SLACK) of the DECODED stream; what lies past
+                    // this chunk's core (one byte of context + the slack) is kept for the next chunk
+                    std::lock_guard<std::mutex> lk(src_m);
+                    if (src_done || first_rc.load() != BC_OK) break;
+                    c = src_next++;
+                    virt = (c == 0) ? 1 : 0;
+                    core_lo = c * CHUNK;
+                    base = virt ? core_lo : core_lo - 1;
+                    const uint64_t left = virt ? 0 : 1;
+                    const uint64_t want = left + CHUNK + SLACK;
+                    uint64_t have = carry.size();
+                    if (have) memcpy(s.h_text, carry.data(), have);
+                    bool at_end = false;
+                    while (have < want) {
+                        uint64_t got = 0;
+                        int rr = bc_reader_read_raw(rd, (char*)s.h_text + have, want - have, &got);
+                        if (rr != BC_OK) return rr;
+                        if (got == 0) { at_end = true; break; }
+                        have += got;
+                    }
+                    nbytes = have;
+                    hi = base + have;
+                    if (have <= left + CHUNK) {  // the stream ends inside this chunk's core: the last chunk
+                        core_hi = base + have;
+                        src_done = true;
+                        carry.clear();
+                    } else {
+                        core_hi = core_lo + CHUNK;
+                        carry.assign(s.h_text + left + CHUNK - 1, s.h_text + have);
+                    }
+                    fsize = at_end ? hi : ~0ull;  // (compared with `hi` below: does the stream go on behind the buffer?)
+                    if (have == 0) break;         // an empty stream (a later chunk always starts with the kept bytes)
                 }
                 // owned newlines: file positions [core_lo - 1, core_hi - 1) = buffer offsets [0, own_hi); the first chunk
                 // starts at the range's first line instead (a virtual newline in front of it).  The newline at
@@ -576,12 +652,13 @@ int run_file(FileJob& J) {
                     lines_before += n_own;
                     const uint64_t gri0_ = g.fastq ? ((line_base + 2) >> 2) : line_base;
                     const uint64_t gri1_ = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
-                    reads_launched += gri1_ - gri0_;
+                    if (c % J.n_parts == J.part) reads_launched += gri1_ - gri0_;
                     if (store && c == 0) {  // size the run-wide arrays from the first chunk's density (+25 %)
                         const char* e = getenv("BC_STREAM_EST_PCT");  // (tests shrink the estimate to exercise the growth path)
                         const double pct = e && atoi(e) > 0 ? atoi(e) / 100.0 : 1.25;
-                        store->estimate = (uint64_t)((double)(gri1_ - gri0_) * ((double)span / (double)std::max<uint64_t>(core_hi - core_lo, 1)) * pct) +
-                                          (pct < 1.0 ? 16 : 65536);
+                        // (a compressed stream's length is not known: eight chunks' worth, doubled as it fills)
+                        const double chunks = compressed ? 8.0 : (double)span / (double)std::max<uint64_t>(core_hi - core_lo, 1);
+                        store->estimate = (uint64_t)((double)(gri1_ - gri0_) * chunks * pct) + (pct < 1.0 ? 16 : 65536);
                     }
                     ++next_to_publish;
                 }
@@ -591,7 +668,7 @@ int run_file(FileJob& J) {
                 const uint64_t gri0 = g.fastq ? ((line_base + 2) >> 2) : line_base;
                 const uint64_t gri1 = g.fastq ? ((line_base + n_own + 2) >> 2) : line_base + n_own;
                 const uint64_t n_reads = gri1 - gri0;
-                if (n_own == 0 || n_reads == 0) continue;
+                if (n_own == 0 || n_reads == 0 || c % J.n_parts != J.part) continue;  // (another part's chunk: its lines are counted, no more)
                 // ---- device pass
                 const uint64_t n_words = (nbytes + 31) / 32;
                 const uint64_t nl_cap = n_real + SLACK + 64;
@@ -731,9 +808,11 @@ int run_file(FileJob& J) {
 int file_kind(const char* path, const char* who, int* fastq) {
     std::string p(path);
     auto ends = [&](const char* suf) { size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
+    if (ends(".gz")) p.resize(p.size() - 3);       // heuristicount.py:104-116: the type is read behind an optional .gz / .zst
+    else if (ends(".zst")) p.resize(p.size() - 4);
     if (ends(".fastq")) *fastq = 1;
     else if (ends(".reads")) *fastq = 0;
-    else { set_error("%s: an uncompressed .fastq or .reads file is needed, got %s", who, path); return BC_EINVAL; }
+    else { set_error("%s: a .fastq or .reads file (optionally .gz / .zst) is needed, got %s", who, path); return BC_EINVAL; }
     return BC_OK;
 }
 
@@ -970,10 +1049,35 @@ int bc_stream_result_pair_odd(const bc_stream_result* r, uint64_t* keys, uint64_
     return BC_OK;
 }
 
+static int stream_count_file_impl(bc_lib* lib, const char* path, uint64_t byte_begin, uint64_t byte_end, uint32_t part,
+                                  uint32_t n_parts, int64_t start, const char* L, int L_len, const char* R, int R_len,
+                                  int reverse, int max_mismatch, int algo, uint64_t key_base, int n_threads,
+                                  uint64_t* h_counts, uint64_t* h_first_seen, bc_stream_result** out);
+
 int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uint64_t byte_end, int64_t start,
                          const char* L, int L_len, const char* R, int R_len, int reverse, int max_mismatch, int algo,
                          uint64_t key_base, int n_threads, uint64_t* h_counts, uint64_t* h_first_seen,
                          bc_stream_result** out) {
+    return stream_count_file_impl(lib, path, byte_begin, byte_end, 0, 1, start, L, L_len, R, R_len, reverse, max_mismatch, algo,
+                                  key_base, n_threads, h_counts, h_first_seen, out);
+}
+
+// The same for one PART of a file's chunks: chunk c (16 MiB of the decoded stream) belongs to part c % n_parts.  How several
+// ranks share a compressed file (every rank decodes the stream; windows, match and tally of a chunk run on one rank): the
+// "stride" plan of barcoder_amd.heuristicount.  Keys are key_base + the read's index in the whole file.
+int bc_stream_count_file_part(bc_lib* lib, const char* path, uint32_t part, uint32_t n_parts, int64_t start,
+                              const char* L, int L_len, const char* R, int R_len, int reverse, int max_mismatch, int algo,
+                              uint64_t key_base, int n_threads, uint64_t* h_counts, uint64_t* h_first_seen,
+                              bc_stream_result** out) {
+    if (n_parts < 1 || part >= n_parts) { set_error("bc_stream_count_file_part: part %u of %u", part, n_parts); return BC_EINVAL; }
+    return stream_count_file_impl(lib, path, 0, ~0ull, part, n_parts, start, L, L_len, R, R_len, reverse, max_mismatch, algo,
+                                  key_base, n_threads, h_counts, h_first_seen, out);
+}
+
+static int stream_count_file_impl(bc_lib* lib, const char* path, uint64_t byte_begin, uint64_t byte_end, uint32_t part,
+                                  uint32_t n_parts, int64_t start, const char* L, int L_len, const char* R, int R_len,
+                                  int reverse, int max_mismatch, int algo, uint64_t key_base, int n_threads,
+                                  uint64_t* h_counts, uint64_t* h_first_seen, bc_stream_result** out) {
     if (!lib || !path || !out) { set_error("bc_stream_count_file: null argument"); return BC_EINVAL; }
     uint32_t G = 0; int k = 0, device = 0;
     bc_lib_info(lib, &G, &k, &device);
@@ -987,7 +1091,8 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
     BC_HIP(hipSetDevice(device));
     struct stat sb;
     if (stat(path, &sb) != 0) { set_error("cannot open %s", path); return BC_EINVAL; }
-    const uint64_t span = std::min<uint64_t>(byte_end, (uint64_t)sb.st_size) - std::min<uint64_t>(std::min<uint64_t>(byte_begin, byte_end), (uint64_t)sb.st_size);
+    uint64_t span = std::min<uint64_t>(byte_end, (uint64_t)sb.st_size) - std::min<uint64_t>(std::min<uint64_t>(byte_begin, byte_end), (uint64_t)sb.st_size);
+    if (is_compressed(path)) span *= 4;  // (a guess at the decoded length: it only sizes the first miss list, which grows)
     // run-wide device state
     DevBuf d_counts, d_first;
     MissList misses;
@@ -1003,6 +1108,7 @@ int bc_stream_count_file(bc_lib* lib, const char* path, uint64_t byte_begin, uin
         if ((rc = misses.reserve(est)) != BC_OK) return rc;
     }
     J.lib = lib; J.path = path; J.byte_begin = byte_begin; J.byte_end = byte_end;
+    J.part = part; J.n_parts = n_parts;
     J.max_mismatch = max_mismatch; J.algo = algo; J.n_threads = n_threads; J.key_base = key_base;
     J.d_counts = (uint32_t*)d_counts.p; J.d_first = (uint64_t*)d_first.p; J.misses = &misses;
     if ((rc = run_file(J)) != BC_OK) return rc;
@@ -1073,7 +1179,25 @@ int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_b
         if ((rc = file_kind(paths[f], "bc_stream_count_pair", &J[f].g.fastq)) != BC_OK) return rc;
         J[f].lib = lib; J[f].path = paths[f]; J[f].byte_begin = begins[f]; J[f].byte_end = ends_[f];
         J[f].n_threads = n_threads; J[f].key_base = key_base; J[f].store = &W[f];
-        if ((rc = run_file(J[f])) != BC_OK) return rc;
+    }
+    if (is_compressed(paths[0]) || is_compressed(paths[1])) {
+        // compressed mates: each file's decoder is one sequential thread at a time — both files at once, so the two
+        // decoders run side by side (plain files are read by eight threads each: one after the other, as before)
+        int rcs[2] = {BC_OK, BC_OK};
+        std::string errs[2];
+        std::thread other([&] {
+            (void)hipSetDevice(device);
+            rcs[1] = run_file(J[1]);
+            if (rcs[1] != BC_OK) errs[1] = bc_last_error();
+        });
+        rcs[0] = run_file(J[0]);
+        if (rcs[0] != BC_OK) errs[0] = bc_last_error();
+        other.join();
+        for (int f = 0; f < 2; ++f)
+            if (rcs[f] != BC_OK) { set_error("%s", errs[f].c_str()); return rcs[f]; }
+    } else {
+        for (int f = 0; f < 2; ++f)
+            if ((rc = run_file(J[f])) != BC_OK) return rc;
     }
     if (J[0].n_reads != J[1].n_reads) {
         set_error("Length of reads1 and reads2 must be the same for paired-end data.");  // heuristicount.py:484-486

@@ -733,15 +733,18 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     t_lib = _time.perf_counter()
     G = len(cc.labels)
     plan = shard_plan(file1, file2, world)
-    # the device path takes a single uncompressed file whose start offset is known (not None after sampling)
-    # (barcodes of more than 32 nt: text hashes + verification on the device too; paired or compressed input takes the
+    # the device path takes a single file — plain, or .gz / .zst decoded into the upload buffers — whose start offset is
+    # known (not None after sampling)
+    # (barcodes of more than 32 nt: text hashes + verification on the device too; paired input of such barcodes takes the
     # host front half, see ChunkCounter._match)
-    device_ingest = (not is_paired and not file1.endswith((".gz", ".zst")) and (plan == "bytes" or world == 1)
+    compressed1 = file1.endswith((".gz", ".zst"))
+    device_ingest = (not is_paired and (plan == "bytes" or world == 1 or compressed1)
                      and (bc_start2 if need_swap else bc_start1) is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                      and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     # paired-end: two uncompressed files; with several ranks every rank takes byte ranges of both files that hold the same
     # reads (ingest.paired_read_ranges: newline counts per slice, made common knowledge by one small gather)
-    device_pairs = (bc_len <= 32 and is_paired and not file1.endswith((".gz", ".zst")) and not file2.endswith((".gz", ".zst"))
+    compressed_pair = is_paired and (file1.endswith((".gz", ".zst")) or file2.endswith((".gz", ".zst")))
+    device_pairs = (bc_len <= 32 and is_paired and (not compressed_pair or world == 1)
                     and bc_start1 is not None and bc_start2 is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                     and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     undoc_tables, odd_events = [], []
@@ -791,15 +794,18 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
             # single uncompressed file: raw bytes -> HBM, everything per read on the device (bc_stream_count_file).
             # Nominal byte cuts become record-aligned ranges; the key of a read = range start + its ordinal.
             from .ingest import record_boundary, stream_count_file
+            part = None
             if plan == "bytes":
                 lo, hi = record_boundary(file1, a), record_boundary(file1, b)
             else:
                 lo, hi = 0, os.path.getsize(file1)
+                if world > 1:  # a compressed file over several ranks: chunk c of the decoded stream is rank c % world's
+                    part = (rank, world)
             s1, s2, Lf, Rf, Lr, Rr = cc.geom
             reverse = bool(need_swap)
             start, L, R = (s2, Lr, Rr) if reverse else (s1, Lf, Rf)
             c64, f64 = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
-            sr = stream_count_file(cc.lib.handle, file1, lo, hi, start, L, R, reverse, max_mismatch, cc.algo, lo, c64, f64)
+            sr = stream_count_file(cc.lib.handle, file1, lo, hi, start, L, R, reverse, max_mismatch, cc.algo, lo, c64, f64, part=part)
             counts[:G], first_seen[:G] = c64, f64
             undoc_tables.append((sr.u_words, sr.u_counts, sr.u_first))
             for key, text in sr.odd:  # string semantics for windows that cannot be packed (ChunkCounter._windows)
@@ -885,6 +891,8 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     return dict(doc=doc, undoc=undoc, total_reads=total_reads, barcodes=barcodes, bc_len=bc_len,
                 bc_start1=bc_start1, bc_start2=bc_start2, flanks_fwd=(L_fwd, R_fwd), flanks_rev=(L_rev, R_rev),
                 need_swap=need_swap, forward_name=fwd_name, reverse_name=rev_name, shard_plan=plan,
+                bulk_pass=("device ingest (bc_stream_count_pair)" if device_pairs else
+                           "device ingest (bc_stream_count_file)" if device_ingest else "host front half"),
                 bulk_mreads_per_s=(n_mine[0] / t_bulk[0] / 1e6 if t_bulk[0] > 0 else None),
                 seconds=dict(sampling=t_sampled - t_start, library=t_lib - t_sampled,
                              library_build_overlapped=t_lib_done - t_lib0, bulk=t_bulk[0],

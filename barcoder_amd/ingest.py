@@ -121,15 +121,24 @@ class StreamResult:
 
 def stream_count_file(lib_handle, path: str, byte_begin: int, byte_end: int, start: int, L: str, R: str, reverse: bool,
                       max_mismatch: int, algo: str, key_base: int, counts: np.ndarray, first_seen: np.ndarray,
-                      n_threads: int = 0) -> StreamResult:
-    """The device path for an uncompressed single-end file: raw bytes in, counts / first-seen (accumulated into the
-    given uint64 arrays), undocumented table and odd windows out."""
+                      n_threads: int = 0, part=None) -> StreamResult:
+    """The device path for a single-end file: raw bytes in (a .gz / .zst stream is decoded on the host, 16 MiB at a time,
+    into the upload buffers), counts / first-seen (accumulated into the given uint64 arrays), undocumented table and
+    odd windows out.  part = (p, n): only the chunks c of the (decoded) stream with c % n == p — how several ranks
+    share a compressed file (bc_stream_count_file_part); the byte range must then be the whole file."""
     lib = N.load()
     h = N.vp()
     Lb, Rb = L.encode("ascii"), R.encode("ascii")
-    N.check(lib.bc_stream_count_file(lib_handle, path.encode(), int(byte_begin), int(byte_end), int(start), Lb, len(Lb),
-                                     Rb, len(Rb), 1 if reverse else 0, int(max_mismatch), N.ALGOS[algo], int(key_base),
-                                     int(n_threads), N.ptr(counts), N.ptr(first_seen), C.byref(h)))
+    if part is not None:
+        N.check(lib.bc_stream_count_file_part(lib_handle, path.encode(), int(part[0]), int(part[1]), int(start), Lb, len(Lb),
+                                              Rb, len(Rb), 1 if reverse else 0, int(max_mismatch), N.ALGOS[algo], int(key_base),
+                                              int(n_threads), N.ptr(counts), N.ptr(first_seen), C.byref(h)))
+    else:
+        if path.endswith((".gz", ".zst")):
+            byte_begin, byte_end = 0, 2**64 - 1  # a compressed stream has no byte ranges
+        N.check(lib.bc_stream_count_file(lib_handle, path.encode(), int(byte_begin), int(byte_end), int(start), Lb, len(Lb),
+                                         Rb, len(Rb), 1 if reverse else 0, int(max_mismatch), N.ALGOS[algo], int(key_base),
+                                         int(n_threads), N.ptr(counts), N.ptr(first_seen), C.byref(h)))
     try:
         n, nu, no, ob, sec = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
         N.check(lib.bc_stream_result_info(h, C.byref(n), C.byref(nu), C.byref(no), C.byref(ob), C.byref(sec)))

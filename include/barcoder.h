@@ -126,6 +126,9 @@ int bc_reader_open_range(const char *path, uint64_t begin, uint64_t end, bc_read
 int bc_reader_tell(const bc_reader *r, uint64_t *offset_out);
 int bc_reader_next(bc_reader *r, uint64_t max_reads, char *h_text, uint64_t text_cap,
                    uint64_t *h_off /* max_reads + 1 */, uint64_t *n_out);
+/* The decoded byte stream itself, sequentially (what the device ingest uploads of a
+ * .gz / .zst file; *got == 0 at the end; not to be mixed with bc_reader_next). */
+int bc_reader_read_raw(bc_reader *r, char *dst, uint64_t cap, uint64_t *got);
 int bc_reader_close(bc_reader *r);
 
 /* ---- barcodes of 33 ... 1000 nt (exact match) ---------------------------------
@@ -145,8 +148,8 @@ int bc_hash_windows(const char *h_text, const uint64_t *h_off, size_t n_reads, i
 
 /* ---- a reads file straight through the device --------------------------------
  * bc_stream_count_file: everything process_chunk does per read
- * (heuristicount.py:428-562) for the records of an UNCOMPRESSED .reads / .fastq
- * file that lie in [byte_begin, byte_end) — a range that starts at a record
+ * (heuristicount.py:428-562) for the records of a .reads / .fastq file that lie in
+ * [byte_begin, byte_end) — a range that starts at a record
  * boundary (0, or a bc_reader_open_range / bc_reader_tell position) — with the
  * raw bytes uploaded in chunks and line splitting, strip, N-skip (:524), window
  * slice (:527), flank test (:458-460), packing, reverse complement (:532-533),
@@ -165,6 +168,21 @@ int bc_stream_count_file(bc_lib *lib, const char *path, uint64_t byte_begin, uin
                          int64_t start, const char *L, int L_len, const char *R, int R_len,
                          int reverse, int max_mismatch, int algo, uint64_t key_base, int n_threads,
                          uint64_t *h_counts, uint64_t *h_first_seen, bc_stream_result **out);
+/* Compressed input (.gz / .zst, heuristicount.py:60-72, :100-153) takes the same path: the
+ * stream is decoded on the host, sequentially, in 16 MiB pieces straight into the
+ * page-locked upload buffers of the worker threads (whichever worker is next decodes;
+ * uploads and kernels of earlier chunks overlap it), so the bulk rate is the decoder's.
+ * A compressed stream has no byte ranges: bc_stream_count_file wants (0, UINT64_MAX) for
+ * it, and several ranks share it by CHUNK instead — bc_stream_count_file_part: chunk c
+ * (16 MiB of the decoded stream) belongs to part c % n_parts; every rank decodes, one rank
+ * does a chunk's per-read work; keys are key_base + the read's index in the whole file.
+ * (Plain files may be split the same way.)  bc_stream_count_pair accepts compressed mates
+ * too (whole files: both decoders run side by side). */
+int bc_stream_count_file_part(bc_lib *lib, const char *path, uint32_t part, uint32_t n_parts,
+                              int64_t start, const char *L, int L_len, const char *R, int R_len,
+                              int reverse, int max_mismatch, int algo, uint64_t key_base,
+                              int n_threads, uint64_t *h_counts, uint64_t *h_first_seen,
+                              bc_stream_result **out);
 int bc_stream_result_info(const bc_stream_result *r, uint64_t *n_reads, uint64_t *n_undoc,
                           uint64_t *n_odd, uint64_t *odd_bytes, double *seconds);
 int bc_stream_result_undoc(const bc_stream_result *r, uint64_t *words, uint64_t *counts,

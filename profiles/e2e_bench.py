@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """End-to-end timing of barcoder_amd.heuristicount.count_barcodes on a synthetic
 .reads file (5 nt + CCGGATTCAG + 20-mer + GTTTTAGAGC, the layout of BASELINE.md
-section 2).  usage: python profiles/e2e_bench.py [n_reads] [n_guides] [paired]
-`paired` adds a mate file (3 nt + the reverse complement of flank + 20-mer + flank) and counts the pairs."""
+section 2).  usage: python profiles/e2e_bench.py [n_reads] [n_guides] [paired|gz|zst]
+`paired` adds a mate file (3 nt + the reverse complement of flank + 20-mer + flank) and counts the pairs;
+`gz` / `zst` compress the file first (gzip level 1 / the system libzstd) and also time the bare decoder on it:
+the bulk rate of a compressed file is the decoder's."""
 import os, sys, time, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +13,7 @@ from barcoder_amd import encoding as E, synth as S, heuristicount as H
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
 PAIRED = len(sys.argv) > 3 and sys.argv[3] == "paired"
+COMP = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] in ("gz", "zst") else None
 d = tempfile.mkdtemp(prefix="bc_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 lib = S.library(G, 20)
 labels = E.unpack_kmers(lib, 20)
@@ -49,6 +52,44 @@ with open(rd, "wb") as f:
 if f2 is not None:
     f2.close()
 print(f"generated {n} reads ({os.path.getsize(rd) / 1e6:.0f} MB) in {time.perf_counter() - t0:.1f} s", file=sys.stderr)
+if COMP:
+    import ctypes as C
+    from barcoder_amd import _native as N
+    plain_size = os.path.getsize(rd)
+    t0 = time.perf_counter()
+    if COMP == "gz":
+        import subprocess
+        subprocess.check_call(["gzip", "-1", "-k", rd])
+        os.remove(rd)
+        rd = rd + ".gz"
+    else:
+        z = C.CDLL("libzstd.so.1")
+        z.ZSTD_compressBound.restype = C.c_size_t
+        z.ZSTD_compressBound.argtypes = [C.c_size_t]
+        z.ZSTD_compress.restype = C.c_size_t
+        z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        raw = open(rd, "rb").read()
+        buf = C.create_string_buffer(z.ZSTD_compressBound(len(raw)))
+        m_ = z.ZSTD_compress(buf, len(buf), raw, len(raw), 1)
+        os.remove(rd)
+        rd = rd + ".zst"
+        open(rd, "wb").write(buf.raw[:m_])
+        del raw, buf
+    print(f"compressed to {os.path.getsize(rd) / 1e6:.0f} MB in {time.perf_counter() - t0:.1f} s", file=sys.stderr)
+    # the bare decoder: bc_reader_read_raw into a scratch buffer, nothing else
+    L = N.load()
+    h = N.vp()
+    N.check(L.bc_reader_open(rd.encode(), C.byref(h)))
+    scratch = np.empty(16 << 20, np.uint8)
+    got, total = C.c_uint64(1), 0
+    t0 = time.perf_counter()
+    while got.value:
+        N.check(L.bc_reader_read_raw(h, N.ptr(scratch), scratch.size, C.byref(got)))
+        total += got.value
+    dt_dec = time.perf_counter() - t0
+    L.bc_reader_close(h)
+    assert total == plain_size
+    print({"decoder_alone": COMP, "decoded_GB_per_s": round(total / dt_dec / 1e9, 3), "Mreads_per_s": round(n / dt_dec / 1e6, 1)})
 t0 = time.perf_counter()
 r = H.count_barcodes(fa, rd, rd2 if PAIRED else None)
 dt = time.perf_counter() - t0
@@ -56,7 +97,7 @@ print({"reads": n, "guides": G, "seconds": round(dt, 2), "Mreads_per_s": round(n
        "documented_reads": sum(r["doc"].values()), "undocumented_reads": r["undoc"].total(),
        "offset": r["bc_start1"], "flanks": r["flanks_fwd"]})
 
-print({"bulk_pass": ("device ingest (bc_stream_count_pair)" if PAIRED else "device ingest (bc_stream_count_file)") if r["shard_plan"] == "stride" and os.environ.get("BC_DEVICE_INGEST", "1") != "0" else "host front half",
+print({"bulk_pass": r["bulk_pass"],
        "bulk_Mreads_per_s": round(r["bulk_mreads_per_s"], 1), "bulk_GB_per_s_of_file": round(r["bulk_mreads_per_s"] * 46e6 / 1e9, 2),
        "undocumented_barcodes": len(r["undoc"]), "seconds": {k_: round(v, 2) for k_, v in r["seconds"].items()}})
 t0 = time.perf_counter()

@@ -690,3 +690,40 @@ def test_crispri_views_match_reference_class():
         for view in ("source_unique_targets", "mapped_targets", "unique_targets", "unambiguous_targets"):
             assert rec(getattr(lib, view)) == case[view], (case["pam"], view)
         assert [int(i) for i in lib.unambiguous_targets.index] == case["unambiguous_index"]
+
+
+def test_reader_raw_stream(tmp_path):
+    """bc_reader_read_raw: the decoded byte stream of a plain / .gz / .zst reads file, sequentially, in pieces of any
+    size (what the device ingest uploads of a compressed file); a stream cut short is an error, never a short file."""
+    import ctypes as Ct
+    from barcoder_amd import _native as N
+    raw = b"".join(b"ACGT" * 9 + bytes([65 + i % 4]) + b"\n" for i in range(50_000))
+    files = {"a.reads": raw, "a.reads.gz": gzip.compress(raw, 1)}
+    z = _zstd_compress(raw)
+    if z is not None:
+        files["a.reads.zst"] = z
+    L = N.load()
+    for name, data in files.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        for piece in (1 << 20, 70_001):
+            h = N.vp()
+            N.check(L.bc_reader_open(str(p).encode(), Ct.byref(h)))
+            buf, got, out = np.empty(piece, np.uint8), Ct.c_uint64(1), []
+            while True:
+                N.check(L.bc_reader_read_raw(h, N.ptr(buf), piece, Ct.byref(got)))
+                if not got.value:
+                    break
+                out.append(buf[:got.value].tobytes())
+            L.bc_reader_close(h)
+            assert b"".join(out) == raw, (name, piece)
+        if name != "a.reads":
+            cut = tmp_path / ("cut_" + name)
+            cut.write_bytes(data[:len(data) // 2])
+            h = N.vp()
+            N.check(L.bc_reader_open(str(cut).encode(), Ct.byref(h)))
+            buf, got = np.empty(1 << 20, np.uint8), Ct.c_uint64(1)
+            with pytest.raises(ValueError, match="truncated|damaged"):
+                while got.value:
+                    N.check(L.bc_reader_read_raw(h, N.ptr(buf), buf.size, Ct.byref(got)))
+            L.bc_reader_close(h)

@@ -85,6 +85,101 @@ def test_device_ingest_equals_host_front_half(gpu_device, tmp_path, monkeypatch,
     assert dev["bulk_mreads_per_s"] > 0
 
 
+def _zstd_compress(raw: bytes):
+    import ctypes
+    try:
+        z = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    cap = z.ZSTD_compressBound(len(raw))
+    out = ctypes.create_string_buffer(cap)
+    n = z.ZSTD_compress(out, cap, raw, len(raw), 1)
+    return out.raw[:n]
+
+
+@pytest.mark.parametrize("ext,fastq,reverse", [(".gz", False, False), (".gz", True, True), (".zst", False, True)])
+def test_compressed_input_takes_the_device_path(gpu_device, tmp_path, monkeypatch, ext, fastq, reverse):
+    """heuristicount.py:60-72, :100-153: .gz / .zst are first-class inputs.  A compressed file goes through the same
+    device path as its plain twin — decoded on the host 16 MiB at a time into the upload buffers — and gives the same
+    documented counts in the same first-seen order, undocumented table, odd windows and read total as the plain file on
+    the device path and as the compressed file on the host front half; split into parts (chunk c -> part c % n: several
+    ranks over one compressed file) the parts add up to the whole; a damaged stream is an error, not a short file."""
+    import gzip
+    from barcoder_amd import DeviceLibrary, encoding as E, heuristicount as H, ingest as I, synth as S
+    rng = np.random.default_rng(29 + fastq)
+    k = 20
+    lib = S.library(2500, k)
+    lib_s = E.unpack_kmers(lib, k)
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">g{i}\n{s}\n" for i, s in enumerate(lib_s)))
+    n = 330_000 if fastq else 800_000                    # three device chunks of decoded text either way
+    plain = _make_file(tmp_path, "c.fastq" if fastq else "c.reads", n, k, fastq, rng, lib_s, reverse, trailing_newline=not fastq)
+    raw = open(plain, "rb").read()
+    assert len(raw) > 33 << 20
+    comp = plain + ext
+    if ext == ".gz":
+        with gzip.open(comp, "wb", compresslevel=1) as f:
+            f.write(raw)
+    else:
+        z = _zstd_compress(raw)
+        if z is None:
+            pytest.skip("libzstd not available")
+        open(comp, "wb").write(z)
+    monkeypatch.setenv("BC_DEVICE_INGEST", "1")
+    a = H.count_barcodes(str(fa), plain, device=gpu_device, max_mismatch=1)
+    b = H.count_barcodes(str(fa), comp, device=gpu_device, max_mismatch=1)
+    monkeypatch.setenv("BC_DEVICE_INGEST", "0")
+    c = H.count_barcodes(str(fa), comp, device=gpu_device, max_mismatch=1, chunk_reads=150_001)
+    assert "device ingest" in b["bulk_pass"] and "device ingest" not in c["bulk_pass"], (b["bulk_pass"], c["bulk_pass"])
+    for other in (b, c):
+        assert other["total_reads"] == a["total_reads"] == n
+        assert list(other["doc"].items()) == list(a["doc"].items())
+        assert dict(other["undoc"].items()) == dict(a["undoc"].items())
+        assert other["undoc"].extra == a["undoc"].extra
+    assert sum(a["doc"].values()) > 0.7 * n and len(a["undoc"]) > 500 and len(a["undoc"].extra) > 0
+    # parts: chunk c of the decoded stream belongs to part c % 3; keys are read indices in the whole file
+    dl = DeviceLibrary(lib, k, gpu_device)
+    G = lib.size
+    start, Lf, Rf = (5, L_FLANK, R_FLANK)
+    if reverse:
+        from barcoder_amd.heuristicount import rev_comp
+        start, Lf, Rf = 5, rev_comp(R_FLANK), rev_comp(L_FLANK)  # (the window starts at its left flank, as in a forward read)
+        assert a["bc_start2"] == 15 and a["need_swap"]
+
+    def run(parts):
+        cc, ff = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
+        tabs, nn, odd = [], 0, []
+        for p_ in parts:
+            r = I.stream_count_file(dl.handle, comp, 0, 0, start, Lf, Rf, reverse, 1, "auto", 0, cc, ff, n_threads=3, part=p_)
+            tabs.append((r.u_words, r.u_counts, r.u_first))
+            nn += r.n_reads
+            odd += r.odd
+        uw, uc, uf = H.merge_undocumented(tabs)
+        return nn, cc, ff, uw, uc, uf, sorted(odd)
+    whole, split = run([None]), run([(0, 3), (1, 3), (2, 3)])
+    assert whole[0] == split[0] == n and int(whole[1].sum()) == sum(a["doc"].values())
+    for x, y in zip(whole[1:6], split[1:6]):
+        np.testing.assert_array_equal(x, y)
+    assert whole[6] == split[6]
+    # a stream cut short is an error
+    cut = str(tmp_path / ("cut.fastq" if fastq else "cut.reads")) + ext
+    data = open(comp, "rb").read()
+    open(cut, "wb").write(data[:len(data) * 2 // 3])
+    cc, ff = np.zeros(G, np.uint64), np.full(G, np.iinfo(np.uint64).max, np.uint64)
+    with pytest.raises(ValueError, match="truncated|damaged"):
+        I.stream_count_file(dl.handle, cut, 0, 0, start, Lf, Rf, reverse, 0, "auto", 0, cc, ff)
+    with pytest.raises(ValueError, match="byte ranges"):
+        N_ = __import__("barcoder_amd._native", fromlist=["x"])
+        h = N_.vp()
+        import ctypes as C
+        N_.check(N_.load().bc_stream_count_file(dl.handle, comp.encode(), 10, 1000, start, Lf.encode(), len(Lf), Rf.encode(), len(Rf),
+                                                1 if reverse else 0, 0, N_.ALGOS["auto"], 0, 0, N_.ptr(cc), N_.ptr(ff), C.byref(h)))
+
+
 def test_stream_byte_ranges_tile_the_file(gpu_device, tmp_path):
     """Record-aligned byte ranges (what the ranks of `--gpus N` get) add up to the whole file: counts summed, keys
     min'ed, undocumented tables merged — for .reads and FASTQ."""
