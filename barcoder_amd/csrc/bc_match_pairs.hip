@@ -64,6 +64,18 @@ using namespace bc;
 // any budget <= 3 (see the header of this file).
 struct PairBest { uint32_t mind, cnt, bidx; };
 
+// Slab geometry of the pair tables: 64-byte slabs of fifteen rests + tail (about 6 guides per bucket).  Round 4 built the
+// form round 3's notes asked for — 32-byte slabs of seven rests under a key one base longer (1.5 guides per bucket at 1e5:
+// a visit scans 8 slots instead of 16, a quad fetches two mates' slabs per turn, two turns instead of four) — and
+// measured it SLOWER at every library size: 45.3 against 47.3 G reads/s at 1e5 guides (best grouping), 22.6 / 23.9 at
+// 3e5, 8.3 / 10.3 at 1e6 (profiles/r04_d3_slab32_ab.txt): halving the scan doubles the tables (2.1 MB each), and the
+// passes' time follows what a group keeps in the L2, not the instruction count.  Kept as the compile-time A/B
+// (-DBC_PAIR_SLAB32=1); tests/test_match_gpu.py passes in both forms.
+#ifndef BC_PAIR_SLAB32
+#define BC_PAIR_SLAB32 0
+#endif
+constexpr uint32_t PSW = BC_PAIR_SLAB32 ? 8u : 16u;   // words per slab (the last one: {next << 4 | count})
+
 __device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t one, uint32_t zero) { return (m & one) | (~m & zero); }
 template <int J>
 __device__ __forceinline__ uint32_t qb(uint32_t v) { return quad_perm<J * 0x55>(v); }  // lane J of the quad, to the whole quad
@@ -75,6 +87,19 @@ __device__ __forceinline__ uint32_t qb(uint32_t v) { return quad_perm<J * 0x55>(
 template <int J>
 __device__ __forceinline__ uint32_t scan4(const u32x4& w, uint32_t rest, uint32_t nb) {
     const uint32_t rj = qb<J>(rest);
+    const uint32_t e[4] = {w.x, w.y, w.z, w.w};
+    uint32_t f = 0;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        const uint32_t x = rj ^ e[i];
+        const uint32_t mm = (x | (x >> 16)) & 0xFFFFu;
+        f = __builtin_amdgcn_alignbit(f, (uint32_t)__popc(mm) + nb, 31);  // (f << 1) | sign
+    }
+    return f;  // four bits
+}
+
+// the same against a rest that is already the right mate's (32-byte slabs: the mate depends on the lane)
+__device__ __forceinline__ uint32_t scan4r(const u32x4& w, uint32_t rj, uint32_t nb) {
     const uint32_t e[4] = {w.x, w.y, w.z, w.w};
     uint32_t f = 0;
 #pragma unroll
@@ -112,27 +137,44 @@ __device__ __forceinline__ void pairs_lookup_tables(const PairParams& pp, int t0
             // makes every wait a wait for everything in flight, the next round's list entry included)
             typedef const u32x4 __attribute__((address_space(1)))* slab_ptr;
             typedef const uint32_t __attribute__((address_space(1)))* word_ptr;
-            const slab_ptr base = (slab_ptr)(uintptr_t)T.rests + q;
-            const u32x4 w0 = base[(size_t)qb<0>(slab) * 4u], w1 = base[(size_t)qb<1>(slab) * 4u];
-            const u32x4 w2 = base[(size_t)qb<2>(slab) * 4u], w3 = base[(size_t)qb<3>(slab) * 4u];
-            if (!hooked) { hook(); hooked = true; }
-            const uint32_t fl = scan4<0>(w0, rest, ~max_mm) | (scan4<1>(w1, rest, ~max_mm) << 4) | (scan4<2>(w2, rest, ~max_mm) << 8) |
-                                (scan4<3>(w3, rest, ~max_mm) << 12);
-            // bits [4 q, 4 q + 4) of every quad lane's flags belong to this lane's slab: entries 4 Q ... 4 Q + 3 from lane Q
-            const uint32_t sh = 4u * q;
-            uint32_t cand = ((qb<0>(fl) >> sh) & 15u) | (((qb<1>(fl) >> sh) & 15u) << 4) | (((qb<2>(fl) >> sh) & 15u) << 8) |
-                            (((qb<3>(fl) >> sh) & 15u) << 12);
-            // the slab's last word {next << 4 | count} arrived on quad lane 3
-            const uint32_t x0 = qb<3>(w0.w), x1 = qb<3>(w1.w), x2 = qb<3>(w2.w), x3 = qb<3>(w3.w);
-            const uint32_t q0 = 0u - (q & 1u), q1 = 0u - (q >> 1);
-            const uint32_t tail = bit_select(q1, bit_select(q0, x3, x2), bit_select(q0, x1, x0));
+            uint32_t cand, tail;
+            if constexpr (PSW == 8u) {
+                // 32-byte slabs: two mates' slabs per turn — in turn 0 lanes 0, 1 take the halves of mate 0's slab and
+                // lanes 2, 3 those of mate 1's, in turn 1 mates 2 and 3 (quad_perm [0,0,1,1] / [2,2,3,3]); one tag
+                // look-up per 64 bytes requested when the two slabs happen to share a line, two otherwise
+                const slab_ptr base = (slab_ptr)(uintptr_t)T.rests + (q & 1u);
+                const u32x4 w0 = base[(size_t)quad_perm<0x50>(slab) * 2u], w1 = base[(size_t)quad_perm<0xFA>(slab) * 2u];
+                if (!hooked) { hook(); hooked = true; }
+                const uint32_t fl = scan4r(w0, quad_perm<0x50>(rest), ~max_mm) | (scan4r(w1, quad_perm<0xFA>(rest), ~max_mm) << 4);
+                // this lane's slab came in turn q >> 1, its low half on lane 2 (q & 1), its high half on the lane after
+                const uint32_t sh = 4u * (q >> 1);
+                cand = ((quad_perm<0x88>(fl) >> sh) & 15u) | (((quad_perm<0xDD>(fl) >> sh) & 15u) << 4);
+                // the slab's last word {next << 4 | count} is the high half's fourth
+                const uint32_t x0 = quad_perm<0xDD>(w0.w), x1 = quad_perm<0xDD>(w1.w);
+                tail = (q >> 1) ? x1 : x0;
+            } else {
+                const slab_ptr base = (slab_ptr)(uintptr_t)T.rests + q;
+                const u32x4 w0 = base[(size_t)qb<0>(slab) * 4u], w1 = base[(size_t)qb<1>(slab) * 4u];
+                const u32x4 w2 = base[(size_t)qb<2>(slab) * 4u], w3 = base[(size_t)qb<3>(slab) * 4u];
+                if (!hooked) { hook(); hooked = true; }
+                const uint32_t fl = scan4<0>(w0, rest, ~max_mm) | (scan4<1>(w1, rest, ~max_mm) << 4) | (scan4<2>(w2, rest, ~max_mm) << 8) |
+                                    (scan4<3>(w3, rest, ~max_mm) << 12);
+                // bits [4 q, 4 q + 4) of every quad lane's flags belong to this lane's slab: entries 4 Q ... 4 Q + 3 from lane Q
+                const uint32_t sh = 4u * q;
+                cand = ((qb<0>(fl) >> sh) & 15u) | (((qb<1>(fl) >> sh) & 15u) << 4) | (((qb<2>(fl) >> sh) & 15u) << 8) |
+                       (((qb<3>(fl) >> sh) & 15u) << 12);
+                // the slab's last word {next << 4 | count} arrived on quad lane 3
+                const uint32_t x0 = qb<3>(w0.w), x1 = qb<3>(w1.w), x2 = qb<3>(w2.w), x3 = qb<3>(w3.w);
+                const uint32_t q0 = 0u - (q & 1u), q1 = 0u - (q >> 1);
+                tail = bit_select(q1, bit_select(q0, x3, x2), bit_select(q0, x1, x0));
+            }
             const uint32_t cnt = tail & 15u, next = tail >> 4;
-            cand &= (1u << cnt) - 1u;  // (count <= 15: the last word itself never counts)
+            cand &= (1u << cnt) - 1u;  // (count <= PSW - 1: the last word itself never counts)
             if (!live) cand = 0u;
             while (cand) {
                 const uint32_t e = (uint32_t)__ffs((int)cand) - 1u;
                 cand &= cand - 1u;
-                const uint32_t x = rest ^ ((word_ptr)(uintptr_t)T.rests)[(size_t)slab * 16u + e];  // (the quad has just brought the line into the L1)
+                const uint32_t x = rest ^ ((word_ptr)(uintptr_t)T.rests)[(size_t)slab * PSW + e];  // (the quad has just brought the line into the L1)
                 const uint32_t mm = (x | (x >> 16)) & 0xFFFFu;
                 // counted here only if this table's pair is the first pair of the guide's clean pieces: what is left
                 // of pieces a and b is clean, every earlier piece is dirty
@@ -141,7 +183,7 @@ __device__ __forceinline__ void pairs_lookup_tables(const PairParams& pp, int t0
                 for (int c = 0; c < 3; ++c) ok = ok && (c >= (int)T.n_other || (mm & T.other[c]) != 0u);
                 if (ok) {  // a guide within the budget — its index comes from the parallel array
                     const uint32_t d = (uint32_t)__popc(mm);
-                    const uint32_t g = ((word_ptr)(uintptr_t)T.gidx)[(size_t)slab * 16u + e];
+                    const uint32_t g = ((word_ptr)(uintptr_t)T.gidx)[(size_t)slab * PSW + e];
                     if (d < b.mind) { b.mind = d; b.cnt = 1u; b.bidx = g; }
                     else if (d == b.mind) { ++b.cnt; b.bidx = min(b.bidx, g); }
                 }
@@ -418,7 +460,8 @@ int build_pair_index(bc_lib* lib) {
     for (int c = 0; c < 5; ++c) { p_len[c] = k / 5 + (c < k % 5 ? 1 : 0); p_start[c] = at; at += p_len[c]; }
     // key length in bases: ~6 guides per bucket, at least k - 16 (the rest must fit 16 bases per plane), at most 9
     int want = 1;
-    while (want < 9 && ((double)lib->G / (double)(1ull << (2 * want))) > 8.0) ++want;
+    // (32-byte slabs hold seven: about 1.5 per bucket; 64-byte slabs fifteen: about 6)
+    while (want < 9 && ((double)lib->G / (double)(1ull << (2 * want))) > (PSW == 8u ? 2.0 : 8.0)) ++want;
     want = std::max(want, k - 16);
     if (want > 9) return BC_OK;
     // the ten tables are independent: one host thread each (50 ms single-threaded at 1e5 guides)
@@ -462,29 +505,29 @@ int build_pair_index(bc_lib* lib) {
         // slabs of 15 rests + tail {next << 4 | count}; the guide indices in a parallel array
         std::vector<uint32_t>& rests = built[t].rests;
         std::vector<uint32_t>& gix = built[t].gidx;
-        rests.assign((size_t)nb * 16, 0u);
-        gix.assign((size_t)nb * 16, 0u);
+        rests.assign((size_t)nb * PSW, 0u);
+        gix.assign((size_t)nb * PSW, 0u);
         for (uint32_t bkt = 0; bkt < nb; ++bkt) {
             size_t cur = bkt;
             uint32_t pos = 0;
             for (uint32_t j = cnt[bkt]; j < cnt[bkt + 1]; ++j) {
-                if (pos == 15) {
-                    const size_t nxt = rests.size() / 16;
-                    rests.resize(rests.size() + 16, 0u);
-                    gix.resize(gix.size() + 16, 0u);
-                    rests[cur * 16 + 15] = ((uint32_t)nxt << 4) | 15u;
+                if (pos == PSW - 1u) {
+                    const size_t nxt = rests.size() / PSW;
+                    rests.resize(rests.size() + PSW, 0u);
+                    gix.resize(gix.size() + PSW, 0u);
+                    rests[cur * PSW + PSW - 1u] = ((uint32_t)nxt << 4) | (PSW - 1u);
                     cur = nxt;
                     pos = 0;
                 }
                 const uint32_t g = order[j];
                 const uint64_t v = lib->h_guides[g];
-                rests[cur * 16 + pos] = pair_rest_plane(T, (uint32_t)v) | (pair_rest_plane(T, (uint32_t)(v >> 32)) << 16);
-                gix[cur * 16 + pos] = g;
+                rests[cur * PSW + pos] = pair_rest_plane(T, (uint32_t)v) | (pair_rest_plane(T, (uint32_t)(v >> 32)) << 16);
+                gix[cur * PSW + pos] = g;
                 ++pos;
             }
-            rests[cur * 16 + 15] = pos;  // last slab of the bucket: no next
+            rests[cur * PSW + PSW - 1u] = pos;  // last slab of the bucket: no next
         }
-        if ((rests.size() / 16) >> 28) return;  // slab numbers travel in 28 bits
+        if ((rests.size() / PSW) >> 28) return;  // slab numbers travel in 28 bits
         built[t].T = T;
         built[t].ok = true;
     };
@@ -504,7 +547,7 @@ int build_pair_index(bc_lib* lib) {
         built[t].T.rests = d_rests;
         built[t].T.gidx = d_gidx;
         pp.t[pp.ntab++] = built[t].T;
-        lib->pair_slabs.push_back((uint32_t)(built[t].rests.size() / 16));
+        lib->pair_slabs.push_back((uint32_t)(built[t].rests.size() / PSW));
     }
     std::vector<PairParams> one(1, pp);
     PairParams* d_pp;
@@ -574,8 +617,8 @@ int launch_cascade_stage2(bc_lib* lib, int max_mm, const uint64_t* d_reads, uint
     const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + BLOCK - 1) / BLOCK, (uint64_t)lib->knobs.pair_grid));  // 8 workgroups per CU
     for (int t0 = 0; t0 < ntab;) {  // greedy groups: tables in order while their slabs fit the budget, at least one
         int t1 = t0 + 1;
-        uint64_t bytes = (uint64_t)lib->pair_slabs[(size_t)t0] * 64u;
-        while (t1 < ntab && bytes + (uint64_t)lib->pair_slabs[(size_t)t1] * 64u <= budget) bytes += (uint64_t)lib->pair_slabs[(size_t)t1++] * 64u;
+        uint64_t bytes = (uint64_t)lib->pair_slabs[(size_t)t0] * (PSW * 4u);
+        while (t1 < ntab && bytes + (uint64_t)lib->pair_slabs[(size_t)t1] * (PSW * 4u) <= budget) bytes += (uint64_t)lib->pair_slabs[(size_t)t1++] * (PSW * 4u);
         hipLaunchKernelGGL(k_cascade_pass, dim3(pgrid), dim3(BLOCK), 0, st, lib->d_pairs, t0, t1, t0 == 0 ? 1 : 0, t1 == ntab ? 1 : 0,
                            (const uint64_t*)w->casc_dread, (const uint32_t*)w->casc_dpos, w->casc_state,
                            (const unsigned long long*)w->casc_count, max_mm, o.best_idx, o.best_dist, o.n_best, o.counts, o.first_seen,

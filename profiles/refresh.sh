@@ -1,12 +1,12 @@
 #!/bin/bash
 # Regenerate the round's measurement artefacts on the GPU box (one gpurun call):
 #   make -C barcoder_amd/csrc diag          # here, before the call: the stage-attribution build travels with the tree
-#   gpurun --timeout 1200 -- 'bash profiles/refresh.sh r03'   -> gpurun_out/refresh_r03/ ; copy what is judged into profiles/
+#   gpurun --timeout 1200 -- 'bash profiles/refresh.sh r04'   -> gpurun_out/refresh_r04/ ; copy what is judged into profiles/
 # Kernel trace and every PMC set run as separate rocprofv3 invocations (run_prof.sh); nothing here combines --pmc with
-# system / runtime tracing.  STEPS="prof bench variants exact pam diag d3 e2e targets sweep" selects parts.
+# system / runtime tracing.  STEPS="prof bench variants exact pam diag mix d3 e2e targets sweep" selects parts.
 set -u
-TAG=${1:-r03}
-STEPS=${STEPS:-prof bench variants exact pam diag d3 e2e targets sweep}
+TAG=${1:-r04}
+STEPS=${STEPS:-prof bench variants exact pam diag mix d3 e2e targets sweep}
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/refresh_$TAG
 mkdir -p $OUT
@@ -61,6 +61,10 @@ if has diag; then
   echo "stage attribution" >> $OUT/progress.log
   DIAGS="0 1 3" bash profiles/diag.sh > $OUT/${TAG}_stage_attribution.txt 2>&1
 fi
+if has mix; then   # read-mix sweep of the d <= 2 matcher: 5 / 10 (standard) / 20 / 50 % reads that match nothing
+  echo "mix sweep" >> $OUT/progress.log
+  bash profiles/mix_sweep.sh > $OUT/${TAG}_mix_sweep.txt 2>&1
+fi
 if has d3; then
   echo "d3 kernels" >> $OUT/progress.log
   bash profiles/ktime.sh d3 --max-mismatch 3 > $OUT/${TAG}_d3_kernels.txt 2>&1
@@ -70,6 +74,8 @@ if has e2e; then
   BC_LIB_PROF=1 BC_SAMPLE_PROF=1 python3 profiles/e2e_bench.py 1e8 > $OUT/${TAG}_e2e_bench.txt 2>&1
   python3 profiles/e2e_bench.py 5e7 100000 paired > $OUT/${TAG}_e2e_paired.txt 2>&1
   BC_LIB_PROF=1 BC_SAMPLE_PROF=1 BC_STREAM_PROF=1 python3 profiles/e2e_bench.py 1e7 > $OUT/${TAG}_e2e_1e7.txt 2>&1   # a small job: the fixed costs
+  python3 profiles/e2e_bench.py 2e7 100000 gz > $OUT/${TAG}_e2e_gz.txt 2>&1     # compressed input: the decoder alone, then the job
+  python3 profiles/e2e_bench.py 2e7 100000 zst > $OUT/${TAG}_e2e_zst.txt 2>&1
 fi
 if has targets; then
   echo "targets" >> $OUT/progress.log
