@@ -978,13 +978,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             // non-temporal: nothing in this kernel touches these lines again, the tables should keep the L2 (3 % measured)
             const u32x4 t = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2], (uint32_t)idx[3]};
             const uint64_t st0 = (diag & 64u) ? (uint64_t)(blockIdx.x & 255u) * WAVE_T : tile0;  // BC_DIAG 64: results into 0.4 MB (timing experiment)
-            __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(o.best_idx + st0) + (p0 >> 2));
+            stream_store(t, reinterpret_cast<u32x4*>(o.best_idx + st0) + (p0 >> 2));
             if (o.best_dist) {
-                __builtin_nontemporal_store(dist[0] | (dist[1] << 8) | (dist[2] << 16) | (dist[3] << 24),
+                stream_store(dist[0] | (dist[1] << 8) | (dist[2] << 16) | (dist[3] << 24),
                                             reinterpret_cast<uint32_t*>(o.best_dist + st0) + (p0 >> 2));
             }
             if (o.n_best) {
-                __builtin_nontemporal_store(nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24),
+                stream_store(nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24),
                                             reinterpret_cast<uint32_t*>(o.n_best + st0) + (p0 >> 2));
             }
         } else {

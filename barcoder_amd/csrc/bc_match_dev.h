@@ -75,10 +75,45 @@ namespace {
 using namespace bc;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Result / record stores of the wave matcher: nothing in the kernel touches these lines again.  BC_STORE_POLICY picks the
+// cache-policy bits (compile-time experiment, profiles/r04_store_policy_ab.txt): 0 = nt (the compiler's non-temporal
+// store), 1 = sc0 sc1 nt (write through to memory, streaming), 2 = sc1 nt, 3 = no bits.
+#ifndef BC_STORE_POLICY
+#define BC_STORE_POLICY 0
+#endif
+__device__ __forceinline__ void stream_store(u32x4 v, u32x4* p) {
+#if BC_STORE_POLICY == 0 || !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, p);
+#elif BC_STORE_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+#elif BC_STORE_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void stream_store(uint32_t v, uint32_t* p) {
+#if BC_STORE_POLICY == 0 || !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, p);
+#elif BC_STORE_POLICY == 1
+    asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+#elif BC_STORE_POLICY == 2
+    asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
 // streaming input: keep it out of the L2's way (the lookup tables live there)
+#ifndef BC_LOAD_POLICY
+#define BC_LOAD_POLICY 0   // read stream: 0 = non-temporal loads, 1 = plain loads (compile-time experiment)
+#endif
 __device__ __forceinline__ void load_reads4(const uint64_t* p, uint64_t (&r)[4]) {
     const u32x4* q = reinterpret_cast<const u32x4*>(p);
+#if BC_LOAD_POLICY == 0
     u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+#else
+    u32x4 a = q[0], b = q[1];
+#endif
     r[0] = (uint64_t)a.x | ((uint64_t)a.y << 32); r[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
     r[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); r[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
 }
@@ -117,7 +152,7 @@ __device__ __forceinline__ void part_emit(const PartOut& P, uint32_t tile, const
     for (uint32_t d = lane; d < (used >> 1); d += 64u) {
         const uint32_t r = d >> dw_log2, within = d & ((1u << dw_log2) - 1u);
         const uint32_t v = ovf ? 0xFFFFFFFFu : sw[d];
-        __builtin_nontemporal_store(v, (uint32_t*)(line0 + (size_t)r * stride + within * 4u));
+        stream_store(v, (uint32_t*)(line0 + (size_t)r * stride + within * 4u));
     }
 }
 
