@@ -94,7 +94,10 @@ __global__ __launch_bounds__(BLOCK) void k_lines_to_windows(const uint8_t* __res
                                                             uint64_t gri0, Geometry g, uint64_t key0,
                                                             uint64_t* __restrict__ packed, uint8_t* __restrict__ status,
                                                             OddRec* __restrict__ odd, uint32_t odd_cap,
-                                                            uint32_t* __restrict__ flags, uint32_t* __restrict__ woff) {
+                                                            uint32_t* __restrict__ flags, uint32_t* __restrict__ woff,
+                                                            char* __restrict__ otext) {
+    // otext (paired runs of barcodes of more than 32 nt): the barcode as the library spells it, kk characters at the
+    // read's index — the pairing and the verification run after both files are in
     uint32_t* n_odd = flags;
     const int kk = g.text_k ? g.text_k : g.k;  // characters of a barcode
     const uint64_t n_nl = *n_nl_p;
@@ -147,6 +150,13 @@ __global__ __launch_bounds__(BLOCK) void k_lines_to_windows(const uint8_t* __res
                         else
                             w = text_hash64_at((size_t)kk, [&](size_t i) { return sq[i]; });
                         woff[r] = (uint32_t)(a + (uint64_t)ws + (uint64_t)g.L_len);
+                        if (otext) {
+                            char* dst = otext + r * (uint64_t)kk;
+                            for (int j = 0; j < kk; ++j) {
+                                const uint8_t c = g.reverse ? sq[kk - 1 - j] : sq[j];
+                                dst[j] = (char)(!g.reverse ? c : c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : 'C');
+                            }
+                        }
                         st = BC_WIN_OK;
                     }
                 } else if (n == wlen) {
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void k_long_verify_tally(int32_t* __restrict
     for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += stride) {
         const int32_t g = best_idx[r];
         if (g < 0) continue;
-        const uint8_t* sq = text + woff[r];
+        const uint8_t* sq = text + (woff ? (uint64_t)woff[r] : r * (uint64_t)kk);  // (no offsets: a store of kk characters per read)
         const char* lt = lib_text + (size_t)g * (size_t)kk;
         bool same = true;
         for (int j = 0; j < kk && same; ++j) same = oriented_char(sq, kk, reverse, j) == (uint8_t)lt[j];
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) void k_collect_misses_long(const int32_t* __
             const uint64_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             m_words[at] = packed[r];
             m_keys[at] = key0 + r;
-            const uint8_t* sq = text + woff[r];
+            const uint8_t* sq = text + (woff ? (uint64_t)woff[r] : r * (uint64_t)kk);
             char* dst = m_text + at * (uint64_t)kk;
             for (int j = 0; j < kk; ++j) dst[j] = (char)oriented_char(sq, kk, reverse, j);
         }
@@ -310,6 +320,29 @@ __global__ __launch_bounds__(BLOCK) void k_pair_flags(const uint64_t* __restrict
     const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += stride)
         flags[r] = (st1[r] == BC_WIN_OK && st2[r] == BC_WIN_OK && p1[r] == p2[r]) ? 0 : 1;
+}
+
+// ... barcodes of more than 32 nt: p1, p2 are text hashes; equal hashes must hold equal texts
+__global__ __launch_bounds__(BLOCK) void k_pair_flags_long(const uint64_t* __restrict__ p1, const uint8_t* __restrict__ st1,
+                                                           const uint64_t* __restrict__ p2, const uint8_t* __restrict__ st2,
+                                                           const char* __restrict__ t1, const char* __restrict__ t2, int kk,
+                                                           uint64_t n, uint8_t* __restrict__ flags) {
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += stride) {
+        bool ok = st1[r] == BC_WIN_OK && st2[r] == BC_WIN_OK && p1[r] == p2[r];
+        const char *a = t1 + r * (uint64_t)kk, *b = t2 + r * (uint64_t)kk;
+        for (int j = 0; ok && j < kk; ++j) ok = a[j] == b[j];
+        flags[r] = ok ? 0 : 1;
+    }
+}
+// the kk-character texts of the listed reads (pairs with an odd window: the packed mate's barcode goes back as text)
+__global__ __launch_bounds__(BLOCK) void k_gather_texts(const uint64_t* __restrict__ idx, uint64_t m, const char* __restrict__ t,
+                                                        int kk, char* __restrict__ out) {
+    const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= m) return;
+    const char* src = t + idx[j] * (uint64_t)kk;
+    char* dst = out + j * (uint64_t)kk;
+    for (int c = 0; c < kk; ++c) dst[c] = src[c];
 }
 
 __global__ __launch_bounds__(BLOCK) void k_gather_pairs(const uint64_t* __restrict__ idx, uint64_t m,
@@ -454,21 +487,26 @@ struct MissList {
 // finished; growing takes the exclusive side, so nothing is in flight while the arrays move.
 struct WindowStore {
     DevBuf packed, status;   // uint64[cap], uint8[cap]
+    DevBuf texts;            // char[cap][text_k]: barcodes of more than 32 nt, as the library spells them (text_k > 0)
+    int text_k = 0;
     uint64_t cap = 0, estimate = 0;
     std::shared_mutex m;
     int grow(uint64_t need) {  // caller holds the exclusive lock
         const uint64_t ncap = std::max<uint64_t>(std::max<uint64_t>(cap * 2, need + (estimate && estimate < need ? 16 : 65536)), estimate);
-        DevBuf np_, ns;
+        DevBuf np_, ns, nt;
         int rc;
         if ((rc = np_.reserve(ncap * 8)) != BC_OK) return rc;
         if ((rc = ns.reserve(ncap)) != BC_OK) return rc;
+        if (text_k && (rc = nt.reserve(ncap * (uint64_t)text_k)) != BC_OK) return rc;
         if (cap) {
             BC_HIP(hipMemcpy(np_.p, packed.p, cap * 8, hipMemcpyDeviceToDevice));
             BC_HIP(hipMemcpy(ns.p, status.p, cap, hipMemcpyDeviceToDevice));
+            if (text_k) BC_HIP(hipMemcpy(nt.p, texts.p, cap * (uint64_t)text_k, hipMemcpyDeviceToDevice));
         }
         BC_HIP(hipDeviceSynchronize());
         std::swap(np_.p, packed.p); std::swap(np_.cap, packed.cap);
         std::swap(ns.p, status.p); std::swap(ns.cap, status.cap);
+        std::swap(nt.p, texts.p); std::swap(nt.cap, texts.cap);
         cap = ncap;
         return BC_OK;
     }
@@ -686,6 +724,7 @@ int run_file(FileJob& J) {
                 } drain{s.st};
                 uint64_t* d_packed;
                 uint8_t* d_status;
+                char* d_otext = nullptr;
                 if (store) {  // the windows go to the run-wide arrays, at the reads' own indices
                     window_lock = std::shared_lock<std::shared_mutex>(store->m);
                     if (gri1 > store->cap) {
@@ -698,6 +737,7 @@ int run_file(FileJob& J) {
                     }
                     d_packed = (uint64_t*)store->packed.p + gri0;
                     d_status = (uint8_t*)store->status.p + gri0;
+                    if (store->text_k) d_otext = (char*)store->texts.p + gri0 * (uint64_t)store->text_k;
                 } else {
                     if ((rc2 = s.packed.reserve(n_reads * 8 + 64)) != BC_OK) return rc2;
                     if ((rc2 = s.status.reserve(n_reads + 64)) != BC_OK) return rc2;
@@ -721,7 +761,7 @@ int run_file(FileJob& J) {
                 hipLaunchKernelGGL(k_lines_to_windows, dim3(grid_for(n_own)), dim3(BLOCK), 0, s.st, (const uint8_t*)s.text.p,
                                    nbytes, (const uint32_t*)s.nl.p, (const uint64_t*)s.d_n, nl_cap, n_own, virt,
                                    hi < fsize ? 1 : 0, line_base, gri0, g, key0, d_packed, d_status, (OddRec*)s.odd.p,
-                                   odd_cap, s.d_nodd, (uint32_t*)s.woff.p);
+                                   odd_cap, s.d_nodd, (uint32_t*)s.woff.p, d_otext);
                 BC_HIP(hipGetLastError());
                 if (!store && g.text_k) {
                     // barcodes of more than 32 nt: the exact table on the text hashes (no tally: a hit is a hint), the
@@ -1158,12 +1198,11 @@ int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_b
                                const char* R_rev, int R_rev_len, int max_mismatch, int algo, uint64_t key_base, int n_threads,
                                uint64_t* h_counts, uint64_t* h_first_seen, bc_stream_result** out) {
     if (!lib || !path_fwd || !path_rev || !out) { set_error("bc_stream_count_pair: null argument"); return BC_EINVAL; }
-    if (lib->text_k != 0) {
-        // a text-hash library (bc_lib_attach_text): its guides are hashes of barcodes of more than 32 nt, not k-mers —
-        // pairing packed 32-base windows against them would count nothing, silently
-        set_error("bc_stream_count_pair: barcodes of more than 32 nt are not paired on the device (library with attached texts)");
-        return BC_EINVAL;
-    }
+    // a text-hash library (bc_lib_attach_text: barcodes of more than 32 nt): the stores keep every window's text beside its
+    // hash (text_k bytes per read and file), pairs need equal hashes AND equal texts, a hit is verified against the
+    // library's text, exact match only
+    const int text_k = lib->text_k;
+    if (text_k && max_mismatch != 0) { set_error("bc_stream_count_pair: barcodes of more than 32 nt are matched exactly"); return BC_EINVAL; }
     uint32_t G = 0; int k = 0, device = 0;
     bc_lib_info(lib, &G, &k, &device);
     const auto t_begin = std::chrono::steady_clock::now();
@@ -1179,6 +1218,8 @@ int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_b
         if ((rc = file_kind(paths[f], "bc_stream_count_pair", &J[f].g.fastq)) != BC_OK) return rc;
         J[f].lib = lib; J[f].path = paths[f]; J[f].byte_begin = begins[f]; J[f].byte_end = ends_[f];
         J[f].n_threads = n_threads; J[f].key_base = key_base; J[f].store = &W[f];
+        J[f].g.text_k = text_k;
+        W[f].text_k = text_k;
     }
     if (is_compressed(paths[0]) || is_compressed(paths[1])) {
         // compressed mates: each file's decoder is one sequential thread at a time — both files at once, so the two
@@ -1212,8 +1253,10 @@ int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_b
         if (n == 0) return BC_OK;
         const uint64_t *p1 = (const uint64_t*)W[0].packed.p, *p2 = (const uint64_t*)W[1].packed.p;
         const uint8_t *s1 = (const uint8_t*)W[0].status.p, *s2 = (const uint8_t*)W[1].status.p;
-        // pairs with an odd window: both mates' windows back to the host (a packed mate is rebuilt from its word there)
+        // pairs with an odd window: both mates' windows back to the host (a packed mate is rebuilt from its word there —
+        // or, barcodes of more than 32 nt, from its text in the store)
         std::vector<uint64_t> keys;
+        std::vector<int64_t> ia, ib;  // the pair's entry in each file's odd list (-1: that mate is not odd)
         {
             size_t a = 0, b = 0;
             const auto &A = J[0].odd_all, &B = J[1].odd_all;
@@ -1221,17 +1264,16 @@ int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_b
                 const uint64_t ka = a < A.size() ? A[a].key : ~0ull, kb = b < B.size() ? B[b].key : ~0ull;
                 const uint64_t kk = std::min(ka, kb);
                 keys.push_back(kk);
-                res->pair_text1 += (ka == kk) ? A[a].text : std::string();
-                res->pair_text2 += (kb == kk) ? B[b].text : std::string();
-                res->pair_off1.push_back(res->pair_text1.size());
-                res->pair_off2.push_back(res->pair_text2.size());
+                ia.push_back(ka == kk ? (int64_t)a : -1);
+                ib.push_back(kb == kk ? (int64_t)b : -1);
                 if (ka == kk) ++a;
                 if (kb == kk) ++b;
             }
         }
         const uint64_t m = keys.size();
+        std::vector<char> tx1, tx2;  // long barcodes: the stored texts of the listed pairs' mates
         if (m) {
-            DevBuf d_idx, o1, o2, os1, os2;
+            DevBuf d_idx, o1, o2, os1, os2, ot1, ot2;
             int rc3;
             std::vector<uint64_t> idx(m);
             for (uint64_t j = 0; j < m; ++j) idx[j] = keys[j] - key_base;
@@ -1247,6 +1289,28 @@ int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_b
             BC_HIP(hipMemcpy(res->pair_p2.data(), o2.p, m * 8, hipMemcpyDeviceToHost));
             BC_HIP(hipMemcpy(res->pair_st1.data(), os1.p, m, hipMemcpyDeviceToHost));
             BC_HIP(hipMemcpy(res->pair_st2.data(), os2.p, m, hipMemcpyDeviceToHost));
+            if (text_k) {
+                if ((rc3 = ot1.reserve(m * (uint64_t)text_k)) != BC_OK || (rc3 = ot2.reserve(m * (uint64_t)text_k)) != BC_OK) return rc3;
+                hipLaunchKernelGGL(k_gather_texts, dim3((unsigned)((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, (const uint64_t*)d_idx.p, m,
+                                   (const char*)W[0].texts.p, text_k, (char*)ot1.p);
+                hipLaunchKernelGGL(k_gather_texts, dim3((unsigned)((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, (const uint64_t*)d_idx.p, m,
+                                   (const char*)W[1].texts.p, text_k, (char*)ot2.p);
+                BC_HIP(hipGetLastError());
+                tx1.resize(m * (size_t)text_k); tx2.resize(m * (size_t)text_k);
+                BC_HIP(hipMemcpy(tx1.data(), ot1.p, tx1.size(), hipMemcpyDeviceToHost));
+                BC_HIP(hipMemcpy(tx2.data(), ot2.p, tx2.size(), hipMemcpyDeviceToHost));
+            }
+        }
+        // the mates' texts: an odd mate's stripped read (kept by the host as the chunk went through); a packed mate's is
+        // empty — except for barcodes of more than 32 nt, whose packed word is a hash: then the barcode itself, as the
+        // library spells it (the caller rebuilds the window from it as it does from a packed word)
+        for (uint64_t j = 0; j < m; ++j) {
+            if (ia[j] >= 0) res->pair_text1 += J[0].odd_all[(size_t)ia[j]].text;
+            else if (text_k && res->pair_st1[j] == BC_WIN_OK) res->pair_text1.append(tx1.data() + j * (size_t)text_k, (size_t)text_k);
+            if (ib[j] >= 0) res->pair_text2 += J[1].odd_all[(size_t)ib[j]].text;
+            else if (text_k && res->pair_st2[j] == BC_WIN_OK) res->pair_text2.append(tx2.data() + j * (size_t)text_k, (size_t)text_k);
+            res->pair_off1.push_back(res->pair_text1.size());
+            res->pair_off2.push_back(res->pair_text2.size());
         }
         // pair, match, collect
         DevBuf d_counts, d_first, flags, best, d_cursor;
@@ -1260,20 +1324,39 @@ int bc_stream_count_pair_range(bc_lib* lib, const char* path_fwd, uint64_t fwd_b
         BC_HIP(hipMemset(d_counts.p, 0, (size_t)G * 4));
         BC_HIP(hipMemset(d_first.p, 0xFF, (size_t)G * 8));
         BC_HIP(hipMemset(d_cursor.p, 0, 16));
-        hipLaunchKernelGGL(k_pair_flags, dim3(grid_for(n)), dim3(BLOCK), 0, 0, p1, s1, p2, s2, n, (uint8_t*)flags.p);
-        BC_HIP(hipGetLastError());
-        if ((rc3 = bc_match_dev(lib, p1, (const uint8_t*)flags.p, n, max_mismatch, algo, (int32_t*)best.p, nullptr, nullptr,
-                                (uint32_t*)d_counts.p, (uint64_t*)d_first.p, key_base, nullptr)) != BC_OK) return rc3;
-        BC_HIP(hipDeviceSynchronize());
-        if ((rc3 = misses.reserve(n)) != BC_OK) return rc3;  // every pair could be a miss
-        hipLaunchKernelGGL(k_collect_misses, dim3(grid_for(n)), dim3(BLOCK), 0, 0, (const int32_t*)best.p, p1, n, kmer_mask(k),
-                           key_base, (uint64_t*)misses.words.p, (uint64_t*)misses.keys.p, (unsigned long long*)d_cursor.p);
+        misses.text_k = text_k;
+        if (text_k) {
+            // barcodes of more than 32 nt: equal hashes AND equal texts pair; the exact table answers with a hint (no
+            // tally), the library's text decides, the verified hits are tallied, the misses keep their texts
+            hipLaunchKernelGGL(k_pair_flags_long, dim3(grid_for(n)), dim3(BLOCK), 0, 0, p1, s1, p2, s2, (const char*)W[0].texts.p,
+                               (const char*)W[1].texts.p, text_k, n, (uint8_t*)flags.p);
+            BC_HIP(hipGetLastError());
+            if ((rc3 = bc_match_dev(lib, p1, (const uint8_t*)flags.p, n, 0, BC_ALGO_HASH, (int32_t*)best.p, nullptr, nullptr, nullptr,
+                                    nullptr, key_base, nullptr)) != BC_OK) return rc3;
+            hipLaunchKernelGGL(k_long_verify_tally, dim3(grid_for(n)), dim3(BLOCK), 0, 0, (int32_t*)best.p, (const uint8_t*)W[0].texts.p,
+                               (const uint32_t*)nullptr, lib->d_text, text_k, 0, n, key_base, (uint32_t*)d_counts.p, (uint64_t*)d_first.p);
+            BC_HIP(hipGetLastError());
+            BC_HIP(hipDeviceSynchronize());
+            if ((rc3 = misses.reserve(n)) != BC_OK) return rc3;
+            hipLaunchKernelGGL(k_collect_misses_long, dim3(grid_for(n)), dim3(BLOCK), 0, 0, (const int32_t*)best.p, p1,
+                               (const uint8_t*)W[0].texts.p, (const uint32_t*)nullptr, text_k, 0, n, key_base, (uint64_t*)misses.words.p,
+                               (uint64_t*)misses.keys.p, (char*)misses.texts.p, (unsigned long long*)d_cursor.p);
+        } else {
+            hipLaunchKernelGGL(k_pair_flags, dim3(grid_for(n)), dim3(BLOCK), 0, 0, p1, s1, p2, s2, n, (uint8_t*)flags.p);
+            BC_HIP(hipGetLastError());
+            if ((rc3 = bc_match_dev(lib, p1, (const uint8_t*)flags.p, n, max_mismatch, algo, (int32_t*)best.p, nullptr, nullptr,
+                                    (uint32_t*)d_counts.p, (uint64_t*)d_first.p, key_base, nullptr)) != BC_OK) return rc3;
+            BC_HIP(hipDeviceSynchronize());
+            if ((rc3 = misses.reserve(n)) != BC_OK) return rc3;  // every pair could be a miss
+            hipLaunchKernelGGL(k_collect_misses, dim3(grid_for(n)), dim3(BLOCK), 0, 0, (const int32_t*)best.p, p1, n, kmer_mask(k),
+                               key_base, (uint64_t*)misses.words.p, (uint64_t*)misses.keys.p, (unsigned long long*)d_cursor.p);
+        }
         BC_HIP(hipGetLastError());
         unsigned long long used = 0;
         BC_HIP(hipMemcpy(&used, d_cursor.p, 8, hipMemcpyDeviceToHost));
         misses.used = used;
         if ((rc3 = tallies_to_host(G, d_counts, d_first, h_counts, h_first_seen)) != BC_OK) return rc3;
-        return group_misses(misses, device, res);
+        return text_k ? group_misses_long(misses, device, res) : group_misses(misses, device, res);
     };
     rc = body();
     if (rc != BC_OK) { delete res; return rc; }

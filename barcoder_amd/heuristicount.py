@@ -744,7 +744,9 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     # paired-end: two uncompressed files; with several ranks every rank takes byte ranges of both files that hold the same
     # reads (ingest.paired_read_ranges: newline counts per slice, made common knowledge by one small gather)
     compressed_pair = is_paired and (file1.endswith((".gz", ".zst")) or file2.endswith((".gz", ".zst")))
-    device_pairs = (bc_len <= 32 and is_paired and (not compressed_pair or world == 1)
+    # (barcodes of more than 32 nt pair on the device too: the stores keep bc_len bytes of text per read and file — up to
+    # 256 nt, beyond that the host front half)
+    device_pairs = (bc_len <= 256 and is_paired and (not compressed_pair or world == 1)
                     and bc_start1 is not None and bc_start2 is not None and os.environ.get("BC_DEVICE_INGEST", "1") != "0"
                     and len(L_fwd or "") <= 15 and len(R_fwd or "") <= 15 and len(L_rev or "") <= 15 and len(R_rev or "") <= 15)
     undoc_tables, odd_events = [], []
@@ -777,10 +779,13 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
             for key, w1p, st1, w2p, st2, t1, t2 in sr.odd:  # string semantics (ChunkCounter.match_buffers)
                 if st1 == N.WIN_SKIP or st2 == N.WIN_SKIP:
                     continue
+                # a packed mate's barcode: from its word, or (more than 32 nt: the word is a hash) the text that came along
+                b1 = t1 if (bc_len > 32 and st1 != N.WIN_ODD) else None
+                b2 = t2 if (bc_len > 32 and st2 != N.WIN_ODD) else None
                 w1 = t1[s1:s1 + len(Lf) + bc_len + len(Rf)] if st1 == N.WIN_ODD else \
-                    Lf + unpack_kmers(np.array([w1p], np.uint64), bc_len)[0] + Rf
+                    Lf + (b1 if b1 is not None else unpack_kmers(np.array([w1p], np.uint64), bc_len)[0]) + Rf
                 w2 = t2[s2:s2 + len(Lr) + bc_len + len(Rr)] if st2 == N.WIN_ODD else \
-                    Lr + rev_comp(unpack_kmers(np.array([w2p], np.uint64), bc_len)[0]) + Rr
+                    Lr + rev_comp(b2 if b2 is not None else unpack_kmers(np.array([w2p], np.uint64), bc_len)[0]) + Rr
                 q1, q2 = w1[len(Lf):len(w1) - len(Rf)], w2[len(Lr):len(w2) - len(Rr)]
                 has = w1.startswith(Lf) and w1.endswith(Rf) and w2.startswith(Lr) and w2.endswith(Rr)
                 if q1 != rev_comp(q2) or not has:

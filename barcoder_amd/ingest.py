@@ -220,9 +220,10 @@ def paired_read_ranges(file_a: str, file_b: str, rank: int, world: int, gather):
 def stream_count_pair(lib_handle, path_fwd: str, path_rev: str, start_fwd: int, L_fwd: str, R_fwd: str, start_rev: int,
                       L_rev: str, R_rev: str, max_mismatch: int, algo: str, key_base: int, counts: np.ndarray,
                       first_seen: np.ndarray, n_threads: int = 0, range_fwd=None, range_rev=None) -> StreamResult:
-    """The device path for two uncompressed mate files (bc_stream_count_pair).  `odd` of the result holds, per pair
-    with an odd window, (key, p1, st1, p2, st2, text1, text2): the packed word / status of each mate and the stripped
-    text of each odd mate ('' for a packed one)."""
+    """The device path for two mate files (bc_stream_count_pair; plain or compressed).  `odd` of the result holds, per
+    pair with an odd window, (key, p1, st1, p2, st2, text1, text2): the packed word / status of each mate and the stripped
+    text of each odd mate ('' for a packed one — except for barcodes of more than 32 nt, whose word is a hash: then the
+    packed mate's barcode as the library spells it).  Such libraries return their undocumented windows as rows of text."""
     lib = N.load()
     h = N.vp()
     enc = [x.encode("ascii") for x in (L_fwd, R_fwd, L_rev, R_rev)]
@@ -236,7 +237,14 @@ def stream_count_pair(lib_handle, path_fwd: str, path_rev: str, start_fwd: int, 
         n, nu, no, ob, sec = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double()
         N.check(lib.bc_stream_result_info(h, C.byref(n), C.byref(nu), C.byref(no), C.byref(ob), C.byref(sec)))
         uw, uc, uf = (np.empty(nu.value, np.uint64) for _ in range(3))
-        if nu.value:
+        tk = C.c_int()
+        N.check(lib.bc_stream_result_text_info(h, C.byref(tk)))
+        if tk.value:  # barcodes of more than 32 nt: rows of text (void dtype, one per row)
+            rows = np.empty((nu.value, tk.value), np.uint8)
+            if nu.value:
+                N.check(lib.bc_stream_result_undoc_text(h, N.ptr(rows), N.ptr(uc), N.ptr(uf)))
+            uw = rows.view(np.dtype((np.void, tk.value))).reshape(-1)
+        elif nu.value:
             N.check(lib.bc_stream_result_undoc(h, N.ptr(uw), N.ptr(uc), N.ptr(uf)))
         m, b1, b2 = C.c_uint64(), C.c_uint64(), C.c_uint64()
         N.check(lib.bc_stream_result_pair_info(h, C.byref(m), C.byref(b1), C.byref(b2)))

@@ -196,8 +196,8 @@ int bc_stream_result_undoc_text(const bc_stream_result *r, char *text, uint64_t 
 int bc_stream_result_free(bc_stream_result *r);
 
 /* bc_stream_count_pair: the paired-end form (heuristicount.py:469-518, reached from
- * :540-554).  Both UNCOMPRESSED files go through the device one after the other,
- * each leaving {packed window, status} per read in HBM; then the pairs are formed
+ * :540-554).  Both files (plain: one after the other; .gz / .zst: their decoders side
+ * by side) go through the device, each leaving {packed window, status} per read in HBM; then the pairs are formed
  * (neither mate holds an N, both show their flanks, seq1 == rev_comp(seq2), :489-507),
  * matched once over the whole run (documented: both windows in the library,
  * :509-515; undocumented: flanks only, :517-518) and tallied.  path_fwd = the file
@@ -208,7 +208,14 @@ int bc_stream_result_free(bc_stream_result *r);
  * numbers of reads fail with BC_EINVAL and the reference's message (:484-486).
  * Pairs with an odd window (flanks present, window short or not pure ACGT) come
  * back through bc_stream_result_pair_*: per pair its key, both mates' packed word
- * and status, and the stripped text of each odd mate (empty for a packed one). */
+ * and status, and the stripped text of each odd mate (empty for a packed one).
+ * A library with attached texts (barcodes of 33 ... 1000 nt, bc_lib_attach_text;
+ * max_mismatch must be 0): the per-read stores also keep the window's text as the
+ * library spells it (text_k bytes per read and file), a pair needs equal hashes AND
+ * equal texts, every hit is verified against the library's text, the undocumented
+ * windows come back as texts (bc_stream_result_undoc_text), and a PACKED mate of an
+ * odd pair returns its barcode text (text_k characters) where a short barcode returns
+ * nothing — its word is a hash and cannot be unpacked. */
 int bc_stream_count_pair(bc_lib *lib, const char *path_fwd, const char *path_rev,
                          int64_t start_fwd, const char *L_fwd, int L_fwd_len, const char *R_fwd,
                          int R_fwd_len, int64_t start_rev, const char *L_rev, int L_rev_len,

@@ -119,3 +119,42 @@ def test_long_barcodes_two_ranks_equal_one(gpu_device, tmp_path):
         outs.append((out.stdout, [ln for ln in out.stderr.splitlines() if "Barcode" in ln or "Fraction" in ln or ln.rstrip().endswith(("*  1", "*  2"))]))
     assert outs[0][0] == outs[1][0] and len(outs[0][0].splitlines()) > 250
     assert outs[0][1] == outs[1][1] and any("Undocumented" in ln for ln in outs[0][1])
+
+
+@pytest.mark.parametrize("layout", ["paired", "gz"])
+def test_long_barcodes_stride_plan_with_idle_ranks(gpu_device, tmp_path, layout):
+    """Barcodes of more than 32 nt on the plans that split by CHUNK — mate pairs (host front half, chunk c -> rank
+    c % world) and one compressed file (device ingest, bc_stream_count_file_part) — over three ranks with FEWER chunks
+    than ranks: a rank that owns no chunk contributes an empty undocumented table, which must have the text-row shape
+    of the others (round 3's advisor: it came back as packed words and broke the merge) — stdout and the summary equal
+    the single-process run."""
+    import random
+    rng = random.Random(7)
+    k = 40
+    lib = list(dict.fromkeys("".join(rng.choice("ACGT") for _ in range(k)) for _ in range(200)))
+    L, R = "CCGGATTCAG", "GTTTTAGAGC"
+    comp = str.maketrans("ACGT", "TGCA")
+    r1, r2 = [], []
+    for i in range(3000):
+        bc = rng.choice(lib) if rng.random() > 0.2 else "".join(rng.choice("ACGT") for _ in range(k))
+        mid = L + bc + R
+        r1.append("".join(rng.choice("ACGT") for _ in range(4)) + mid + "AC")
+        r2.append("GT" + mid.translate(comp)[::-1] + "".join(rng.choice("ACGT") for _ in range(3)))
+    fa = tmp_path / "long.fasta"
+    fa.write_text("".join(f">b{i}\n{s}\n" for i, s in enumerate(lib)))
+    if layout == "paired":
+        files = [tmp_path / "m1.reads", tmp_path / "m2.reads"]
+        files[0].write_text("".join(r + "\n" for r in r1))
+        files[1].write_text("".join(r + "\n" for r in r2))
+    else:
+        files = [tmp_path / "one.reads.gz"]
+        with gzip.open(files[0], "wt") as f:
+            f.write("".join(r + "\n" for r in r1))
+    outs = []
+    for ranks in (1, 3):
+        out = subprocess.run([sys.executable, "-m", "barcoder_amd.heuristicount", str(fa)] + [str(p) for p in files] +
+                             ["--gpus", str(ranks), "--chunk-reads", "2000"], cwd=ROOT, capture_output=True, text=True,
+                             timeout=900, env=_bare_env("gloo"))
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append((out.stdout, [ln for ln in out.stderr.splitlines() if "Barcode" in ln or "Fraction" in ln]))
+    assert outs[0] == outs[1] and len(outs[0][0].splitlines()) > 150

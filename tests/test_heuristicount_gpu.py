@@ -213,6 +213,25 @@ def test_barcodes_longer_than_32_nt(gpu_device, oracle, tmp_path, k, monkeypatch
         assert tables[0][0] == [(key, v) for key, v in ref.items() if not key.endswith("*")], path
         assert tables[0][1] == {key: v for key, v in ref.items() if key.endswith("*")}, path
     assert tables[0][3] is True
+    # mate pairs of such barcodes (round 4): both files through the device — the stores keep every window's text beside
+    # its hash, pairs need equal hashes and equal texts, pairs with an odd window come back as text — against the host
+    # front half and the oracle's process_paired_end, in either file order, plain and gzip-compressed
+    import gzip
+    want_pair, _ = oracle.process_chunk_py((fwd, mates), lib, 5, 3, k, Lf, Rf, Lr, Rr, False)
+    gz1, gz2 = tmp_path / "long.reads.gz", tmp_path / "long_rev.reads.gz"
+    for src, dst in ((rd, gz1), (rv, gz2)):
+        with gzip.open(dst, "wb", compresslevel=1) as f:
+            f.write(open(src, "rb").read())
+    for f1, f2 in ((rd, rv), (rv, rd), (gz1, gz2)):
+        tables = []
+        for env in ("1", "0"):
+            monkeypatch.setenv("BC_DEVICE_INGEST", env)
+            r = H.count_barcodes(str(fa), str(f1), str(f2), device=gpu_device)
+            assert ("device ingest (bc_stream_count_pair)" in r["bulk_pass"]) == (env == "1")
+            tables.append((list(r["doc"].items()), dict(r["undoc"].items()), r["total_reads"]))
+        assert tables[0] == tables[1], (f1, f2)
+        assert tables[0][0] == [(key, v) for key, v in want_pair.items() if not key.endswith("*")], (f1, f2)
+        assert tables[0][1] == {key: v for key, v in want_pair.items() if key.endswith("*")}, (f1, f2)
     # several 16 MiB chunks on several worker threads, the miss list grown past its (shrunken) first estimate
     big = tmp_path / "long_big.reads"
     big.write_text("".join(r + "\n" for r in fwd) * (60 if k == 40 else 30))
@@ -252,7 +271,7 @@ def test_long_barcode_entry_points_refuse_what_they_cannot_do(gpu_device, tmp_pa
         stream_count_file(long_lib.handle, str(rd), 0, os.path.getsize(rd), 5, "", "", False, 1, "auto", 0, c64, f64)
     sr = stream_count_file(long_lib.handle, str(rd), 0, os.path.getsize(rd), 5, "", "", False, 0, "auto", 0, c64, f64)
     assert sr.n_reads == len(seqs) and int(c64.sum()) == len(seqs) and sr.u_words.size == 0
-    # the paired entry point pairs packed windows of at most 32 bases: a library of text hashes is refused there
+    # the paired entry point takes such a library too (texts kept beside the hashes), exact match only
     from barcoder_amd.ingest import stream_count_pair
-    with pytest.raises(ValueError, match="more than 32 nt"):
-        stream_count_pair(long_lib.handle, str(rd), str(rd), 5, "", "", 2, "", "", 0, "auto", 0, c64, f64)
+    with pytest.raises(ValueError, match="matched exactly"):
+        stream_count_pair(long_lib.handle, str(rd), str(rd), 5, "", "", 2, "", "", 1, "auto", 0, c64, f64)
