@@ -19,7 +19,7 @@ for f in glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if "k_" in r["Name"]:
             print(sys.argv[2], r["Name"][:70].replace("(anonymous namespace)::", ""), "calls", r["Calls"],
-                  "avg_us %.1f min_us %.1f" % (float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+                  "avg_us %.1f min_us %.1f max_us %.1f" % (float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
 }
 if has prof; then
