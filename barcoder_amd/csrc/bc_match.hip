@@ -69,36 +69,53 @@ __global__ __launch_bounds__(BLOCK) void k_match_hash(const uint64_t* __restrict
         int32_t idx[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { r[j] = 0; idx[j] = BC_IDX_SKIP; }
+        // a whole tile (the wave's 64 groups all exist): lane l takes reads 2l, 2l + 1, 128 + 2l, 129 + 2l of it, so that each
+        // of the two load instructions covers 1 KiB contiguously and every line of the stream is requested once (see
+        // k_match_wq); a ragged last tile keeps four consecutive reads per lane
+        const bool whole = VEC == 4 && g0 + 63 < ngroups;  // wave-uniform
+        auto index_of = [&](int j) -> uint64_t {
+            return whole ? g0 * 4 + (j < 2 ? 0u : 128u) + 2u * lane + (uint32_t)(j & 1) : g * VEC + (uint64_t)j;
+        };
         if (active) {
             if constexpr (VEC == 4) {
-                load_reads4(reads + g * 4, r);
+                if (whole) load_reads2x2(reads + g0 * 4, lane, r);
+                else load_reads4(reads + g * 4, r);
             } else {
                 r[0] = reads[g];
             }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                uint64_t i = g * VEC + j;
-                if (read_skipped(r[j], flags, i, k)) idx[j] = BC_IDX_SKIP;
+                if (read_skipped(r[j], flags, index_of(j), k)) idx[j] = BC_IDX_SKIP;
                 else idx[j] = hash_lookup<WIDE>(r[j] & kmask, s64, s32, guides, k, log_slots, kmask);
             }
         }
         if constexpr (VEC == 4) {
             if (active) {   // results are final: non-temporal stores keep the table in the L2
-                const u32x4 t = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2], (uint32_t)idx[3]};
-                __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(o.best_idx) + g);
-                if (o.best_dist) {
-                    uchar4 d;
-                    d.x = idx[0] >= 0 ? 0 : BC_DIST_NONE; d.y = idx[1] >= 0 ? 0 : BC_DIST_NONE;
-                    d.z = idx[2] >= 0 ? 0 : BC_DIST_NONE; d.w = idx[3] >= 0 ? 0 : BC_DIST_NONE;
-                    __builtin_nontemporal_store((uint32_t)d.x | ((uint32_t)d.y << 8) | ((uint32_t)d.z << 16) | ((uint32_t)d.w << 24), reinterpret_cast<uint32_t*>(o.best_dist) + g);
-                }
-                if (o.n_best) {
-                    uchar4 d;
-                    d.x = idx[0] >= 0; d.y = idx[1] >= 0; d.z = idx[2] >= 0; d.w = idx[3] >= 0;
-                    __builtin_nontemporal_store((uint32_t)d.x | ((uint32_t)d.y << 8) | ((uint32_t)d.z << 16) | ((uint32_t)d.w << 24), reinterpret_cast<uint32_t*>(o.n_best) + g);
+                uint32_t dd[4], nn[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dd[j] = idx[j] >= 0 ? 0u : (uint32_t)BC_DIST_NONE; nn[j] = idx[j] >= 0 ? 1u : 0u; }
+                if (whole) {
+                    uint64_t* bi = reinterpret_cast<uint64_t*>(o.best_idx + g0 * 4) + lane;
+                    stream_store((uint64_t)(uint32_t)idx[0] | ((uint64_t)(uint32_t)idx[1] << 32), bi);
+                    stream_store((uint64_t)(uint32_t)idx[2] | ((uint64_t)(uint32_t)idx[3] << 32), bi + 64);
+                    if (o.best_dist) {
+                        uint16_t* bd = reinterpret_cast<uint16_t*>(o.best_dist + g0 * 4) + lane;
+                        stream_store((uint16_t)(dd[0] | (dd[1] << 8)), bd);
+                        stream_store((uint16_t)(dd[2] | (dd[3] << 8)), bd + 64);
+                    }
+                    if (o.n_best) {
+                        uint16_t* bn = reinterpret_cast<uint16_t*>(o.n_best + g0 * 4) + lane;
+                        stream_store((uint16_t)(nn[0] | (nn[1] << 8)), bn);
+                        stream_store((uint16_t)(nn[2] | (nn[3] << 8)), bn + 64);
+                    }
+                } else {
+                    const u32x4 t = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2], (uint32_t)idx[3]};
+                    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(o.best_idx) + g);
+                    if (o.best_dist) __builtin_nontemporal_store(dd[0] | (dd[1] << 8) | (dd[2] << 16) | (dd[3] << 24), reinterpret_cast<uint32_t*>(o.best_dist) + g);
+                    if (o.n_best) __builtin_nontemporal_store(nn[0] | (nn[1] << 8) | (nn[2] << 16) | (nn[3] << 24), reinterpret_cast<uint32_t*>(o.n_best) + g);
                 }
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) tally(o, g * VEC + j, idx[j]);
+                for (int j = 0; j < VEC; ++j) tally(o, index_of(j), idx[j]);
             }
             if (o.part.rec) {
                 const uint32_t w = threadIdx.x >> 6;
@@ -735,15 +752,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     for (int i = 0; i < 32; ++i) pfv[i] = 0;
 #endif
     // ---- phase 1: table 0, primary slab, every read (exact hits and isolated near hits are final)
+    // Which four reads of the tile a lane owns.  A FULL tile (every tile but a ragged last one): reads 2l, 2l + 1 and
+    // 128 + 2l, 129 + 2l — so that each of the two 16-byte-per-lane load instructions covers 1 KiB of the tile CONTIGUOUSLY
+    // and every line of the stream is requested once.  (Round 3 gave lane l reads 4l .. 4l + 3: both load instructions then
+    // touch every 64-byte sector of the tile, half of it each, and the vector L1 asked the L2 for every sector twice —
+    // 0.125 instead of 0.0625 requests per read of the most expensive kind, the ones that wait for HBM: round 4 measured
+    // 1.682 -> 1.619 requests per read and -3 % time with the loads rearranged, profiles/r04_stream_load_contiguous.txt.)
+    // A ragged tile keeps the consecutive assignment (element-wise loads and stores).
+    const bool whole = tn == (uint32_t)WAVE_T;  // wave-uniform
     const uint32_t p0 = lane * 4u;
-    const bool full = p0 + 3 < tn;
+    const bool full = whole;
+    auto pos_of = [&](int j) -> uint32_t { return whole ? ((j < 2 ? 0u : 128u) + 2u * lane + (uint32_t)(j & 1)) : p0 + (uint32_t)j; };
     int32_t idx[4];
     uint32_t at[4];     // list entry of the lane's reads that were listed
     uint32_t dist4 = 0; // distances of the reads settled in phase 1, one byte each
     {
         uint64_t r[4] = {0, 0, 0, 0};
         if (full) {
-            load_reads4(reads + ((diag & 16u) ? (uint64_t)(blockIdx.x & 255u) * WAVE_T : tile0) + p0, r);  // BC_DIAG 16: the read stream from 512 KB that stay in L2 (timing experiment)
+            // (BC_DIAG 16: the read stream from 512 KB that stay in L2 — timing experiment)
+            load_reads2x2(reads + ((diag & 16u) ? (uint64_t)(blockIdx.x & 255u) * WAVE_T : tile0), lane, r);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -752,7 +779,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         bool ok[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ok[j] = p0 + j < tn && !read_skipped(r[j], flags, tile0 + p0 + j, k);
+            ok[j] = pos_of(j) < tn && !read_skipped(r[j], flags, tile0 + pos_of(j), k);
             r[j] &= kmask;
         }
         // skipped reads fetch bucket 0 (always mapped) and ignore it: no branch around the loads
@@ -975,17 +1002,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             }
         }
         if (full) {
-            // non-temporal: nothing in this kernel touches these lines again, the tables should keep the L2 (3 % measured)
-            const u32x4 t = {(uint32_t)idx[0], (uint32_t)idx[1], (uint32_t)idx[2], (uint32_t)idx[3]};
+            // non-temporal: nothing in this kernel touches these lines again, the tables should keep the L2 (3 % measured).
+            // The lane's reads are two pairs (2l, 2l + 1 and 128 + 2l, 129 + 2l): two 8-byte index stores and two 2-byte
+            // stores per byte array, each instruction a contiguous 512 / 128 bytes of whole 64-byte sectors
             const uint64_t st0 = (diag & 64u) ? (uint64_t)(blockIdx.x & 255u) * WAVE_T : tile0;  // BC_DIAG 64: results into 0.4 MB (timing experiment)
-            stream_store(t, reinterpret_cast<u32x4*>(o.best_idx + st0) + (p0 >> 2));
+            uint64_t* bi = reinterpret_cast<uint64_t*>(o.best_idx + st0) + lane;
+            stream_store((uint64_t)(uint32_t)idx[0] | ((uint64_t)(uint32_t)idx[1] << 32), bi);
+            stream_store((uint64_t)(uint32_t)idx[2] | ((uint64_t)(uint32_t)idx[3] << 32), bi + 64);
             if (o.best_dist) {
-                stream_store(dist[0] | (dist[1] << 8) | (dist[2] << 16) | (dist[3] << 24),
-                                            reinterpret_cast<uint32_t*>(o.best_dist + st0) + (p0 >> 2));
+                uint16_t* bd = reinterpret_cast<uint16_t*>(o.best_dist + st0) + lane;
+                stream_store((uint16_t)(dist[0] | (dist[1] << 8)), bd);
+                stream_store((uint16_t)(dist[2] | (dist[3] << 8)), bd + 64);
             }
             if (o.n_best) {
-                stream_store(nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24),
-                                            reinterpret_cast<uint32_t*>(o.n_best + st0) + (p0 >> 2));
+                uint16_t* bn = reinterpret_cast<uint16_t*>(o.n_best + st0) + lane;
+                stream_store((uint16_t)(nb[0] | (nb[1] << 8)), bn);
+                stream_store((uint16_t)(nb[2] | (nb[3] << 8)), bn + 64);
             }
         } else {
 #pragma unroll
@@ -998,7 +1030,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (p0 + j < tn) tally(o, tile0 + p0 + j, idx[j]);
+            if (pos_of(j) < tn) tally(o, tile0 + pos_of(j), idx[j]);
         if (o.part.rec) {
             // the lists are dead (every lane has its results in registers): the list entries become the record staging
             // area (the first 2 KiB = PART_SLOTS two-byte slots), the item stack the range counters
@@ -1014,7 +1046,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             bool ms[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ms[j] = p0 + j < tn && idx[j] == BC_IDX_MISS;
+                ms[j] = pos_of(j) < tn && idx[j] == BC_IDX_MISS;
                 const unsigned long long m = vote(ms[j]);
                 off[j] = mtot + rank_of(m);
                 mtot += (uint32_t)__popcll(m);
@@ -1023,8 +1055,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (ms[j]) {
-                    o.miss_pos[tile0 + off[j]] = (uint32_t)(tile0 + p0 + j);
-                    o.miss_read[tile0 + off[j]] = k > 31 ? (reads[tile0 + p0 + j] & kmask) : mr[j];
+                    o.miss_pos[tile0 + off[j]] = (uint32_t)(tile0 + pos_of(j));
+                    o.miss_read[tile0 + off[j]] = k > 31 ? (reads[tile0 + pos_of(j)] & kmask) : mr[j];
                 }
         }
     }

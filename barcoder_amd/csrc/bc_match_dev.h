@@ -92,6 +92,8 @@ __device__ __forceinline__ void stream_store(u32x4 v, u32x4* p) {
     *p = v;
 #endif
 }
+__device__ __forceinline__ void stream_store(uint64_t v, uint64_t* p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void stream_store(uint16_t v, uint16_t* p) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void stream_store(uint32_t v, uint32_t* p) {
 #if BC_STORE_POLICY == 0 || !defined(__HIP_DEVICE_COMPILE__)
     __builtin_nontemporal_store(v, p);
@@ -113,6 +115,19 @@ __device__ __forceinline__ void load_reads4(const uint64_t* p, uint64_t (&r)[4])
     u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
 #else
     u32x4 a = q[0], b = q[1];
+#endif
+    r[0] = (uint64_t)a.x | ((uint64_t)a.y << 32); r[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    r[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); r[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+}
+
+// the same for a whole tile of 256 reads and lane l's reads 2l, 2l + 1, 128 + 2l, 129 + 2l: each of the two load instructions
+// covers 1 KiB contiguously, so every line of the stream is requested once (k_match_wq: see there)
+__device__ __forceinline__ void load_reads2x2(const uint64_t* tile, uint32_t lane, uint64_t (&r)[4]) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(tile);
+#if BC_LOAD_POLICY == 0
+    const u32x4 a = __builtin_nontemporal_load(q + lane), b = __builtin_nontemporal_load(q + 64 + lane);
+#else
+    const u32x4 a = q[lane], b = q[64 + lane];
 #endif
     r[0] = (uint64_t)a.x | ((uint64_t)a.y << 32); r[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
     r[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); r[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
