@@ -2811,7 +2811,9 @@ int bc_multi_create(const uint64_t* h_guides, uint32_t n_guides, int k, const in
     bool distinct = true;
     for (int i = 0; i < n_gpus; ++i)
         for (int j = 0; j < i; ++j) distinct = distinct && m->devices[i] != m->devices[j];
-    if (n_gpus > 1 && distinct) {
+    // (BC_MULTI_RCCL=1: a communicator also for a single device — a group of one still goes through ncclCommInitAll and
+    // ncclAllReduce, which is how the RCCL branch is exercised on a one-GPU box: tests/test_dist_gpu.py)
+    if ((n_gpus > 1 || env_int("BC_MULTI_RCCL", 0) == 1) && distinct) {
         if (!g_rccl.load()) { bc_multi_destroy(m); set_error("bc_multi_create: librccl is not available"); return BC_ENODEV; }
         m->comms.assign(n_gpus, nullptr);
         int r = g_rccl.CommInitAll(m->comms.data(), n_gpus, m->devices.data());

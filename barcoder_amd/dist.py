@@ -194,7 +194,9 @@ def reduce_counts(counts, first_seen=None, device=None, async_op=False):
     else:
         c, f = counts, first_seen
     pending = Pending()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    # (a group of ONE still runs its collectives: a one-rank "nccl" group is how the RCCL branch is exercised on a
+    # one-GPU box, tests/test_dist_gpu.py; without a group nothing is reduced)
+    if dist.is_available() and dist.is_initialized():
         gloo_on_gpu = _group_backend() == "gloo" and c.is_cuda
         for t, op in ((c, dist.ReduceOp.SUM), (f, dist.ReduceOp.MIN)):
             if t is None:

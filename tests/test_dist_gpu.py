@@ -158,3 +158,56 @@ def test_long_barcodes_stride_plan_with_idle_ranks(gpu_device, tmp_path, layout)
         assert out.returncode == 0, out.stderr[-2000:]
         outs.append((out.stdout, [ln for ln in out.stderr.splitlines() if "Barcode" in ln or "Fraction" in ln]))
     assert outs[0] == outs[1] and len(outs[0][0].splitlines()) > 150
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["BC_ROOT"])
+import torch, torch.distributed as dist
+from barcoder_amd import dist as D, synth as S, DeviceLibrary, GpuMatcher, MultiGpuMatcher
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["BC_PORT"])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+G = 5000
+c = torch.arange(G, dtype=torch.int64, device="cuda")
+f = torch.full((G,), D.I64_MAX, dtype=torch.int64, device="cuda")
+f[::3] = 7
+c2, f2 = D.reduce_counts(c.clone(), f.clone(), device=0)                      # RCCL SUM / MIN of int64, device tensors
+assert torch.equal(c2, c) and torch.equal(f2, f)
+c3, f3, pend = D.reduce_counts(c.clone(), f.clone(), device=0, async_op=True)   # the bench's overlapped form
+pend.wait(); torch.cuda.synchronize()
+assert torch.equal(c3, c) and torch.equal(f3, f)
+cn, fn = D.reduce_counts(np.arange(G, dtype=np.uint64), np.full(G, D.U64_MAX, np.uint64), device=0)  # numpy in, numpy out
+assert cn.tolist() == list(range(G)) and int(fn.min()) == D.I64_MAX
+dist.barrier(); dist.destroy_process_group()
+# the one-process form: ncclCommInitAll + grouped ncclAllReduce (uint64 SUM, MIN) on a communicator of one
+lib = S.library(3000, 20)
+reads = S.reads(lib, 20, 2, 0, 40_001, 1)
+want = GpuMatcher(DeviceLibrary(lib, 20, 0)).match(reads, None, 2, "seed", first_index=5)
+mm = MultiGpuMatcher(lib, 20, [0])
+assert mm.uses_rccl, "BC_MULTI_RCCL=1 must give a communicator"
+got = mm.match(reads, None, 2, "seed", first_index=5)
+for a in ("best_idx", "best_dist", "n_best", "counts", "first_seen"):
+    assert np.array_equal(getattr(got, a), getattr(want, a)), a
+mm.close()
+print("rccl-one-rank-ok")
+"""
+
+
+def test_rccl_branch_on_a_group_of_one(gpu_device, tmp_path):
+    """The RCCL code paths, executed on this box's one GPU in a group of one rank: torch.distributed's "nccl" backend
+    under dist.reduce_counts (device tensors, sync and async, and the numpy form), and bc_multi_gpu_match's own
+    communicator (BC_MULTI_RCCL=1).  A group of one moves no data between devices — what this pins is that librccl
+    loads, the communicator initialises on gfx950, and the collectives accept our dtypes, ops and streams; the job-wide
+    arithmetic over several ranks is pinned by the gloo tests above.  Own process: the group must not outlive the test."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "rccl_one.py"
+    script.write_text(_RCCL_ONE_RANK)
+    env = dict(_bare_env("nccl"), BC_ROOT=ROOT, BC_PORT=str(port), BC_MULTI_RCCL="1")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "rccl-one-rank-ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
