@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -106,6 +107,13 @@ struct StrSet {
         }
     }
     bool contains(std::string_view v) const { return contains(str_hash(v), v); }
+    int64_t find_slot(uint64_t h, std::string_view v) const {  // the entry's slot (stable while the set does not grow), -1 = absent
+        for (size_t i = (size_t)h & mask;; i = (i + 1) & mask) {
+            const Slot& s = tab[i];
+            if (!s.p) return -1;
+            if (s.h == h && s.len == v.size() && memcmp(s.p, v.data(), v.size()) == 0) return (int64_t)i;
+        }
+    }
     void prefetch(uint64_t h) const { __builtin_prefetch(&tab[(size_t)h & mask]); }
     void grow() {
         std::vector<Slot> old;
@@ -119,15 +127,17 @@ struct StrSet {
                 tab[i] = s;
             }
     }
-    bool insert(uint64_t h, std::string_view v) {  // true when new
+    bool insert(uint64_t h, std::string_view v) { return insert_at(h, v, own) != nullptr; }  // true when new
+    // where the string now lives (nullptr: it was there already); `copy`: into the arena, else the caller's bytes stay
+    const char* insert_at(uint64_t h, std::string_view v, bool copy) {
         size_t i = (size_t)h & mask;
         for (;; i = (i + 1) & mask) {
             const Slot& s = tab[i];
             if (!s.p) break;
-            if (s.h == h && s.len == v.size() && memcmp(s.p, v.data(), v.size()) == 0) return false;
+            if (s.h == h && s.len == v.size() && memcmp(s.p, v.data(), v.size()) == 0) return nullptr;
         }
         const char* at = v.data();
-        if (own) {
+        if (copy) {
             const size_t need = std::max<size_t>(v.size(), 1);  // (an empty string still needs a non-null address)
             if (used + need > cap) {
                 cap = std::max<size_t>(1u << 22, need);
@@ -143,10 +153,44 @@ struct StrSet {
         }
         tab[i] = Slot{h, at, v.size()};
         if (++count * 2 > tab.size()) grow();
-        return true;
+        return at;
     }
     bool insert(std::string_view v) { return insert(str_hash(v), v); }
     size_t size() const { return count; }
+};
+
+// The library (or its reverse complements) as a set in eight parts by the top bits of the hash: the parts are filled by
+// as many threads, never grow afterwards, and every entry has a stable id (part base + slot) — what the per-chunk
+// "first occurrence" table of the sampling pass is indexed by.
+struct LibSet {
+    std::vector<StrSet> part;
+    size_t base[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    explicit LibSet(size_t expect) { for (int p = 0; p < 8; ++p) part.emplace_back(expect / 8 + expect / 32 + 16, false); }
+    // hashes of the G entries (computed by the caller's threads), entry g = at(g)
+    template <typename At>
+    void build(const std::vector<uint64_t>& h, uint32_t G, At at, unsigned threads) {
+        auto fill = [&](unsigned p0, unsigned step) {
+            for (unsigned p = p0; p < 8; p += step)
+                for (uint32_t g = 0; g < G; ++g)
+                    if ((unsigned)(h[g] >> 61) == p) part[p].insert(h[g], at(g));
+        };
+        const unsigned step = threads >= 8 ? 8u : threads >= 4 ? 4u : threads >= 2 ? 2u : 1u;
+        if (step == 1) fill(0, 1);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < step; ++t) th.emplace_back(fill, t, step);
+            for (auto& x : th) x.join();
+        }
+        for (int p = 0; p < 8; ++p) base[p + 1] = base[p] + part[p].tab.size();
+    }
+    int64_t find(uint64_t h, std::string_view v) const {
+        const unsigned p = (unsigned)(h >> 61);
+        const int64_t s = part[p].find_slot(h, v);
+        return s < 0 ? -1 : (int64_t)base[p] + s;
+    }
+    bool contains(uint64_t h, std::string_view v) const { return part[h >> 61].contains(h, v); }
+    size_t size() const { size_t n = 0; for (const StrSet& s : part) n += s.size(); return n; }
+    size_t slots() const { return base[8]; }
 };
 
 struct Chunk {
@@ -221,7 +265,10 @@ struct Roll {
 
 struct bc_sample {
     int64_t n_novel = 0, off1 = -1, off2 = -1;  // -1 = None
-    std::vector<std::string> valid1, valid2;    // sample1 / sample2 AFTER the swap rule
+    std::vector<std::string_view> valid1, valid2;  // sample1 / sample2 AFTER the swap rule: views into what follows
+    std::vector<std::string> strs[2];              // (the paired / unfiltered path keeps copies)
+    std::vector<std::vector<char>> texts;          // (single-end fast path: the sampled chunks' text, kept)
+    std::vector<StrSet> arenas;                    // (... and the sets whose arenas hold what was copied instead)
     uint64_t n_observed = 0, n_chunks = 0;
     int need_swap = 0, satisfied = 0;
 };
@@ -232,51 +279,72 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     if (!file1 || !barcodes || !out || G == 0 || k < 1) { set_error("bc_sample_data: bad argument"); return BC_EINVAL; }
     const bool paired = file2 && *file2;
     const auto t_entry = std::chrono::steady_clock::now();
-    // the library and its reverse complements as two contiguous blobs (no per-entry allocation), the sets hold views
+    // the library and its reverse complements as two contiguous blobs (no per-entry allocation), the sets hold views.
+    // Everything per entry — reverse complement, the two string hashes, the purity test and the pre-filter bits — is done
+    // by worker threads over ranges of the library; the sets are then filled in eight parts by as many threads.
     std::vector<char> rev_blob((size_t)G * k);
     auto fwd_at = [&](uint32_t g) { return std::string_view(barcodes + (size_t)g * k, (size_t)k); };
     auto rev_at = [&](uint32_t g) { return std::string_view(rev_blob.data() + (size_t)g * k, (size_t)k); };
-    for (uint32_t g = 0; g < G; ++g) {
-        const char* src = barcodes + (size_t)g * k;
-        char* dst = rev_blob.data() + (size_t)g * k;
-        for (int j = 0; j < k; ++j) {
-            char c = src[k - 1 - j];
-            switch (c) {
-                case 'A': c = 'T'; break;
-                case 'T': c = 'A'; break;
-                case 'C': c = 'G'; break;
-                case 'G': c = 'C'; break;
-                default: break;
-            }
-            dst[j] = c;
-        }
-    }
-    StrSet fwd(G, false), rev(G, false);
-    {
-        std::thread other([&] { for (uint32_t g = 0; g < G; ++g) rev.insert(rev_at(g)); });
-        for (uint32_t g = 0; g < G; ++g) fwd.insert(fwd_at(g));
-        other.join();
-    }
-    const uint64_t n_lib = fwd.size();  // len(barcodes) of the SET (heuristicount.py:174-176)
+    const unsigned hw0 = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned TS = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(16, hw0), G / 2048 + 1));
     // Pre-filter for the k-mer sweep (most windows of a read are no barcode): 2^24 bits set at a hash of the packed
     // value of every library entry and reverse complement.  Only when every entry is pure upper-case ACGT and fits a
     // 64-bit packing; otherwise the sweep asks the sets for every window, as the reference does.
-    bool prefilter = k <= 32;
-    for (uint32_t g = 0; g < G && prefilter; ++g)
-        for (int j = 0; j < k; ++j) prefilter = prefilter && base_code((unsigned char)barcodes[(size_t)g * k + j]) < 4;
-    std::vector<uint64_t> pf_bits, pf_small;
-    if (prefilter) {
+    std::vector<uint64_t> pf_bits, pf_small, hash_f(G), hash_r(G);
+    if (k <= 32) {
         pf_bits.assign((1u << PF_BITS) / 64, 0);
         pf_small.assign((1u << PF_SMALL_BITS) / 64, 0);
-        for (uint32_t g = 0; g < G; ++g)
+    }
+    std::atomic<bool> pure{k <= 32};
+    auto per_entry = [&](uint32_t g0, uint32_t g1) {
+        bool all_pure = true;
+        for (uint32_t g = g0; g < g1; ++g) {
+            const char* src = barcodes + (size_t)g * k;
+            char* dst = rev_blob.data() + (size_t)g * k;
+            for (int j = 0; j < k; ++j) {
+                char c = src[k - 1 - j];
+                switch (c) {
+                    case 'A': c = 'T'; break;
+                    case 'T': c = 'A'; break;
+                    case 'C': c = 'G'; break;
+                    case 'G': c = 'C'; break;
+                    default: break;
+                }
+                dst[j] = c;
+            }
+            hash_f[g] = str_hash(fwd_at(g));
+            hash_r[g] = str_hash(rev_at(g));
+            if (k > 32) continue;
             for (const std::string_view sp : {fwd_at(g), rev_at(g)}) {
                 uint64_t v = 0;
-                for (int j = 0; j < k; ++j) v = (v << 2) | (uint64_t)base_code((unsigned char)sp[j]);
+                for (int j = 0; j < k; ++j) {
+                    const int c = base_code((unsigned char)sp[j]);
+                    all_pure = all_pure && c < 4;
+                    v = (v << 2) | (uint64_t)(c & 3);
+                }
+                // (bits of an impure entry are harmless: one impure entry switches the pre-filter off altogether)
                 const uint32_t h = Roll::hash(v), hs = Roll::hash_small(v);
-                pf_bits[h >> 6] |= 1ull << (h & 63);
-                pf_small[hs >> 6] |= 1ull << (hs & 63);
+                __atomic_fetch_or(&pf_bits[h >> 6], 1ull << (h & 63), __ATOMIC_RELAXED);
+                __atomic_fetch_or(&pf_small[hs >> 6], 1ull << (hs & 63), __ATOMIC_RELAXED);
             }
+        }
+        if (!all_pure) pure.store(false, std::memory_order_relaxed);
+    };
+    if (TS == 1) per_entry(0, G);
+    else {
+        std::vector<std::thread> th;
+        const uint32_t per = (G + TS - 1) / TS;
+        for (unsigned t = 0; t < TS; ++t) th.emplace_back(per_entry, std::min(G, t * per), std::min(G, (t + 1) * per));
+        for (auto& x : th) x.join();
     }
+    LibSet fwd(G), rev(G);
+    {
+        std::thread other([&] { rev.build(hash_r, G, rev_at, std::max(1u, TS / 2)); });
+        fwd.build(hash_f, G, fwd_at, std::max(1u, TS / 2));
+        other.join();
+    }
+    const uint64_t n_lib = fwd.size();  // len(barcodes) of the SET (heuristicount.py:174-176)
+    const bool prefilter = pure.load();
     bc_reader *r1 = nullptr, *r2 = nullptr;
     int rc = bc_reader_open(file1, &r1);
     if (rc != BC_OK) return rc;
@@ -292,12 +360,30 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     OrderedCounter<int> orients[2];      // 0 = "forward", 1 = "reverse"
     OrderedCounter<int64_t> offsets[2];
     std::vector<std::string> valid_store[2];
+    const bool lookahead = !paired && prefilter;  // the single-end fast path (below)
     // (single-end runs with the pre-filter count their distinct reads in seen_part instead: no table to clear for nothing)
-    StrSet valid[2] = {StrSet(2 * (size_t)n_lib), StrSet(paired ? 2 * (size_t)n_lib : 0)},
-           seen_reads((!paired && prefilter) ? 0 : 6 * (size_t)n_lib), observed(2 * (size_t)n_lib);
+    StrSet valid[2] = {StrSet(lookahead ? 0 : 2 * (size_t)n_lib), StrSet(paired ? 2 * (size_t)n_lib : 0)},
+           seen_reads(lookahead ? 0 : 6 * (size_t)n_lib), observed(lookahead ? 0 : 2 * (size_t)n_lib);
     StrSet c_barcodes((size_t)n_lib, false), c_reads((size_t)n_lib, false);  // per chunk: views into the chunk's text
     std::vector<StrSet> seen_part;  // single-end runs with the pre-filter: seen_reads in eight parts (see `remember`)
     for (int p = 0; p < 8; ++p) seen_part.emplace_back((size_t)0);  // (they grow inside their own threads)
+    // ---- state of the single-end fast path ------------------------------------------------------------------------
+    // valid reads (sample1): a set in eight parts by the hash, filled by as many threads, and the reads in the order the
+    // reference would have added them; "observed" barcodes as one bit per library id; the text of the sampled chunks is
+    // KEPT (up to KEEP_BYTES: the sets then hold views instead of copies; past that they copy into their arenas)
+    constexpr size_t KEEP_BYTES = 1ull << 30;
+    std::vector<StrSet> vset;
+    for (int p = 0; p < 8; ++p) vset.emplace_back(lookahead ? (size_t)n_lib / 4 : 0, true);
+    std::vector<std::string_view> valid_views;
+    std::vector<std::vector<char>> kept;
+    size_t kept_bytes = 0;
+    const size_t fwd_slots = fwd.slots(), id_slots = fwd_slots + rev.slots();
+    std::vector<uint64_t> obs_bits(lookahead ? (id_slots + 63) / 64 : 0, 0);
+    // first[id] = the earliest (read, candidate) of the CURRENT chunk whose window is library entry `id`.  Keys of later
+    // chunks are smaller than any key of an earlier one, so the table is never cleared.
+    std::unique_ptr<std::atomic<uint64_t>[]> first(lookahead ? new std::atomic<uint64_t>[id_slots] : nullptr);
+    if (lookahead)
+        for (size_t i = 0; i < id_slots; ++i) first[i].store(~0ull, std::memory_order_relaxed);
     auto seen_count = [&]() {
         size_t n = seen_reads.size();
         for (const StrSet& p : seen_part) n += p.size();
@@ -329,8 +415,13 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         // runs the reference's sequential logic unchanged on warm lines.
         constexpr uint64_t AHEAD = 12;
         constexpr int MAXC = 6;
-        struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint64_t hk[MAXC]; uint8_t in[MAXC]; };  // in: bit 0 forward set, bit 1 reverse
-        const bool lookahead = !paired && prefilter;
+        struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint64_t hk[MAXC]; uint32_t id[MAXC]; uint8_t in[MAXC]; };  // in: bit 0 forward set, bit 1 reverse
+        // (id: the window's library id — the forward set's when it is there, else fwd_slots + the reverse set's: one
+        // id per distinct string, which is what the reference's per-chunk novel_barcodes is keyed by)
+        const uint64_t chunk_tag = (uint64_t)(0xFFFFFFull - std::min<uint64_t>(n_chunks, 0xFFFFFFull)) << 40;
+        auto key_of = [&](uint64_t q, int c) { return chunk_tag | (q << 3) | (uint64_t)c; };
+        std::atomic<bool> any_overflow{false};
+        const bool retain = lookahead && kept_bytes + c1.text.size() <= KEEP_BYTES;
         // what a read contributes before any growing set is consulted — its hash, the windows that ARE library entries
         // (pre-filter, then the two library sets, which never change) — is a pure function of the read: computed for the
         // whole chunk by worker threads; the order-dependent logic below then touches only the reads that hold a
@@ -363,10 +454,17 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 const size_t i = e + 1 - (size_t)k;
                 const std::string_view kmer = rd.substr(i, k);
                 const uint64_t hk = str_hash(kmer);
-                const uint8_t in = (uint8_t)((fwd.contains(hk, kmer) ? 1 : 0) | (rev.contains(hk, kmer) ? 2 : 0));
+                const int64_t idf = fwd.find(hk, kmer), idr = rev.find(hk, kmer);
+                const uint8_t in = (uint8_t)((idf >= 0 ? 1 : 0) | (idr >= 0 ? 2 : 0));
                 if (!in) continue;  // (a false positive of the pre-filter)
-                if (a.ncand == MAXC) { a.overflow = true; break; }
-                a.pos[a.ncand] = (uint32_t)i; a.hk[a.ncand] = hk; a.in[a.ncand] = in; ++a.ncand;
+                if (a.ncand == MAXC) { a.overflow = true; any_overflow.store(true, std::memory_order_relaxed); break; }
+                const uint32_t id = (uint32_t)(idf >= 0 ? (size_t)idf : fwd_slots + (size_t)idr);
+                a.pos[a.ncand] = (uint32_t)i; a.hk[a.ncand] = hk; a.id[a.ncand] = id; a.in[a.ncand] = in;
+                // earliest occurrence of this library entry in the chunk (reads ascending, then positions)
+                const uint64_t key = key_of(q, a.ncand);
+                uint64_t cur = first[id].load(std::memory_order_relaxed);
+                while (key < cur && !first[id].compare_exchange_weak(cur, key, std::memory_order_relaxed)) {}
+                ++a.ncand;
             }
         };
         auto warm = [&](uint64_t q) {  // pull the slots read q will touch towards the core
@@ -379,9 +477,15 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         auto remember = [&](unsigned part0, unsigned step) {
             for (uint64_t q = 0; q < nz; ++q) {
                 const unsigned part = (unsigned)(prep[q].h1 >> 61);
-                if (part % step == part0) seen_part[part].insert(prep[q].h1, c1.read(q));
+                if (part % step == part0) seen_part[part].insert_at(prep[q].h1, c1.read(q), !retain);
             }
         };
+        auto obs_mark = [&](uint32_t id) { obs_bits[id >> 6] |= 1ull << (id & 63); };
+        auto valid_add = [&](uint64_t h1, std::string_view rd) {  // (sequential callers only)
+            const char* at = vset[h1 >> 61].insert_at(h1, rd, !retain);
+            if (at) valid_views.emplace_back(at, rd.size());
+        };
+        bool chunk_done = false;  // the fast path has dealt with the whole chunk
         if (lookahead) {
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
             const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(16, hw), nz / 4096 + 1));
@@ -402,9 +506,83 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 const unsigned step = T >= 8 ? 8u : T >= 4 ? 4u : 2u;  // (eight parts: a divisor of eight threads take them)
                 for (unsigned t = 0; t < step; ++t) rem_threads.emplace_back([&, t, step] { remember(t, step); });  // (step by value: its scope ends before the threads do)
             }
-            for (uint64_t q = 0; q < std::min<uint64_t>(AHEAD, nz); ++q) warm(q);
+            if (!any_overflow.load()) {
+                // ---- the chunk without the order-dependent loop.  The reference counts a library k-mer the FIRST time it
+                // meets it in a chunk (novel_barcodes) and nothing else of that loop depends on the order: skipping a
+                // read equal to an earlier valid one changes nothing (that read's library k-mers are all in
+                // novel_barcodes by then).  first[] holds those first meetings; what is left is to walk them in order.
+                chunk_done = true;
+                any_read = nz > 0;
+                if (nz) last1_truthy = !c1.read(nz - 1).empty();
+                last2_truthy = false;
+                const uint64_t per = (nz + T - 1) / T;
+                std::vector<std::vector<uint64_t>> counted(T);  // (q << 3 | candidate) of the counted meetings, ascending
+                auto collect = [&](uint64_t t) {
+                    std::vector<uint64_t>& out_v = counted[t];
+                    for (uint64_t q = t * per; q < std::min(nz, (t + 1) * per); ++q) {
+                        const Ahead& a = prep[q];
+                        for (int c = 0; c < a.ncand; ++c)
+                            if (first[a.id[c]].load(std::memory_order_relaxed) == key_of(q, c)) out_v.push_back((q << 3) | (uint64_t)c);
+                    }
+                };
+                if (T == 1) collect(0);
+                else {
+                    std::vector<std::thread> th;
+                    for (uint64_t t = 0; t < T; ++t) th.emplace_back(collect, t);
+                    for (auto& x : th) x.join();
+                }
+                // counters in the order of the meetings (Counter ties resolve to the first inserted key): per chunk only the
+                // first appearance of a key and its total matter
+                std::vector<std::pair<int, int64_t>> or_seq;
+                std::vector<std::pair<int64_t, int64_t>> off_seq;
+                std::vector<int32_t> off_at;  // position -> index into off_seq, -1
+                int or_at[2] = {-1, -1};
+                std::vector<uint64_t> vq;     // the reads with a counted meeting, ascending
+                for (uint64_t t = 0; t < T; ++t)
+                    for (const uint64_t e : counted[t]) {
+                        const uint64_t q = e >> 3;
+                        const Ahead& a = prep[q];
+                        const int c = (int)(e & 7);
+                        ++all_novel;  // (c_barcodes.size() of the loop form)
+                        obs_mark(a.id[c]);
+                        if (vq.empty() || vq.back() != q) vq.push_back(q);
+                        const uint32_t pos = a.pos[c];
+                        if (pos >= off_at.size()) off_at.resize((size_t)pos + 64, -1);
+                        for (int lib = 0; lib < 2; ++lib)
+                            if (a.in[c] & (1 << lib)) {
+                                div[0]++;
+                                if (or_at[lib] < 0) { or_at[lib] = (int)or_seq.size(); or_seq.emplace_back(lib, 0); }
+                                or_seq[or_at[lib]].second++;
+                                if (off_at[pos] < 0) { off_at[pos] = (int32_t)off_seq.size(); off_seq.emplace_back((int64_t)pos, 0); }
+                                off_seq[off_at[pos]].second++;
+                            }
+                    }
+                for (const auto& it : or_seq) orients[0].add(it.first, it.second);
+                for (const auto& it : off_seq) offsets[0].add(it.first, it.second);
+                // valid reads: each part of the set takes its own reads (a new one leaves its address), then they join
+                // sample1 in the order of the meetings
+                std::vector<const char*> new_at(vq.size(), nullptr);
+                auto add_valid = [&](unsigned p0, unsigned step) {
+                    for (size_t j = 0; j < vq.size(); ++j) {
+                        const uint64_t h1 = prep[vq[j]].h1;
+                        const unsigned part = (unsigned)(h1 >> 61);
+                        if (part % step == p0) new_at[j] = vset[part].insert_at(h1, c1.read(vq[j]), !retain);
+                    }
+                };
+                const unsigned vstep = T >= 8 ? 8u : T >= 4 ? 4u : T >= 2 ? 2u : 1u;
+                if (vstep == 1 || vq.size() < 4096) add_valid(0, 1);
+                else {
+                    std::vector<std::thread> th;
+                    for (unsigned t = 0; t < vstep; ++t) th.emplace_back(add_valid, t, vstep);
+                    for (auto& x : th) x.join();
+                }
+                for (size_t j = 0; j < vq.size(); ++j)
+                    if (new_at[j]) valid_views.emplace_back(new_at[j], c1.read(vq[j]).size());
+            } else {
+                for (uint64_t q = 0; q < std::min<uint64_t>(AHEAD, nz); ++q) warm(q);
+            }
         }
-        for (uint64_t q = 0; q < nz; ++q) {
+        for (uint64_t q = 0; q < nz && !chunk_done; ++q) {
             const std::string_view read1 = c1.read(q);
             const std::string_view read2 = have2 ? c2.read(q) : std::string_view();
             any_read = true;
@@ -428,9 +606,9 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                         if (c_barcodes.contains(hk, kmer)) continue;
                         for (int lib = 0; lib < 2; ++lib)
                             if (a.in[c] & (1 << lib)) {
-                                div[0]++; c_barcodes.insert(hk, kmer); observed.insert(hk, kmer);
+                                div[0]++; c_barcodes.insert(hk, kmer); obs_mark(a.id[c]);
                                 c_or[0].push_back(lib); c_off[0].push_back((int64_t)i);
-                                if (valid[0].insert(h1, read1)) valid_store[0].emplace_back(read1);
+                                valid_add(h1, read1);
                             }
                     }
                     continue;
@@ -443,11 +621,13 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                     if (!roll1.at(read1, i, pf_bits, pf_small)) continue;
                     const uint64_t hk = str_hash(kmer);
                     if (c_barcodes.contains(hk, kmer)) continue;
+                    const int64_t idf = fwd.find(hk, kmer), idr = rev.find(hk, kmer);
                     for (int lib = 0; lib < 2; ++lib)
-                        if ((lib == 0 ? fwd : rev).contains(hk, kmer)) {
-                            div[0]++; c_barcodes.insert(hk, kmer); observed.insert(hk, kmer);
+                        if ((lib == 0 ? idf : idr) >= 0) {
+                            div[0]++; c_barcodes.insert(hk, kmer);
+                            obs_mark((uint32_t)(idf >= 0 ? (size_t)idf : fwd_slots + (size_t)idr));
                             c_or[0].push_back(lib); c_off[0].push_back((int64_t)i);
-                            if (valid[0].insert(h1, read1)) valid_store[0].emplace_back(read1);
+                            valid_add(h1, read1);
                             c_reads.insert(h1, read1);
                         }
                 }
@@ -493,6 +673,11 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
             for (auto& x : rem_threads) x.join();
             t_rem += std::chrono::duration<double, std::milli>(now() - t_r0).count();
         }
+        if (retain) {  // the sets hold views into this chunk's text: it stays (next_chunk allocates a new buffer)
+            kept_bytes += c1.text.size();
+            kept.push_back(std::move(c1.text));
+            c1.text = std::vector<char>();
+        }
         t_sweep += std::chrono::duration<double, std::milli>(now() - t_mark).count();
         all_novel += c_barcodes.size();
         for (int s = 0; s < 2; ++s) {
@@ -532,15 +717,35 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     const int64_t f2 = last2_truthy ? offsets[1].most_common(1)[0].first : -1;
     bc_sample* s = new bc_sample();
     s->n_novel = (int64_t)seen_count();
-    s->n_observed = observed.size();
+    if (lookahead) {
+        uint64_t n_obs = 0;
+        for (const uint64_t w : obs_bits) n_obs += (uint64_t)__builtin_popcountll(w);
+        s->n_observed = n_obs;
+    } else {
+        s->n_observed = observed.size();
+    }
     s->n_chunks = n_chunks;
     s->satisfied = satisfied;
+    // sample1 / sample2 as views: into the kept chunk texts and the sets' arenas (single-end fast path), or into the
+    // copies the other paths made
+    std::vector<std::string_view> views[2];
+    if (lookahead) {
+        views[0] = std::move(valid_views);
+        s->texts = std::move(kept);
+        s->arenas = std::move(vset);
+    } else {
+        for (int w = 0; w < 2; ++w) {
+            s->strs[w] = std::move(valid_store[w]);
+            views[w].reserve(s->strs[w].size());
+            for (const std::string& x : s->strs[w]) views[w].emplace_back(x);
+        }
+    }
     if (o1 == 0 || o2 == 1) {
         s->need_swap = 0; s->off1 = f1; s->off2 = f2;
-        s->valid1 = std::move(valid_store[0]); s->valid2 = std::move(valid_store[1]);
+        s->valid1 = std::move(views[0]); s->valid2 = std::move(views[1]);
     } else if (o1 == 1 || o2 == 0) {
         s->need_swap = 1; s->off1 = f2; s->off2 = f1;
-        s->valid1 = std::move(valid_store[1]); s->valid2 = std::move(valid_store[0]);
+        s->valid1 = std::move(views[1]); s->valid2 = std::move(views[0]);
     } else {
         delete s;
         set_error("Unable to determine orientation of reads. Please check the input files.");
@@ -572,7 +777,7 @@ int bc_sample_flanks(const bc_sample* s, int which, int64_t start, int bc_len, i
         set_error("bc_sample_flanks: bad argument");
         return BC_EINVAL;
     }
-    const std::vector<std::string>& reads = which ? s->valid2 : s->valid1;
+    const std::vector<std::string_view>& reads = which ? s->valid2 : s->valid1;
     const auto t_begin = std::chrono::steady_clock::now();
     // Counter of the flank candidates: a candidate is at most max_flank <= 64 characters... in practice ten, so up to
     // 15 characters travel as one 128-bit key (characters + length) through an open-addressing table that remembers
@@ -635,14 +840,14 @@ int bc_sample_flanks(const bc_sample* s, int which, int64_t start, int bc_len, i
     FlankCounter tally[2];
     auto count_range = [&](size_t r0, size_t r1, FlankCounter (&tl)[2]) {
         for (size_t ri = r0; ri < r1; ++ri) {
-            const std::string& read = reads[ri];
+            const std::string_view read = reads[ri];
             const int64_t n = (int64_t)read.size();
             // python slices: read[start-max_flank:start] (or read[0:start]) and read[start+k : start+k+max_flank]
             int64_t a = start - max_flank >= 0 ? start - max_flank : 0, b = std::min<int64_t>(std::max<int64_t>(start, 0), n);
             a = std::min(a, n);
-            std::string_view left = b > a ? std::string_view(read).substr((size_t)a, (size_t)(b - a)) : std::string_view();
+            std::string_view left = b > a ? read.substr((size_t)a, (size_t)(b - a)) : std::string_view();
             int64_t c = std::min<int64_t>(std::max<int64_t>(start + bc_len, 0), n), d = std::min<int64_t>(std::max<int64_t>(start + bc_len + max_flank, 0), n);
-            std::string_view right = d > c ? std::string_view(read).substr((size_t)c, (size_t)(d - c)) : std::string_view();
+            std::string_view right = d > c ? read.substr((size_t)c, (size_t)(d - c)) : std::string_view();
             for (size_t m = left.size(); m > 0; --m) tl[0].add(left.substr(left.size() - m));
             for (size_t m = right.size(); m > 0; --m) tl[1].add(right.substr(0, m));
         }

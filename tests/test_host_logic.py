@@ -727,3 +727,57 @@ def test_reader_raw_stream(tmp_path):
                 while got.value:
                     N.check(L.bc_reader_read_raw(h, N.ptr(buf), buf.size, Ct.byref(got)))
             L.bc_reader_close(h)
+
+
+def test_native_sampling_fast_path_equals_loop_form(tmp_path):
+    """The single-end sampler counts a chunk's library k-mers from a table of first meetings filled by worker threads
+    (bc_sample.cpp) instead of walking the reads in order; a chunk that holds a read with more library k-mers than the
+    look-ahead keeps takes the loop form.  Both must give what the golden-pinned Python statement of
+    heuristicount.py:156-379 gives, on input built to hit the corners: repeated reads, reverse-complement barcodes,
+    entries that are their own reverse complement or each other's, reads with two barcodes, a read with eight (third
+    chunk only), short reads, an N inside a window."""
+    import random
+    from barcoder_amd import heuristicount as H
+    rng = random.Random(5)
+    k, G = 16, 12000
+    rc = lambda s: s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    lib = ["ACGTACGTACGTACGT", "AAAACCCCGGGGTTTT"]            # their own reverse complements
+    lib += ["ACGGTCATGCATGGCA", rc("ACGGTCATGCATGGCA")]         # each other's
+    while len(lib) < G:
+        lib.append("".join(rng.choice("ACGT") for _ in range(k)))
+    lib = list(dict.fromkeys(lib))
+    L, R = "CCGGATTCAG", "GTTTTAGAGC"
+    reads = []
+    n = 6 * len(lib)
+    for i in range(n):
+        u = rng.random()
+        pre = "".join(rng.choice("ACGT") for _ in range(5))
+        if u < 0.10 and reads:
+            r = reads[rng.randrange(len(reads))]                  # an earlier read again
+        elif u < 0.20:
+            r = pre + L + rc(rng.choice(lib)) + R
+        elif u < 0.22:
+            r = pre + L + rng.choice(lib) + rng.choice(lib) + R   # two barcodes (and whatever straddles them)
+        elif u < 0.24:
+            r = pre + L + rng.choice(lib)[:10]                    # short
+        elif u < 0.26:
+            b = rng.choice(lib)
+            r = pre + L + b[:7] + "N" + b[8:] + R
+        elif u < 0.30:
+            r = pre + L + lib[rng.randrange(4)] + R               # the palindromic corner, often
+        else:
+            r = pre + L + rng.choice(lib) + R
+        reads.append(r)
+    reads[2 * len(lib) + 17] = "".join(rng.choice(lib) for _ in range(8))   # eight barcodes: the third chunk's loop form
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">b{i}\n{s}\n" for i, s in enumerate(lib)))
+    rd = tmp_path / "r.reads"
+    rd.write_text("".join(r + "\n" for r in reads))
+    ordered = H.read_fasta_ordered(str(fa))
+    want = H.sample_data(str(rd), None, set(ordered), False)
+    smp = H.NativeSample(str(rd), None, ordered, False)
+    got = (smp.n_novel, smp.offset1, smp.offset2, smp.n_valid1, smp.n_valid2, smp.n_observed, smp.need_swap, smp.num_chunks)
+    assert got == (want[0], want[1], want[2], len(want[3]), len(want[4]), len(want[5]), want[6], want[7])
+    assert want[7] >= 4 and want[1] == 15
+    assert tuple(smp.flanks(0, smp.offset1, k)) == tuple(H.find_flanks(want[3], want[1], k))
+    smp.close()
