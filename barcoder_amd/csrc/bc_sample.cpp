@@ -193,8 +193,24 @@ struct LibSet {
     size_t slots() const { return base[8]; }
 };
 
+// a chunk's text: bytes that nobody zeroes first (a std::vector<char> of 6 MB per chunk costs a pass over them)
+struct TextBuf {
+    std::unique_ptr<char[]> p;
+    size_t n = 0;
+    char* data() { return p.get(); }
+    const char* data() const { return p.get(); }
+    size_t size() const { return n; }
+    void resize(size_t m) {  // keeps the first min(n, m) bytes
+        if (m == n) return;
+        std::unique_ptr<char[]> q(new char[std::max<size_t>(m, 1)]);
+        if (n && m) memcpy(q.get(), p.get(), std::min(n, m));
+        p = std::move(q);
+        n = m;
+    }
+};
+
 struct Chunk {
-    std::vector<char> text;
+    TextBuf text;
     std::vector<uint64_t> off;
     uint64_t n = 0;
     std::string_view read(uint64_t i) const { return std::string_view(text.data() + off[i], off[i + 1] - off[i]); }
@@ -267,7 +283,7 @@ struct bc_sample {
     int64_t n_novel = 0, off1 = -1, off2 = -1;  // -1 = None
     std::vector<std::string_view> valid1, valid2;  // sample1 / sample2 AFTER the swap rule: views into what follows
     std::vector<std::string> strs[2];              // (the paired / unfiltered path keeps copies)
-    std::vector<std::vector<char>> texts;          // (single-end fast path: the sampled chunks' text, kept)
+    std::vector<TextBuf> texts;                    // (single-end fast path: the sampled chunks' text, kept)
     std::vector<StrSet> arenas;                    // (... and the sets whose arenas hold what was copied instead)
     uint64_t n_observed = 0, n_chunks = 0;
     int need_swap = 0, satisfied = 0;
@@ -352,7 +368,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
 
     const bool prof = getenv("BC_SAMPLE_PROF") != nullptr;  // tuning aid: where the sampling pass spends its time
     auto now = [] { return std::chrono::steady_clock::now(); };
-    double t_setup = 0, t_read = 0, t_sweep = 0, t_prep = 0, t_rem = 0;
+    double t_setup = 0, t_read = 0, t_sweep = 0, t_prep = 0, t_rem = 0, t_collect = 0, t_count = 0, t_valid = 0, t_alloc = 0;
     static thread_local std::chrono::steady_clock::time_point t_enter;
     t_setup = std::chrono::duration<double, std::milli>(now() - t_entry).count();
     auto t_mark = now();
@@ -375,7 +391,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     std::vector<StrSet> vset;
     for (int p = 0; p < 8; ++p) vset.emplace_back(lookahead ? (size_t)n_lib / 4 : 0, true);
     std::vector<std::string_view> valid_views;
-    std::vector<std::vector<char>> kept;
+    std::vector<TextBuf> kept;
     size_t kept_bytes = 0;
     const size_t fwd_slots = fwd.slots(), id_slots = fwd_slots + rev.slots();
     std::vector<uint64_t> obs_bits(lookahead ? (id_slots + 63) / 64 : 0, 0);
@@ -389,23 +405,44 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         for (const StrSet& p : seen_part) n += p.size();
         return n;
     };
+    // what the worker threads note per read of a chunk (see the loop): reused from chunk to chunk, never cleared
+    constexpr uint64_t AHEAD = 12;
+    constexpr int MAXC = 6;
+    struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint32_t id[MAXC]; uint8_t in[MAXC]; };  // in: bit 0 forward set, bit 1 reverse
+    std::vector<Ahead> prep;
     uint64_t all_novel = 0;
     bool satisfied = false;
     uint64_t n_chunks = 0;
     bool last1_truthy = false, last2_truthy = false, any_read = false;
     Chunk c1, c2;
+    // single-end fast path: the next chunk is read by a thread of its own while this one is worked on (the stopping rule
+    // may make that one read too many; the reader is used by one thread at a time)
+    Chunk ahead_chunk;
+    std::thread ahead_reader;
+    int ahead_rc = BC_OK;
+    auto join_reader = [&]() { if (ahead_reader.joinable()) ahead_reader.join(); };
     for (;;) {
         t_mark = now();
-        if ((rc = next_chunk(r1, n_lib, c1)) != BC_OK) break;
-        if (paired && (rc = next_chunk(r2, n_lib, c2)) != BC_OK) break;
+        if (lookahead && n_chunks > 0) {
+            join_reader();
+            rc = ahead_rc;
+            if (rc != BC_OK) break;
+            std::swap(c1, ahead_chunk);
+        } else {
+            if ((rc = next_chunk(r1, n_lib, c1)) != BC_OK) break;
+            if (paired && (rc = next_chunk(r2, n_lib, c2)) != BC_OK) break;
+        }
         t_read += std::chrono::duration<double, std::milli>(now() - t_mark).count();
         if (c1.n == 0) break;
+        if (lookahead) ahead_reader = std::thread([&] { ahead_rc = next_chunk(r1, n_lib, ahead_chunk); });
         t_mark = now();
         ++n_chunks;
         std::vector<int> c_or[2];
         std::vector<int64_t> c_off[2];
-        c_barcodes.clear();
-        c_reads.clear();
+        if (!lookahead) {  // (the fast path clears them only for a chunk that takes the loop form)
+            c_barcodes.clear();
+            c_reads.clear();
+        }
         // zip(read1_chunk, read2_chunk if read2_chunk else [None]*len): an EMPTY mate chunk means "None" mates
         const bool have2 = paired && c2.n > 0;
         const uint64_t nz = have2 ? std::min(c1.n, c2.n) : c1.n;
@@ -413,9 +450,6 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         // several MB.  A few reads ahead of the one being processed, hash the read, sweep its windows through the
         // pre-filter, hash the windows that pass and prefetch every slot the read will touch; the processing below then
         // runs the reference's sequential logic unchanged on warm lines.
-        constexpr uint64_t AHEAD = 12;
-        constexpr int MAXC = 6;
-        struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint64_t hk[MAXC]; uint32_t id[MAXC]; uint8_t in[MAXC]; };  // in: bit 0 forward set, bit 1 reverse
         // (id: the window's library id — the forward set's when it is there, else fwd_slots + the reverse set's: one
         // id per distinct string, which is what the reference's per-chunk novel_barcodes is keyed by)
         const uint64_t chunk_tag = (uint64_t)(0xFFFFFFull - std::min<uint64_t>(n_chunks, 0xFFFFFFull)) << 40;
@@ -426,7 +460,9 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         // (pre-filter, then the two library sets, which never change) — is a pure function of the read: computed for the
         // whole chunk by worker threads; the order-dependent logic below then touches only the reads that hold a
         // library k-mer (the reference's loop does nothing for the others except remember the read: see seen_part)
-        std::vector<Ahead> prep(lookahead ? nz : 0);
+        const auto t_a0 = now();
+        if (lookahead && prep.size() < nz) prep.resize(nz);  // (prepare() writes every field it or anybody reads)
+        t_alloc += std::chrono::duration<double, std::milli>(now() - t_a0).count();
         std::vector<std::thread> rem_threads;
         auto prepare = [&](uint64_t q) {
             Ahead& a = prep[q];
@@ -459,7 +495,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 if (!in) continue;  // (a false positive of the pre-filter)
                 if (a.ncand == MAXC) { a.overflow = true; any_overflow.store(true, std::memory_order_relaxed); break; }
                 const uint32_t id = (uint32_t)(idf >= 0 ? (size_t)idf : fwd_slots + (size_t)idr);
-                a.pos[a.ncand] = (uint32_t)i; a.hk[a.ncand] = hk; a.id[a.ncand] = id; a.in[a.ncand] = in;
+                a.pos[a.ncand] = (uint32_t)i; a.id[a.ncand] = id; a.in[a.ncand] = in;
                 // earliest occurrence of this library entry in the chunk (reads ascending, then positions)
                 const uint64_t key = key_of(q, a.ncand);
                 uint64_t cur = first[id].load(std::memory_order_relaxed);
@@ -467,10 +503,9 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 ++a.ncand;
             }
         };
-        auto warm = [&](uint64_t q) {  // pull the slots read q will touch towards the core
+        auto warm = [&](uint64_t q) {  // (loop form only) pull the slot read q will touch towards the core
             const Ahead& a = prep[q];
-            if (a.ncand) valid[0].prefetch(a.h1);
-            for (int c = 0; c < a.ncand; ++c) { c_barcodes.prefetch(a.hk[c]); observed.prefetch(a.hk[c]); }
+            if (a.ncand) vset[a.h1 >> 61].prefetch(a.h1);
         };
         // seen_reads only ever answers "how many distinct reads so far": eight sets, one per range of the hash, filled by
         // as many threads (every thread looks at every read's hash and keeps its own)
@@ -512,6 +547,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 // read equal to an earlier valid one changes nothing (that read's library k-mers are all in
                 // novel_barcodes by then).  first[] holds those first meetings; what is left is to walk them in order.
                 chunk_done = true;
+                const auto t_c0 = now();
                 any_read = nz > 0;
                 if (nz) last1_truthy = !c1.read(nz - 1).empty();
                 last2_truthy = false;
@@ -531,6 +567,8 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                     for (uint64_t t = 0; t < T; ++t) th.emplace_back(collect, t);
                     for (auto& x : th) x.join();
                 }
+                const auto t_c1 = now();
+                t_collect += std::chrono::duration<double, std::milli>(t_c1 - t_c0).count();
                 // counters in the order of the meetings (Counter ties resolve to the first inserted key): per chunk only the
                 // first appearance of a key and its total matter
                 std::vector<std::pair<int, int64_t>> or_seq;
@@ -559,6 +597,8 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                     }
                 for (const auto& it : or_seq) orients[0].add(it.first, it.second);
                 for (const auto& it : off_seq) offsets[0].add(it.first, it.second);
+                const auto t_c2 = now();
+                t_count += std::chrono::duration<double, std::milli>(t_c2 - t_c1).count();
                 // valid reads: each part of the set takes its own reads (a new one leaves its address), then they join
                 // sample1 in the order of the meetings
                 std::vector<const char*> new_at(vq.size(), nullptr);
@@ -578,7 +618,10 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 }
                 for (size_t j = 0; j < vq.size(); ++j)
                     if (new_at[j]) valid_views.emplace_back(new_at[j], c1.read(vq[j]).size());
+                t_valid += std::chrono::duration<double, std::milli>(now() - t_c2).count();
             } else {
+                c_barcodes.clear();
+                c_reads.clear();
                 for (uint64_t q = 0; q < std::min<uint64_t>(AHEAD, nz); ++q) warm(q);
             }
         }
@@ -601,8 +644,8 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                     // reference's loop that do anything
                     for (int c = 0; c < a.ncand; ++c) {
                         const size_t i = a.pos[c];
-                        const uint64_t hk = a.hk[c];
                         const std::string_view kmer = read1.substr(i, k);
+                        const uint64_t hk = str_hash(kmer);
                         if (c_barcodes.contains(hk, kmer)) continue;
                         for (int lib = 0; lib < 2; ++lib)
                             if (a.in[c] & (1 << lib)) {
@@ -676,10 +719,10 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         if (retain) {  // the sets hold views into this chunk's text: it stays (next_chunk allocates a new buffer)
             kept_bytes += c1.text.size();
             kept.push_back(std::move(c1.text));
-            c1.text = std::vector<char>();
+            c1.text = TextBuf();
         }
         t_sweep += std::chrono::duration<double, std::milli>(now() - t_mark).count();
-        all_novel += c_barcodes.size();
+        if (!chunk_done) all_novel += c_barcodes.size();
         for (int s = 0; s < 2; ++s) {
             for (int o : c_or[s]) orients[s].add(o);
             for (int64_t o : c_off[s]) offsets[s].add(o);
@@ -698,12 +741,15 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
             if (done) break;
         }
     }
+    join_reader();
     bc_reader_close(r1);
     if (r2) bc_reader_close(r2);
     (void)t_enter; (void)t_setup;
     if (prof) fprintf(stderr, "bc_sample_data: %llu chunks of %llu reads: reading %.1f ms, sweep %.1f ms (of it: per-read work on threads %.1f, "
-                      "waiting for the distinct-read count %.1f), sets + filter before the first chunk %.1f ms\n",
-                      (unsigned long long)n_chunks, (unsigned long long)n_lib, t_read, t_sweep, t_prep, t_rem, t_setup);
+                      "waiting for the distinct-read count %.1f; first meetings collected %.1f, counters %.1f, valid reads %.1f, "
+                      "look-ahead array %.1f), sets + filter before the first chunk %.1f ms\n",
+                      (unsigned long long)n_chunks, (unsigned long long)n_lib, t_read, t_sweep, t_prep, t_rem, t_collect, t_count,
+                      t_valid, t_alloc, t_setup);
     if (rc != BC_OK) return rc;
     if (!any_read) { set_error("Unable to determine orientation of reads. Please check the input files."); return BC_EINVAL; }
     // most_common(1)[0][0] on an empty Counter is an IndexError in the reference (logged by main)
