@@ -43,7 +43,8 @@ int bc_reader_close(bc_reader* r);
 
 namespace {
 
-constexpr uint64_t CHUNK = 16ull << 20;   // bytes of file per device pass
+constexpr uint64_t CHUNK_MIN = 16ull << 20;   // bytes of file per device pass: at least (small files, compressed streams) ...
+constexpr uint64_t CHUNK_MAX = 32ull << 20;   // ... and at most: see run_file
 constexpr uint64_t SLACK = 1ull << 20;    // longest line that may run past a chunk's end
 
 struct Geometry {
@@ -398,7 +399,7 @@ struct DevBuf {
 };
 
 struct Slot {  // one worker's buffers
-    uint8_t* h_text = nullptr;   // pinned, 1 + CHUNK + SLACK
+    uint8_t* h_text = nullptr;   // pinned, 1 + chunk + SLACK
     hipStream_t st = nullptr;
     DevBuf text, bits, nl, tmp, packed, status, best, odd;
     DevBuf mw, mk, mt;           // this chunk's undocumented windows (word, key[, text]) before they join the run-wide list
@@ -566,16 +567,26 @@ int run_file(FileJob& J) {
     const uint64_t byte_end = compressed ? ~0ull : std::min(J.byte_end, fsize_plain);
     const uint64_t byte_begin = compressed ? 0 : std::min(J.byte_begin, byte_end);
     const uint64_t span = compressed ? ~0ull : byte_end - byte_begin;
-    const uint64_t n_chunks = compressed ? ~0ull : (span + CHUNK - 1) / CHUNK;
-    std::mutex src_m;                       // compressed: the decoder, `src_next`, `src_done`, `carry`
-    uint64_t src_next = 0;
-    bool src_done = false;
-    std::vector<uint8_t> carry;             // compressed: decoded bytes from one before the next chunk's core on
     int T = J.n_threads;
     if (T <= 0) {  // default; BC_STREAM_THREADS overrides (tuning aid)
         const char* e = getenv("BC_STREAM_THREADS");
         T = e && atoi(e) > 0 ? atoi(e) : 8;  // measured, 4.6 GB file in the page cache: 4 / 8 / 12 / 16 threads -> 144-161 / 210 / 243 / 222 Mreads/s
     }
+    // Chunk size: 32 MiB for a long file, 16 MiB for a short one (under 2 GiB with eight workers: every worker gets several)
+    // and for a compressed stream (length unknown, pace the decoder's).  Measured on a 4.6 GB file in the page cache, eight
+    // workers (profiles/r04_stream_chunk_ab.txt): 16 / 32 / 64 MiB -> 260 / 283 / 202-213 Mreads/s in the bulk pass.  The
+    // workers' time is their pread() into the page-locked buffer (1.2-2.2 s summed over the threads against 0.3-0.5 s of
+    // launches): fewer, longer reads help up to 32 MiB; beyond it the last wave of chunks leaves workers idle.
+    // BC_STREAM_CHUNK_MB overrides (tests, tuning).
+    uint64_t CHUNK = CHUNK_MIN;
+    if (!compressed) CHUNK = std::min<uint64_t>(CHUNK_MAX, std::max<uint64_t>(CHUNK_MIN, (span / (4ull * (uint64_t)T)) / CHUNK_MIN * CHUNK_MIN));
+    if (const char* e = getenv("BC_STREAM_CHUNK_MB"))
+        if (atoi(e) >= 1 && atoi(e) <= 1024) CHUNK = (uint64_t)atoi(e) << 20;
+    const uint64_t n_chunks = compressed ? ~0ull : (span + CHUNK - 1) / CHUNK;
+    std::mutex src_m;                       // compressed: the decoder, `src_next`, `src_done`, `carry`
+    uint64_t src_next = 0;
+    bool src_done = false;
+    std::vector<uint8_t> carry;             // compressed: decoded bytes from one before the next chunk's core on
     T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)T, std::max<uint64_t>(n_chunks, 1)));
     if (compressed) T = std::min(T, 4);  // one decodes, the others upload / launch / collect
     const uint64_t kmask = kmer_mask(k);
@@ -833,7 +844,7 @@ int run_file(FileJob& J) {
         for (auto& t : th) t.join();
     }
     if (getenv("BC_STREAM_PROF"))
-        fprintf(stderr, "stream: %d threads, workers %.3f s; per-thread-summed ms: pread %.0f count %.0f order %.0f launch %.0f sync %.0f\n", T,
+        fprintf(stderr, "stream: %d threads, chunks of %llu MiB, workers %.3f s; per-thread-summed ms: pread %.0f count %.0f order %.0f launch %.0f sync %.0f\n", T, (unsigned long long)(CHUNK >> 20),
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_workers).count(), prof_us[0] / 1e3,
                 prof_us[1] / 1e3, prof_us[2] / 1e3, prof_us[3] / 1e3, prof_us[4] / 1e3);
     if (first_rc.load() != BC_OK) {

@@ -71,6 +71,10 @@ def read_fasta(fasta_file):
         return {line.strip() for line in fh if not line.startswith(">")}
 
 
+_ASCII_SPACE_NOT_NL = " \t\r\x0b\x0c\x1c\x1d\x1e\x1f"  # what str.strip() removes from an ASCII string, "\n" apart
+from itertools import repeat as _repeat  # noqa: E402
+
+
 def read_fasta_ordered(fasta_file, check_extension: bool = False):
     """Same lines as read_fasta, de-duplicated in file order (= guide index order)."""
     if check_extension and not fasta_file.endswith((".gz", ".zst", ".fasta", ".fa")):
@@ -86,6 +90,14 @@ def read_fasta_ordered(fasta_file, check_extension: bool = False):
     lines = text.split("\n")
     if lines and lines[-1] == "":  # (behind the last newline, or an empty file: iteration yields no such line)
         lines.pop()
+    # the usual file — ASCII, no blank or tab anywhere, header and sequence lines alternating — needs no per-line work
+    # (str.strip() has nothing to strip once "\n" is the only white space; 1e5 entries: 35 -> 15 ms of a job's fixed cost)
+    if text.isascii() and not any(c in text for c in _ASCII_SPACE_NOT_NL):
+        heads, seqs = lines[0::2], lines[1::2]
+        if (len(heads) == len(seqs) and all(map(str.startswith, heads, _repeat(">")))
+                and not any(map(str.startswith, seqs, _repeat(">")))):
+            return list(dict.fromkeys(seqs))
+        return list(dict.fromkeys([ln for ln in lines if not ln.startswith(">")]))
     return list(dict.fromkeys([ln.strip() for ln in lines if not ln.startswith(">")]))
 
 
@@ -108,10 +120,11 @@ def validate_barcodes(barcodes):
         raise ValueError("Pass a list or set of barcodes to validate.")
     if len(sequences) < 10:
         raise ValueError("The input contains fewer than 10 sequences. Please provide at least 10 short barcodes.")
-    for seq in sequences:
-        if len(seq) > 1000:
-            raise ValueError(f'The sequence "{seq[:30]}..." is longer than 1,000 bases. '
-                             "Provide a list or fasta file of short barcodes.")
+    if sequences and max(map(len, sequences)) > 1000:  # (one C-level pass; the loop only to name the offender)
+        for seq in sequences:
+            if len(seq) > 1000:
+                raise ValueError(f'The sequence "{seq[:30]}..." is longer than 1,000 bases. '
+                                 "Provide a list or fasta file of short barcodes.")
 
 
 def read_in_chunks(file1, file2=None, chunk_size=2 ** 16):
@@ -671,7 +684,7 @@ def count_barcodes(fasta_file, file1, file2=None, device: int = 0, max_mismatch:
     ordered_lines = read_fasta_ordered(fasta_file, check_extension=True)  # one pass over the file: set and file order
     barcodes = set(ordered_lines)
     validate_barcodes(barcodes)
-    lengths = {len(b) for b in barcodes}
+    lengths = set(map(len, ordered_lines))
     if len(lengths) != 1:
         log.warning("One of the assumptions of this analysis is that all barcodes are the same length\n%s", FEEDBACK)
         raise ValueError("All barcodes must be the same length")

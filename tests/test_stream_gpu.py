@@ -85,6 +85,38 @@ def test_device_ingest_equals_host_front_half(gpu_device, tmp_path, monkeypatch,
     assert dev["bulk_mreads_per_s"] > 0
 
 
+def test_chunk_size_does_not_change_the_result(gpu_device, tmp_path, monkeypatch):
+    """run_file cuts a long file into larger chunks (16 or 32 MiB by the file's size; BC_STREAM_CHUNK_MB overrides):
+    the same FASTQ as 3 MiB chunks (a dozen, ragged ends everywhere), as the default and as one 48 MiB chunk gives the
+    same documented counts, first-seen order, undocumented table and odd windows."""
+    from barcoder_amd import encoding as E, heuristicount as H, synth as S
+    k = 20
+    rng = np.random.default_rng(77)
+    lib = S.library(3000, k)
+    lib_s = E.unpack_kmers(lib, k)
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">g{i}\n{s}\n" for i, s in enumerate(lib_s)))
+    n = 300_000
+    path = _make_file(tmp_path, "r.fastq", n, k, True, rng, lib_s, False, True)
+    assert 20 << 20 < os.path.getsize(path) < 48 << 20
+    got = {}
+    for mb in ("3", None, "48"):
+        if mb is None:
+            monkeypatch.delenv("BC_STREAM_CHUNK_MB", raising=False)
+        else:
+            monkeypatch.setenv("BC_STREAM_CHUNK_MB", mb)
+        got[mb] = H.count_barcodes(str(fa), path, device=gpu_device, max_mismatch=1)
+    monkeypatch.delenv("BC_STREAM_CHUNK_MB", raising=False)
+    a = got[None]
+    assert a["total_reads"] == n and a["bulk_pass"].startswith("device ingest")
+    for mb in ("3", "48"):
+        b = got[mb]
+        assert b["total_reads"] == n
+        assert list(a["doc"].items()) == list(b["doc"].items())
+        assert list(a["undoc"].items()) == list(b["undoc"].items())
+        assert a["undoc"].extra == b["undoc"].extra and len(a["undoc"].extra) > 0
+
+
 def _zstd_compress(raw: bytes):
     import ctypes
     try:
