@@ -572,7 +572,7 @@ int run_file(FileJob& J) {
         const char* e = getenv("BC_STREAM_THREADS");
         T = e && atoi(e) > 0 ? atoi(e) : 8;  // measured, 4.6 GB file in the page cache: 4 / 8 / 12 / 16 threads -> 144-161 / 210 / 243 / 222 Mreads/s
     }
-    // Chunk size: 32 MiB for a long file, 16 MiB for a short one (under 2 GiB with eight workers: every worker gets several)
+    // Chunk size: 32 MiB for a long file, 16 MiB for a short one (under 1 GiB with eight workers: every worker gets several)
     // and for a compressed stream (length unknown, pace the decoder's).  Measured on a 4.6 GB file in the page cache, eight
     // workers (profiles/r04_stream_chunk_ab.txt): 16 / 32 / 64 MiB -> 260 / 283 / 202-213 Mreads/s in the bulk pass.  The
     // workers' time is their pread() into the page-locked buffer (1.2-2.2 s summed over the threads against 0.3-0.5 s of
