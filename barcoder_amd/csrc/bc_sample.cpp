@@ -379,7 +379,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     const bool lookahead = !paired && prefilter;  // the single-end fast path (below)
     // (single-end runs with the pre-filter count their distinct reads in seen_part instead: no table to clear for nothing)
     StrSet valid[2] = {StrSet(lookahead ? 0 : 2 * (size_t)n_lib), StrSet(paired ? 2 * (size_t)n_lib : 0)},
-           seen_reads(lookahead ? 0 : 6 * (size_t)n_lib), observed(lookahead ? 0 : 2 * (size_t)n_lib);
+           seen_reads((lookahead || (paired && prefilter)) ? 0 : 6 * (size_t)n_lib), observed(lookahead ? 0 : 2 * (size_t)n_lib);
     StrSet c_barcodes((size_t)n_lib, false), c_reads((size_t)n_lib, false);  // per chunk: views into the chunk's text
     std::vector<StrSet> seen_part;  // single-end runs with the pre-filter: seen_reads in eight parts (see `remember`)
     for (int p = 0; p < 8; ++p) seen_part.emplace_back((size_t)0);  // (they grow inside their own threads)
@@ -410,6 +410,14 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     constexpr int MAXC = 6;
     struct Ahead { uint64_t h1; int ncand; bool overflow; uint32_t pos[MAXC]; uint32_t id[MAXC]; uint8_t in[MAXC]; };  // in: bit 0 forward set, bit 1 reverse
     std::vector<Ahead> prep;
+    // mate pairs with the pre-filter: the windows of both mates that are library entries, found by the worker threads; the
+    // reference's loop then runs over those alone (it does nothing at any other position), and the distinct-read count is
+    // taken by partitions afterwards (it depends on which pairs the loop skipped)
+    const bool lookahead2 = paired && prefilter;
+    constexpr int MAXC2 = 8;
+    struct Ahead2 { uint64_t h1, h2; int ncand; bool overflow, skipped; uint32_t pos[MAXC2]; uint8_t in1[MAXC2], in2[MAXC2]; };
+    std::vector<Ahead2> prep2;
+    const uint64_t h_none = str_hash(std::string_view("\x01None"));
     uint64_t all_novel = 0;
     bool satisfied = false;
     uint64_t n_chunks = 0;
@@ -520,6 +528,86 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
             const char* at = vset[h1 >> 61].insert_at(h1, rd, !retain);
             if (at) valid_views.emplace_back(at, rd.size());
         };
+        // ---- mate pairs: candidates of both mates, merged by position
+        auto scan_read = [&](std::string_view rd, size_t n_windows, uint32_t* pos, uint8_t* in, int cap) -> int {  // -1: more than cap
+            int n = 0;
+            if ((int64_t)rd.size() < k || n_windows == 0) return 0;
+            const uint64_t kmask2 = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+            const uint64_t* const small = pf_small.data();
+            const uint64_t* const big = pf_bits.data();
+            uint64_t v = 0;
+            int run = 0;
+            const size_t len = std::min(rd.size(), n_windows - 1 + (size_t)k);
+            for (size_t e = 0; e < len; ++e) {
+                const unsigned c = kCode[(unsigned char)rd[e]];
+                v = ((v << 2) | (c & 3u)) & kmask2;
+                run = c < 4 ? run + 1 : 0;
+                if (run < k) continue;
+                const uint32_t hs = Roll::hash_small(v);
+                if (!((small[hs >> 6] >> (hs & 63)) & 1ull)) continue;
+                const uint32_t hb = Roll::hash(v);
+                if (!((big[hb >> 6] >> (hb & 63)) & 1ull)) continue;
+                const size_t i = e + 1 - (size_t)k;
+                const std::string_view kmer = rd.substr(i, k);
+                const uint64_t hk = str_hash(kmer);
+                const uint8_t b = (uint8_t)((fwd.contains(hk, kmer) ? 1 : 0) | (rev.contains(hk, kmer) ? 2 : 0));
+                if (!b) continue;
+                if (n == cap) return -1;
+                pos[n] = (uint32_t)i; in[n] = b; ++n;
+            }
+            return n;
+        };
+        auto prepare2 = [&](uint64_t q) {
+            Ahead2& a = prep2[q];
+            const std::string_view r1 = c1.read(q);
+            const std::string_view r2 = have2 ? c2.read(q) : std::string_view();
+            a.h1 = str_hash(r1);
+            a.h2 = have2 ? str_hash(r2) : h_none;   // (what seen_reads gets beside read1: the mate, or the "None" of an empty mate chunk)
+            a.ncand = 0; a.overflow = false; a.skipped = false;
+            if ((int64_t)r1.size() < k) return;
+            const size_t n_windows = r1.size() - (size_t)k + 1;   // the loop runs over the FIRST mate's windows
+            uint32_t p1[MAXC2], p2[MAXC2];
+            uint8_t b1[MAXC2], b2[MAXC2];
+            const int n1 = scan_read(r1, n_windows, p1, b1, MAXC2);
+            const int n2 = have2 ? scan_read(r2, n_windows, p2, b2, MAXC2) : 0;
+            if (n1 < 0 || n2 < 0) { a.overflow = true; return; }
+            int i1 = 0, i2 = 0;
+            while (i1 < n1 || i2 < n2) {
+                if (a.ncand == MAXC2) { a.overflow = true; return; }
+                const uint32_t pa = i1 < n1 ? p1[i1] : 0xFFFFFFFFu, pb = i2 < n2 ? p2[i2] : 0xFFFFFFFFu;
+                const uint32_t pp = std::min(pa, pb);
+                a.pos[a.ncand] = pp;
+                a.in1[a.ncand] = pa == pp ? b1[i1++] : (uint8_t)0;
+                a.in2[a.ncand] = pb == pp ? b2[i2++] : (uint8_t)0;
+                ++a.ncand;
+            }
+        };
+        // what the loop did not skip goes into seen_reads: read1 and the mate (or "None"), by hash partition
+        auto remember2 = [&](unsigned part0, unsigned step) {
+            for (uint64_t q = 0; q < nz; ++q) {
+                const Ahead2& a = prep2[q];
+                if (a.skipped) continue;
+                const unsigned pa = (unsigned)(a.h1 >> 61), pb = (unsigned)(a.h2 >> 61);
+                if (pa % step == part0) seen_part[pa].insert(a.h1, c1.read(q));
+                if (pb % step == part0) seen_part[pb].insert(a.h2, have2 ? c2.read(q) : std::string_view("\x01None"));
+            }
+        };
+        if (lookahead2) {
+            if (prep2.size() < nz) prep2.resize(nz);
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(16, hw), nz / 4096 + 1));
+            const auto t_p0 = now();
+            if (T == 1) {
+                for (uint64_t q = 0; q < nz; ++q) prepare2(q);
+            } else {
+                std::vector<std::thread> th;
+                const uint64_t per = (nz + T - 1) / T;
+                for (uint64_t t = 0; t < T; ++t)
+                    th.emplace_back([&, t] { for (uint64_t q = t * per; q < std::min(nz, (t + 1) * per); ++q) prepare2(q); });
+                for (auto& x : th) x.join();
+            }
+            t_prep += std::chrono::duration<double, std::milli>(now() - t_p0).count();
+        }
         bool chunk_done = false;  // the fast path has dealt with the whole chunk
         if (lookahead) {
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -676,11 +764,50 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 }
                 continue;
             }
-            const uint64_t h1 = str_hash(read1), h2 = last2_truthy ? str_hash(read2) : 0;
-            if (c_reads.contains(h1, read1) || (last2_truthy && c_reads.contains(h2, read2))) continue;
-            seen_reads.insert(h1, read1);
-            if (paired) seen_reads.insert(have2 ? read2 : std::string_view("\x01None"));
+            const bool la2 = lookahead2;
+            const uint64_t h1 = la2 ? prep2[q].h1 : str_hash(read1), h2 = last2_truthy ? (la2 ? prep2[q].h2 : str_hash(read2)) : 0;
+            if (c_reads.contains(h1, read1) || (last2_truthy && c_reads.contains(h2, read2))) {
+                if (la2) prep2[q].skipped = true;
+                continue;
+            }
+            if (!la2) {
+                seen_reads.insert(h1, read1);
+                if (paired) seen_reads.insert(have2 ? read2 : std::string_view("\x01None"));
+            }
             if ((int64_t)read1.size() < k) continue;
+            if (la2 && !prep2[q].overflow) {
+                // the positions where either mate's window is a library entry, ascending: the iterations of the
+                // reference's loop that do anything (a window already met in this chunk skips its mate's, as there)
+                const Ahead2& a = prep2[q];
+                for (int c = 0; c < a.ncand; ++c) {
+                    const size_t i = a.pos[c];
+                    const std::string_view kmer = read1.substr(i, k);
+                    if (a.in1[c]) {
+                        const uint64_t hk = str_hash(kmer);
+                        if (c_barcodes.contains(hk, kmer)) continue;
+                        for (int lib = 0; lib < 2; ++lib)
+                            if (a.in1[c] & (1 << lib)) {
+                                div[0]++; c_barcodes.insert(hk, kmer); observed.insert(hk, kmer);
+                                c_or[0].push_back(lib); c_off[0].push_back((int64_t)i);
+                                if (valid[0].insert(h1, read1)) valid_store[0].emplace_back(read1);
+                                c_reads.insert(h1, read1);
+                            }
+                    }
+                    if (a.in2[c]) {
+                        const std::string_view kmer2 = read2.substr(i, k);
+                        const uint64_t hk2 = str_hash(kmer2);
+                        if (c_barcodes.contains(hk2, kmer2)) continue;
+                        for (int lib = 0; lib < 2; ++lib)
+                            if (a.in2[c] & (1 << lib)) {
+                                div[1]++; c_barcodes.insert(hk2, kmer2); observed.insert(kmer);  // sic: the first mate's k-mer
+                                c_or[1].push_back(lib); c_off[1].push_back((int64_t)i);
+                                if (valid[1].insert(h2, read2)) valid_store[1].emplace_back(read2);
+                                c_reads.insert(h2, read2);
+                            }
+                    }
+                }
+                continue;
+            }
             Roll roll1(k), roll2(k);
             for (size_t i = 0; i + k <= read1.size(); ++i) {
                 const std::string_view kmer = read1.substr(i, k);
@@ -710,6 +837,12 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                         }
                 }
             }
+        }
+        if (lookahead2) {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const unsigned step = (hw >= 8 && nz >= 8192) ? 8u : (hw >= 4 && nz >= 8192) ? 4u : 1u;
+            if (step == 1) remember2(0, 1);
+            else for (unsigned t = 0; t < step; ++t) rem_threads.emplace_back([&, t, step] { remember2(t, step); });
         }
         {
             const auto t_r0 = now();

@@ -781,3 +781,64 @@ def test_native_sampling_fast_path_equals_loop_form(tmp_path):
     assert want[7] >= 4 and want[1] == 15
     assert tuple(smp.flanks(0, smp.offset1, k)) == tuple(H.find_flanks(want[3], want[1], k))
     smp.close()
+
+
+def test_native_sampling_mate_pairs_equal_loop_form(tmp_path):
+    """Mate pairs with the pre-filter: the worker threads find the windows of both mates that are library entries and the
+    reference's loop runs over those positions alone; the distinct-read count is taken afterwards from the pairs the loop
+    did not skip.  Held against the golden-pinned Python statement of heuristicount.py:156-379 on pairs built to hit the
+    coupling between the mates: a first-mate window already met skips its mate's, a pair is skipped when EITHER mate
+    equals an earlier valid read, mates shorter than the first mate, barcodes past the first mate's last window, a pair
+    with more library k-mers than the look-ahead keeps."""
+    import random
+    from barcoder_amd import heuristicount as H
+    rng = random.Random(9)
+    k, G = 16, 9000
+    rc = lambda s: s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    lib = ["ACGTACGTACGTACGT"]
+    while len(lib) < G:
+        lib.append("".join(rng.choice("ACGT") for _ in range(k)))
+    lib = list(dict.fromkeys(lib))
+    L, R = "CCGGATTCAG", "GTTTTAGAGC"
+    r1s, r2s = [], []
+    n = 7 * len(lib)
+    for i in range(n):
+        u = rng.random()
+        b = rng.choice(lib)
+        pre = "".join(rng.choice("ACGT") for _ in range(5))
+        r1 = pre + L + b + R
+        r2 = pre[:3] + rc(L + b + R)
+        if u < 0.08 and r1s:
+            j = rng.randrange(len(r1s))
+            r1 = r1s[j]                                           # first mate seen before, another mate
+        elif u < 0.16 and r2s:
+            r2 = r2s[rng.randrange(len(r2s))]                     # mate seen before
+        elif u < 0.20:
+            r2 = r2[:rng.randrange(0, 25)]                        # short (or empty) mate
+        elif u < 0.24:
+            r1 = r1[:20]                                          # short first mate: few windows, the mate's barcode lies past them
+        elif u < 0.28:
+            r2 = "AC" + L + b + R                                 # both mates carry the SAME k-mer at the same position
+            r1 = "AC" + L + b + R
+        elif u < 0.32:
+            r2 = pre + L + rng.choice(lib) + R                    # forward barcode in the mate
+        elif u < 0.34:
+            r1 = pre + L + "N" + b[1:] + R
+        r1s.append(r1); r2s.append(r2)
+    j = 2 * len(lib) + 5
+    r1s[j] = "".join(rng.choice(lib) for _ in range(6))
+    r2s[j] = "".join(rng.choice(lib) for _ in range(6))          # twelve library k-mers in one pair
+    fa = tmp_path / "lib.fasta"
+    fa.write_text("".join(f">b{i}\n{s}\n" for i, s in enumerate(lib)))
+    f1, f2 = tmp_path / "a.reads", tmp_path / "b.reads"
+    f1.write_text("".join(r + "\n" for r in r1s))
+    f2.write_text("".join(r + "\n" for r in r2s))
+    ordered = H.read_fasta_ordered(str(fa))
+    want = H.sample_data(str(f1), str(f2), set(ordered), True)
+    smp = H.NativeSample(str(f1), str(f2), ordered, True)
+    got = (smp.n_novel, smp.offset1, smp.offset2, smp.n_valid1, smp.n_valid2, smp.n_observed, smp.need_swap, smp.num_chunks)
+    assert got == (want[0], want[1], want[2], len(want[3]), len(want[4]), len(want[5]), want[6], want[7])
+    assert want[7] >= 3 and len(want[3]) > 1000 and len(want[4]) > 1000
+    assert tuple(smp.flanks(0, smp.offset1, k)) == tuple(H.find_flanks(want[3], want[1], k))
+    assert tuple(smp.flanks(1, smp.offset2, k)) == tuple(H.find_flanks(want[4], want[2], k))
+    smp.close()
