@@ -289,6 +289,14 @@ struct bc_sample {
     int need_swap = 0, satisfied = 0;
 };
 
+// worker threads of the sampling pass for a chunk of nz reads: one per 2 048 reads, at most 16 (32 on a host with 64+
+// hardware threads: measured on the 128-thread GPU box); BC_SAMPLE_THREADS overrides (tuning, tests)
+static uint64_t sample_threads(unsigned hw, uint64_t nz) {
+    if (const char* e = getenv("BC_SAMPLE_THREADS"))
+        if (atoi(e) >= 1 && atoi(e) <= 256) return (uint64_t)atoi(e);
+    return std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(hw >= 64 ? 32 : 16, hw), nz / 2048 + 1));
+}
+
 extern "C" {
 
 int bc_sample_data(const char* file1, const char* file2, const char* barcodes, uint32_t G, int k, bc_sample** out) {
@@ -595,7 +603,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         if (lookahead2) {
             if (prep2.size() < nz) prep2.resize(nz);
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(16, hw), nz / 4096 + 1));
+            const uint64_t T = sample_threads(hw, nz);
             const auto t_p0 = now();
             if (T == 1) {
                 for (uint64_t q = 0; q < nz; ++q) prepare2(q);
@@ -611,7 +619,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
         bool chunk_done = false;  // the fast path has dealt with the whole chunk
         if (lookahead) {
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            const uint64_t T = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(16, hw), nz / 4096 + 1));
+            const uint64_t T = sample_threads(hw, nz);
             const auto t_p0 = now();
             if (T == 1) {
                 for (uint64_t q = 0; q < nz; ++q) prepare(q);
@@ -639,20 +647,22 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 any_read = nz > 0;
                 if (nz) last1_truthy = !c1.read(nz - 1).empty();
                 last2_truthy = false;
-                const uint64_t per = (nz + T - 1) / T;
-                std::vector<std::vector<uint64_t>> counted(T);  // (q << 3 | candidate) of the counted meetings, ascending
+                const uint64_t Tc = std::min<uint64_t>(T, 16);  // (light work: more threads cost more to start than they save)
+                const uint64_t per = (nz + Tc - 1) / Tc;
+                std::vector<std::vector<uint64_t>> counted(Tc);  // (q << 3 | candidate) of the counted meetings, ascending
                 auto collect = [&](uint64_t t) {
                     std::vector<uint64_t>& out_v = counted[t];
+                    out_v.reserve((size_t)per);
                     for (uint64_t q = t * per; q < std::min(nz, (t + 1) * per); ++q) {
                         const Ahead& a = prep[q];
                         for (int c = 0; c < a.ncand; ++c)
                             if (first[a.id[c]].load(std::memory_order_relaxed) == key_of(q, c)) out_v.push_back((q << 3) | (uint64_t)c);
                     }
                 };
-                if (T == 1) collect(0);
+                if (Tc == 1) collect(0);
                 else {
                     std::vector<std::thread> th;
-                    for (uint64_t t = 0; t < T; ++t) th.emplace_back(collect, t);
+                    for (uint64_t t = 0; t < Tc; ++t) th.emplace_back(collect, t);
                     for (auto& x : th) x.join();
                 }
                 const auto t_c1 = now();
@@ -664,7 +674,7 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
                 std::vector<int32_t> off_at;  // position -> index into off_seq, -1
                 int or_at[2] = {-1, -1};
                 std::vector<uint64_t> vq;     // the reads with a counted meeting, ascending
-                for (uint64_t t = 0; t < T; ++t)
+                for (uint64_t t = 0; t < Tc; ++t)
                     for (const uint64_t e : counted[t]) {
                         const uint64_t q = e >> 3;
                         const Ahead& a = prep[q];
