@@ -395,7 +395,9 @@ int bc_sample_data(const char* file1, const char* file2, const char* barcodes, u
     // valid reads (sample1): a set in eight parts by the hash, filled by as many threads, and the reads in the order the
     // reference would have added them; "observed" barcodes as one bit per library id; the text of the sampled chunks is
     // KEPT (up to KEEP_BYTES: the sets then hold views instead of copies; past that they copy into their arenas)
-    constexpr size_t KEEP_BYTES = 1ull << 30;
+    size_t KEEP_BYTES = 1ull << 30;
+    if (const char* e = getenv("BC_SAMPLE_KEEP_MB"))  // (tests: 0 makes every chunk take the copying form)
+        if (atoi(e) >= 0) KEEP_BYTES = (size_t)atoi(e) << 20;
     std::vector<StrSet> vset;
     for (int p = 0; p < 8; ++p) vset.emplace_back(lookahead ? (size_t)n_lib / 4 : 0, true);
     std::vector<std::string_view> valid_views;

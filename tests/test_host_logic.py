@@ -729,7 +729,7 @@ def test_reader_raw_stream(tmp_path):
             L.bc_reader_close(h)
 
 
-def test_native_sampling_fast_path_equals_loop_form(tmp_path):
+def test_native_sampling_fast_path_equals_loop_form(tmp_path, monkeypatch):
     """The single-end sampler counts a chunk's library k-mers from a table of first meetings filled by worker threads
     (bc_sample.cpp) instead of walking the reads in order; a chunk that holds a read with more library k-mers than the
     look-ahead keeps takes the loop form.  Both must give what the golden-pinned Python statement of
@@ -775,12 +775,20 @@ def test_native_sampling_fast_path_equals_loop_form(tmp_path):
     rd.write_text("".join(r + "\n" for r in reads))
     ordered = H.read_fasta_ordered(str(fa))
     want = H.sample_data(str(rd), None, set(ordered), False)
-    smp = H.NativeSample(str(rd), None, ordered, False)
-    got = (smp.n_novel, smp.offset1, smp.offset2, smp.n_valid1, smp.n_valid2, smp.n_observed, smp.need_swap, smp.num_chunks)
-    assert got == (want[0], want[1], want[2], len(want[3]), len(want[4]), len(want[5]), want[6], want[7])
+    # (the sampled chunks' text is kept and the sets hold views into it — up to BC_SAMPLE_KEEP_MB, 1 GiB by default; past
+    # that, here from the second chunk on, the sets copy what they keep: both forms, and several thread counts)
+    for keep_mb, threads in ((None, None), ("1", "3"), ("0", "7")):
+        for name, val in (("BC_SAMPLE_KEEP_MB", keep_mb), ("BC_SAMPLE_THREADS", threads)):
+            if val is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, val)
+        smp = H.NativeSample(str(rd), None, ordered, False)
+        got = (smp.n_novel, smp.offset1, smp.offset2, smp.n_valid1, smp.n_valid2, smp.n_observed, smp.need_swap, smp.num_chunks)
+        assert got == (want[0], want[1], want[2], len(want[3]), len(want[4]), len(want[5]), want[6], want[7]), (keep_mb, threads)
+        assert tuple(smp.flanks(0, smp.offset1, k)) == tuple(H.find_flanks(want[3], want[1], k))
+        smp.close()
     assert want[7] >= 4 and want[1] == 15
-    assert tuple(smp.flanks(0, smp.offset1, k)) == tuple(H.find_flanks(want[3], want[1], k))
-    smp.close()
 
 
 def test_native_sampling_mate_pairs_equal_loop_form(tmp_path):
