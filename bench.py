@@ -318,8 +318,11 @@ def main():
     global K
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: 50 timed steps after 20 untimed ones (0.08 s in all).  The part needs ~20 launches of sustained load to
+    # settle its clocks after a pause (profiles/r04_clock_ramp.txt: 1.06 ms per kernel at the start of a burst, 0.89-0.93
+    # at its end), so a short run measures the ramp; the driver's own --steps / --warmup are taken as given.
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--reads", type=float, default=None,
                     help="reads per GPU (default 1e8 = BASELINE configs[2]; with --gpus 8: 1.25e8 = configs[4], 1e9 reads in all)")
     ap.add_argument("--guides", type=int, default=G)
