@@ -1225,8 +1225,12 @@ __global__ __launch_bounds__(HIST_BLOCK) void k_hist_part(PartOut P, const int32
 __global__ __launch_bounds__(BLOCK) void k_first_refine(const int32_t* __restrict__ best_idx, uint64_t n, uint32_t G,
                                                         uint32_t* __restrict__ first_tile,
                                                         uint64_t* __restrict__ first_seen, uint64_t base,
-                                                        uint32_t* __restrict__ ovf_count) {
+                                                        uint32_t* __restrict__ ovf_count,
+                                                        uint32_t* __restrict__ ovf_flag, uint32_t n_tiles) {
     (void)ovf_count;
+    // the tiles' overflow flags go back to zero for the next pass (the matcher only ever sets them)
+    for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < n_tiles; t += gridDim.x * BLOCK)
+        if (ovf_flag[t] != 0u) ovf_flag[t] = 0u;
     const uint32_t g = (blockIdx.x * BLOCK + threadIdx.x) >> 4;
     const uint32_t sub = threadIdx.x & 15u;
     if (g >= G) return;
@@ -1868,6 +1872,7 @@ int tally_workspace(bc_lib* lib, hipStream_t st, uint64_t n_tiles, uint32_t nr, 
         w->rec = nullptr; w->ovf_list = nullptr; w->tiles_cap = 0;
         BC_HIP(hipMalloc((void**)&w->rec, (((size_t)n_tiles * nr) << cap_log2) * sizeof(uint16_t)));
         BC_HIP(hipMalloc((void**)&w->ovf_list, (size_t)n_tiles * 4));
+        BC_HIP(hipMemset(w->ovf_list, 0, (size_t)n_tiles * 4));  // (zero between passes: part_emit sets, k_first_refine clears)
         w->tiles_cap = n_tiles;
     }
     *out = w;
@@ -1910,7 +1915,8 @@ int launch_hist_part(bc_lib* lib, const MatchOut& o, const TallyWs* w, uint64_t 
     hipLaunchKernelGGL(k_hist_part, dim3(o.part.nr * slices), dim3(HIST_BLOCK), HIST_LDS_BYTES, st, o.part, o.best_idx, n,
                        tail_begin, lib->G, slices, o.counts, o.first_seen ? w->first_tile : nullptr);
     hipLaunchKernelGGL(k_first_refine, dim3((lib->G * 16 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, o.best_idx, n,
-                       o.first_seen ? lib->G : 0u, w->first_tile, o.first_seen, o.base, w->ovf_count);
+                       o.first_seen ? lib->G : 0u, w->first_tile, o.first_seen, o.base, w->ovf_count, w->ovf_list,
+                       o.part.n_tiles);
     BC_HIP(hipGetLastError());
     return BC_OK;
 }

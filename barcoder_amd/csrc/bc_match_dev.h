@@ -157,7 +157,9 @@ __device__ __forceinline__ void part_emit(const PartOut& P, uint32_t tile, const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const uint32_t c = lane < P.nr ? cnt[lane] : 0u;
     const bool ovf = __ballot(c > cap) != 0ull;
-    if (lane == 0) P.ovf_flag[tile] = ovf ? 1u : 0u;
+    // (the flags are zero when a pass starts — k_first_refine clears the ones it finds set — so only an overflowing tile
+    // writes: a four-byte store per tile cost the matcher 12 us per 1e8 reads, profiles/r04_part_emit_flag.txt)
+    if (ovf && lane == 0) P.ovf_flag[tile] = 1u;
     // lines out, one dword per lane and step: dword d of the staging area belongs to range d / (cap / 2); a range's
     // lines lie one stride (< 2^31 bytes) apart, a tile's line at tile * cap * 2 bytes inside it
     const uint32_t* sw = reinterpret_cast<const uint32_t*>(stage);

@@ -24,7 +24,7 @@ PY
 }
 if has prof; then
   echo "rocprof" > $OUT/progress.log
-  bash profiles/run_prof.sh $TAG --steps 20 --warmup 10 > $OUT/run_prof.log 2>&1   # 20 timed + 10 warm-up steps: the average is over launches at the steady clock
+  bash profiles/run_prof.sh $TAG --steps 50 --warmup 20 > $OUT/run_prof.log 2>&1   # the default bench command (50 timed steps after 20)
   python3 profiles/summarize.py gpurun_out/prof_$TAG k_ > $OUT/${TAG}_rocprof_summary.json
   cp gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
   python3 profiles/collect_traffic.py $OUT/${TAG}_rocprof_summary.json 1e8 seed 2 > $OUT/collect_traffic.log 2>&1
