@@ -148,8 +148,8 @@ def secondary_workloads(torch, dev, local, stream, lib_packed, matcher, n, steps
         matcher.synth_reads_dev(1, 0, n, 0, reads.data_ptr(), stream)
         kw = dict(d_best_dist=bd.data_ptr(), d_n_best=nb.data_ptr(), stream=stream)
         matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=2, **kw)
-        k_ms = matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=max(3, steps), **kw)
-        p_ms = matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=max(3, steps),
+        k_ms = matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=max(30, steps), **kw)
+        p_ms = matcher.time_dev(reads.data_ptr(), n, bi.data_ptr(), 0, "hash", iters=max(30, steps),
                                 d_counts=c32.data_ptr(), d_first_seen=fs.data_ptr(), **kw)
         hit = float((bi >= 0).float().mean().item())
         res = {"workload": f"20-mer exact match, {lib_packed.size} guides, {n} reads (BASELINE configs[1])",
@@ -444,8 +444,10 @@ def run(args):
     total_hits = int(job_counts.sum().item())
 
     # dominant kernel alone (the matcher without the tally), HIP events on the launch stream: roofline.achieved;
-    # then the whole pass (matcher + tally) the same way
-    k_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(20, args.steps),
+    # then the whole pass (matcher + tally) the same way.  At least 50 launches each: a burst that follows a pause (the
+    # .item() above) starts with the clock ramp, and an average over fewer launches measures mostly that
+    # (profiles/r04_clock_ramp.txt)
+    k_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(50, args.steps),
                       d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), stream=stream)
     # the same again over 40 launches issued straight after those: the kernel at the clocks a long run settles at (the
     # first ~20 launches after any pause run 5-10 % slower while the power management settles: profiles/r04_clock_ramp.txt);
@@ -454,7 +456,7 @@ def run(args):
                              d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), stream=stream)
     counts32.zero_()
     first_seen.fill_(-1)
-    pass_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(20, args.steps),
+    pass_ms = m.time_dev(reads.data_ptr(), n, best_idx.data_ptr(), args.max_mismatch, args.algo, iters=max(50, args.steps),
                          d_best_dist=best_dist.data_ptr(), d_n_best=n_best.data_ptr(), d_counts=counts32.data_ptr(),
                          d_first_seen=first_seen.data_ptr(), stream=stream)
     achieved = n * ALGO_BYTES / (k_ms * 1e-3) / 1e9
