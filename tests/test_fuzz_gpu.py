@@ -46,3 +46,37 @@ def test_random_cases_agree_with_the_oracle(gpu_device, oracle, seed):
         if not all(np.array_equal(getattr(res, a), ref[a]) for a in ("best_idx", "best_dist", "n_best", "counts", "first_seen")):
             bad.append((case, k, G, d, n, mix, algo, flags is not None))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_random_pam_scans_agree_with_the_oracle(gpu_device, oracle, seed):
+    """Random sequences (ACGT with runs of N and stray lower-case letters, lengths around the 32- and 128-position word and
+    lane boundaries and up to 3e5) x random patterns over {A, C, G, T, N} of 1 ... 8 letters: both strands' PAM bitmaps
+    (`pam.pam_scan` -> k_pam_scan) against oracle.pam_bitmaps, and the sliding spacer set (`pam.sliding_spacers` ->
+    the fused two-launch site pipeline) against oracle.sliding_sites_py, both directions."""
+    import random
+    from barcoder_amd import pam as P
+    rng = random.Random(seed)
+    n_cases = int(os.environ.get("BC_FUZZ_CASES", "25"))
+    for case in range(n_cases):
+        n = rng.choice([0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 257, 4095, 4097, 8191, 8193, 20000, 100003, 300000])
+        s = [rng.choice("ACGT") for _ in range(n)]
+        for _ in range(rng.randrange(0, 4)):            # runs of N
+            if n:
+                a = rng.randrange(n)
+                for j in range(a, min(n, a + rng.randrange(1, 40))):
+                    s[j] = "N"
+        for _ in range(rng.randrange(0, 3)):            # stray lower-case letters (not ACGT to the scan)
+            if n:
+                s[rng.randrange(n)] = rng.choice("acgtn")
+        s = "".join(s)
+        pam = "".join(rng.choice("ACGTNNN") for _ in range(rng.randrange(1, 9)))
+        # (case_sensitive: lower-case letters match nothing, as for the reference's regexes on a raw string; the default of
+        # pack_genome folds case, a convenience the drop-in callers do not use)
+        fwd, rev = P.pam_scan(P.pack_genome(s, 0, case_sensitive=True), pam, gpu_device)
+        f2, r2 = oracle.pam_bitmaps(s, pam)
+        assert np.array_equal(fwd, f2.astype(bool)) and np.array_equal(rev, r2.astype(bool)), (case, n, pam)
+        if n <= 20000:
+            k = rng.choice([4, 6, 12, 20, 32])
+            d = rng.choice(["downstream", "upstream"])
+            assert P.sliding_spacers(s, k, pam, d, gpu_device) == oracle.sliding_sites_py(s, k, pam, d), (case, n, pam, k, d)
