@@ -146,8 +146,9 @@ struct Knobs {
     int prefetch = 8;     // BC_PREFETCH: read-stream prefetch distance of k_match_wq in units of 128 tiles (0 = none)
     int pair_group_kb = 3300;  // BC_PAIR_GROUP_KB: pair tables taken together in one pass of the cascade's second stage
                           // (their slabs stay in an XCD's 4 MiB L2); 0: the one-kernel form over all ten tables
-    int cascade2_min_g = 0;    // BC_CASCADE2_MIN_G: d = 2 as d <= 1 pass + pair index from that many guides on (0: only where
-                          // the wave matcher cannot serve d = 2)
+    int cascade2_min_g = 350000;  // BC_CASCADE2_MIN_G: d = 2 as d <= 1 pass + pair index from that many guides on (0: only
+                          // where the wave matcher cannot serve d = 2); the measured crossover lies between 3e5 and 4e5
+    int pair_four = 1;         // BC_PAIR_FOUR=0: budgets <= 2 walk all ten pair tables instead of the four that cover three clean pieces
     int pair_grid = 16384;     // BC_PAIR_GRID: workgroups of a second-stage pass at most (2 048 = 8 per CU fill the chip; more balance the tail: 226 -> 210 us)
     int pair_chunk_log2 = 27;  // BC_PAIR_CHUNK_LOG2: reads per launch of a cascade in its list form (workspace: 32 bytes per read)
     int pair_pass_min = 65536; // BC_PAIR_PASS_MIN_READS: launches below that take the one-kernel form (tests: 0)
@@ -208,6 +209,12 @@ struct bc_lib {
     const bc::SlabParams* d_slab[bc::MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<uint32_t> pair_slabs;          // slabs of each pair table (64 bytes each): the second stage groups by size
     const bc::PairParams* d_pairs = nullptr;   // 3-mismatch pair index (NULL: not built yet, or k outside 8..25)
+    // The same tables for budgets <= 2: at most two substitutions leave THREE of the five pieces clean, and three pieces
+    // always hold both of {0, 1} or two of {2, 3, 4} — the four tables (0,1) (2,3) (2,4) (3,4) find every such guide
+    // (a covering of the 3-subsets by pairs: the complement of a triangle-free K(2,3)); descriptors with their own
+    // count-once rule (bc_match_pairs.hip, build_pair_index), slabs shared with d_pairs
+    const bc::PairParams* d_pairs2 = nullptr;
+    std::vector<uint32_t> pair_slabs2;
     bool pairs_tried = false;                  // under ws_mutex
     bc::Knobs knobs;
     // geometry of the record tally (ranges, records per line), fixed by the library size: computed once at creation

@@ -1991,9 +1991,11 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
         if (rc != BC_OK) return rc;
         if (lib->knobs.cascade == 1 && lib->d_pairs && aligned16(o_in.best_idx)) return launch_cascade(lib, d_reads, d_flags, n, 3, o_in, st);
     }
-    // d = 2 on a library the wave matcher cannot serve at d = 2 (buckets above 40 guides) but can at d = 1: the d <= 1
-    // pass, then the pair index for the rest, instead of the previous-generation quad kernels over every read
-    // (measured at 7e5 / 1e6 20-mers: see profiles/r03_sweep_G_d.txt)
+    // d = 2 on a library the wave matcher cannot serve at d = 2 (buckets above 40 guides) but can at d = 1, or serves
+    // more slowly than the cascade does (from BC_CASCADE2_MIN_G = 3.5e5 guides on; 0: never): the d <= 1 pass, then the
+    // pair index for the rest — for budgets <= 2 only FOUR of its ten tables (bc_device.h, d_pairs2).  Measured, kernel ms
+    // per 1e8 reads, wave matcher / cascade: 2.43 / 2.52 at 3e5 guides, 3.57 / 2.72 at 4e5, 4.62 / 3.39 at 5e5,
+    // 6.13 / 3.70 at 6.5e5; 1e6: 6.54 with ten tables, 4.49 with four (profiles/r04_cascade2_ab.txt)
     if (algo == BC_ALGO_SEED && max_mm == 2 && lib->knobs.cascade == 1 && lib->knobs.lane && aligned16(o_in.best_idx)) {
         int q01, q2;
         const bool vec_ok = vector_io_ok(d_reads, o_in, n);
@@ -2463,9 +2465,10 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.e8 = env_int("BC_E8", 1);
     lib->knobs.pair_group_kb = env_int("BC_PAIR_GROUP_KB", 3300);
     lib->knobs.pair_pass_min = env_int("BC_PAIR_PASS_MIN_READS", 65536);
-    lib->knobs.cascade2_min_g = env_int("BC_CASCADE2_MIN_G", 0);
+    lib->knobs.cascade2_min_g = env_int("BC_CASCADE2_MIN_G", 350000);
     lib->knobs.pair_chunk_log2 = env_int("BC_PAIR_CHUNK_LOG2", 27);
     lib->knobs.pair_grid = std::max(1, env_int("BC_PAIR_GRID", 16384));
+    lib->knobs.pair_four = env_int("BC_PAIR_FOUR", 1);
     lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));
     {
         PartOut pg{};

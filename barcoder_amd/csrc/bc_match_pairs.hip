@@ -452,7 +452,9 @@ namespace bc {
 
 int build_pair_index(bc_lib* lib) {
     lib->d_pairs = nullptr;
+    lib->d_pairs2 = nullptr;
     lib->pair_slabs.clear();
+    lib->pair_slabs2.clear();
     const int k = lib->k;
     if (k < 8 || k > 25 || lib->G >= (1u << SLAB_GIDX_BITS)) return BC_OK;  // other lengths: the four-segment index
     // five pieces, the longer ones first
@@ -465,7 +467,7 @@ int build_pair_index(bc_lib* lib) {
     want = std::max(want, k - 16);
     if (want > 9) return BC_OK;
     // the ten tables are independent: one host thread each (50 ms single-threaded at 1e5 guides)
-    struct Built { PairTable T{}; std::vector<uint32_t> rests, gidx; bool ok = false; };
+    struct Built { PairTable T{}; std::vector<uint32_t> rests, gidx; bool ok = false; uint32_t other2[3] = {0u, 0u, 0u}, n_other2 = 0; bool in2 = false; };
     Built built[10];
     int pa[10], pb[10], nt = 0;
     for (int a = 0; a < 5; ++a)
@@ -489,6 +491,15 @@ int build_pair_index(bc_lib* lib) {
         T.n_other = 0;
         for (int c = 0; c < b; ++c)
             if (c != a) T.other[T.n_other++] = rest_mask(p_start[c], p_len[c]);
+        // budgets <= 2 (three clean pieces at least) visit the tables (0,1) (2,3) (2,4) (3,4) in that order, and a guide
+        // counts in the first of them whose pair is clean: (0,1) always; the others only when piece 0 or piece 1 is
+        // dirty (ONE mask over both: non-zero = one of them is), and (2,4) / (3,4) only when piece 3 / piece 2 is dirty
+        // too — otherwise (2,3) has counted it already
+        built[t].in2 = (a == 0 && b == 1) || a >= 2;
+        if (a >= 2) {
+            built[t].other2[built[t].n_other2++] = rest_mask(p_start[0], p_len[0]) | rest_mask(p_start[1], p_len[1]);
+            if (b == 4) built[t].other2[built[t].n_other2++] = rest_mask(p_start[a == 2 ? 3 : 2], p_len[a == 2 ? 3 : 2]);
+        }
         const uint32_t nb = 1u << (2 * (la + lb));  // bucket = slab number, overflow slabs appended
         std::vector<uint32_t> cnt(nb + 1, 0u);
         std::vector<uint32_t> bucket_of(lib->G);
@@ -553,8 +564,28 @@ int build_pair_index(bc_lib* lib) {
     PairParams* d_pp;
     int rc = upload(lib, one, &d_pp);
     if (rc != BC_OK) return rc;
+    PairParams pp2{};
+    pp2.ntab = 0;
+    for (int t = 0; t < 10; ++t) {
+        if (!built[t].in2) continue;
+        PairTable T = pp.t[t];
+        T.n_other = built[t].n_other2;
+        for (int c = 0; c < 3; ++c) T.other[c] = built[t].other2[c];
+        pp2.t[pp2.ntab++] = T;
+        lib->pair_slabs2.push_back(lib->pair_slabs[(size_t)t]);
+    }
+    std::vector<PairParams> two(1, pp2);
+    PairParams* d_pp2;
+    rc = upload(lib, two, &d_pp2);
+    if (rc != BC_OK) return rc;
+    lib->d_pairs2 = d_pp2;
     lib->d_pairs = d_pp;
     return BC_OK;
+}
+
+// the descriptors a budget walks: four tables for <= 2 substitutions (BC_PAIR_FOUR=0: all ten, as for three)
+static const PairParams* pairs_for(const bc_lib* lib, int max_mm) {
+    return (max_mm <= 2 && lib->d_pairs2 && lib->knobs.pair_four) ? lib->d_pairs2 : lib->d_pairs;
 }
 
 int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t* d_flags, uint64_t n, const MatchOut& o,
@@ -563,7 +594,7 @@ int launch_pairs(bc_lib* lib, int max_mm, const uint64_t* d_reads, const uint8_t
     if (n == 0) return BC_OK;
     const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
     if (blocks >> 31) { set_error("bc_match: launch too large"); return BC_EINVAL; }
-    hipLaunchKernelGGL(k_match_pairs, dim3((unsigned)blocks), dim3(BLOCK), 0, st, lib->d_pairs, d_reads, d_flags, n, lib->k,
+    hipLaunchKernelGGL(k_match_pairs, dim3((unsigned)blocks), dim3(BLOCK), 0, st, pairs_for(lib, max_mm), d_reads, d_flags, n, lib->k,
                        lib->kmask, max_mm, o);
     BC_HIP(hipGetLastError());
     return BC_OK;
@@ -590,12 +621,14 @@ int launch_cascade_stage2(bc_lib* lib, int max_mm, const uint64_t* d_reads, uint
     const uint64_t n_sub = (n + ST2_SUB - 1) / ST2_SUB;
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_sub, 2048));  // 8 workgroups per CU
     if (!w) {
-        hipLaunchKernelGGL(k_cascade_stage2, dim3(grid), dim3(BLOCK), 0, st, lib->d_pairs, d_reads, n, lib->kmask, max_mm, o.best_idx,
+        hipLaunchKernelGGL(k_cascade_stage2, dim3(grid), dim3(BLOCK), 0, st, pairs_for(lib, max_mm), d_reads, n, lib->kmask, max_mm, o.best_idx,
                            o.best_dist, o.n_best, o.counts, o.first_seen, o.base);
         BC_HIP(hipGetLastError());
         return BC_OK;
     }
-    const int ntab = (int)lib->pair_slabs.size();
+    const bool four = pairs_for(lib, max_mm) == lib->d_pairs2;
+    const std::vector<uint32_t>& slabs = four ? lib->pair_slabs2 : lib->pair_slabs;
+    const int ntab = (int)slabs.size();
     const uint64_t budget = (uint64_t)std::max(0, lib->knobs.pair_group_kb) * 1024ull;
     const uint64_t n_tiles = (n + 255) >> 8;
     if (!listed) {
@@ -617,9 +650,9 @@ int launch_cascade_stage2(bc_lib* lib, int max_mm, const uint64_t* d_reads, uint
     const unsigned pgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + BLOCK - 1) / BLOCK, (uint64_t)lib->knobs.pair_grid));  // 8 workgroups per CU
     for (int t0 = 0; t0 < ntab;) {  // greedy groups: tables in order while their slabs fit the budget, at least one
         int t1 = t0 + 1;
-        uint64_t bytes = (uint64_t)lib->pair_slabs[(size_t)t0] * (PSW * 4u);
-        while (t1 < ntab && bytes + (uint64_t)lib->pair_slabs[(size_t)t1] * (PSW * 4u) <= budget) bytes += (uint64_t)lib->pair_slabs[(size_t)t1++] * (PSW * 4u);
-        hipLaunchKernelGGL(k_cascade_pass, dim3(pgrid), dim3(BLOCK), 0, st, lib->d_pairs, t0, t1, t0 == 0 ? 1 : 0, t1 == ntab ? 1 : 0,
+        uint64_t bytes = (uint64_t)slabs[(size_t)t0] * (PSW * 4u);
+        while (t1 < ntab && bytes + (uint64_t)slabs[(size_t)t1] * (PSW * 4u) <= budget) bytes += (uint64_t)slabs[(size_t)t1++] * (PSW * 4u);
+        hipLaunchKernelGGL(k_cascade_pass, dim3(pgrid), dim3(BLOCK), 0, st, pairs_for(lib, max_mm), t0, t1, t0 == 0 ? 1 : 0, t1 == ntab ? 1 : 0,
                            (const uint64_t*)w->casc_dread, (const uint32_t*)w->casc_dpos, w->casc_state,
                            (const unsigned long long*)w->casc_count, max_mm, o.best_idx, o.best_dist, o.n_best, o.counts, o.first_seen,
                            o.base);

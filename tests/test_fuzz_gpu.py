@@ -48,6 +48,48 @@ def test_random_cases_agree_with_the_oracle(gpu_device, oracle, seed):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("env", [{"BC_CASCADE2_MIN_G": "1"}, {"BC_CASCADE2_MIN_G": "1", "BC_PAIR_PASS_MIN_READS": "0"},
+                                 {"BC_CASCADE2_MIN_G": "1", "BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_GROUP_KB": "1"},
+                                 {"BC_CASCADE2_MIN_G": "1", "BC_PAIR_FOUR": "0"}])
+def test_two_mismatch_cascade_counts_every_guide_once(gpu_device, oracle, env, monkeypatch):
+    """Budget 2 as a cascade (d <= 1 pass, then the pair index) on TIGHTLY clustered libraries: families of guides one to
+    four substitutions apart, reads zero to three substitutions from a family member — so that a read has several guides
+    within the budget, each with three, four or five clean pieces, found in several of the read's buckets.  For budgets
+    <= 2 the second stage walks only the four tables (0,1) (2,3) (2,4) (3,4) with their own count-once rule
+    (bc_match_pairs.hip; BC_PAIR_FOUR=0: all ten with the lexicographic rule): best index, distance and the TIE COUNT must
+    be the oracle's in the one-kernel form, the list form (one table per pass too) and with all ten tables."""
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    rng = np.random.default_rng(41)
+    seen = ties = 0
+    for case in range(12):
+        k = int(rng.choice([8, 11, 16, 20, 20, 20, 23, 25]))
+        fam, per = int(rng.choice([3, 40, 400])), int(rng.choice([4, 12, 30]))
+        centres = S.library(fam, k, seed=int(rng.integers(1, 1 << 30)))
+        lib = np.repeat(centres, per)
+        for _ in range(2):              # every member: up to two substitutions from its centre (members up to four apart)
+            pos = rng.integers(0, k, lib.size).astype(np.uint64)
+            x = rng.integers(0, 4, lib.size).astype(np.uint64)
+            lib ^= ((x & np.uint64(1)) << pos) | ((x >> np.uint64(1)) << (pos + np.uint64(32)))
+        lib = np.unique(np.concatenate([lib, S.library(int(rng.choice([0, 50, 3000])) + 1, k, seed=case + 5)]))
+        rng.shuffle(lib)
+        n = int(rng.choice([257, 4099, 30001]))
+        reads = lib[rng.integers(0, lib.size, n)].copy()
+        for _ in range(3):              # zero to three substitutions (x = 0: none at that turn)
+            pos = rng.integers(0, k, n).astype(np.uint64)
+            x = rng.integers(0, 4, n).astype(np.uint64) * (rng.random(n) < 0.6)
+            reads ^= ((x & np.uint64(1)) << pos) | ((x >> np.uint64(1)) << (pos + np.uint64(32)))
+        flags = (rng.random(n) < 0.03).astype(np.uint8)
+        dl = DeviceLibrary(lib, k, gpu_device)
+        res = GpuMatcher(dl).match(reads, flags, max_mismatch=2, algo="seed", first_index=3)
+        seen += dl.last_kernel == "cascade2:d1+k_match_pairs"
+        ref = oracle.best_hit(E.unpack_kmers(lib, k), E.unpack_kmers(reads & E.kmer_mask(k), k), 2, skip=flags, base=3)
+        ties += int((ref["n_best"] > 1).sum())
+        for a in ("best_idx", "best_dist", "n_best", "counts", "first_seen"):
+            np.testing.assert_array_equal(getattr(res, a), ref[a], err_msg=f"case {case} k {k} G {lib.size} n {n}: {a}")
+    assert seen >= 8 and ties > 5000, (seen, ties)   # (the cascade really ran, and on reads with several best guides)
+
+
 @pytest.mark.parametrize("seed", [3, 4])
 def test_random_pam_scans_agree_with_the_oracle(gpu_device, oracle, seed):
     """Random sequences (ACGT with runs of N and stray lower-case letters, lengths around the 32- and 128-position word and
