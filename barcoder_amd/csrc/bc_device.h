@@ -148,6 +148,7 @@ struct Knobs {
                           // (their slabs stay in an XCD's 4 MiB L2); 0: the one-kernel form over all ten tables
     int cascade2_min_g = 350000;  // BC_CASCADE2_MIN_G: d = 2 as d <= 1 pass + pair index from that many guides on (0: only
                           // where the wave matcher cannot serve d = 2); the measured crossover lies between 3e5 and 4e5
+    int pair_bucket_pct = 800; // BC_PAIR_BUCKET_PCT: the pair tables' key grows while a bucket would hold more than this many guides / 100
     int pair_four = 1;         // BC_PAIR_FOUR=0: budgets <= 2 walk all ten pair tables instead of the four that cover three clean pieces
     int pair_grid = 16384;     // BC_PAIR_GRID: workgroups of a second-stage pass at most (2 048 = 8 per CU fill the chip; more balance the tail: 226 -> 210 us)
     int pair_chunk_log2 = 27;  // BC_PAIR_CHUNK_LOG2: reads per launch of a cascade in its list form (workspace: 32 bytes per read)

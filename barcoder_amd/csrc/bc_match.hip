@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     // (16 narrow entries for buckets above 16 guides, or 8 wide entries)
     static_assert(NQ01 == 1 || NQ01 == 2, "table 0/1 slabs are 64 or 128 bytes");
     static_assert(!WIDE || NQ01 == 2, "wide entries: 8-entry slabs of 128 bytes");
-    static_assert(!LIST || (!WIDE && NQ01 == 1), "the list form is instantiated for 64-byte slabs of 8-byte entries");
+    static_assert(!LIST || !WIDE, "the list form is instantiated for 8-byte entries (64- and 128-byte slabs)");
     // E8: tables 0/1 in their eight-entry form (EightTables): links are 16-bit numbers relative to the table's first
     // overflow slab (lnk_abs makes a slab number of one), list entries and items keep slab numbers
     static_assert(!E8 || (!WIDE && NQ01 == 1), "the eight-entry form exists for 64-byte slabs of 8-byte entries");
@@ -2125,12 +2125,15 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     (void)prof;
 #endif
                     const int wgrid = (int)((n + WAVE_T - 1) / WAVE_T);
-                    const bool listing = o.miss_cnt != nullptr && !wide && nq01 == 1;  // (the shapes the list form exists for)
+                    const bool listing = o.miss_cnt != nullptr && !wide;  // (the shapes the list form exists for: 8-byte entries)
 #define BC_WAVE_LAUNCH(NSEG_, NQ2_, PROF_, WIDE_, NQ01_)                                                           \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, PROF_, WIDE_, NQ01_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
 #define BC_WAVE_LIST(NSEG_, NQ2_, E8_)                                                                               \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, true, E8_>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
+                       lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
+#define BC_WAVE_LIST2(NSEG_, NQ2_)  /* 128-byte slabs of tables 0/1 (libraries above 1.2e5 20-mers): a large library's d = 2 cascade starts here */ \
+    hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 2, true, false>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
                        lib->k, lib->kmask, max_mm | ((lib->knobs.diag & 0xFF) << 8) | ((n >= 4u * WAVE_T ? lib->knobs.prefetch : 0) << 16), o)
 #define BC_WAVE_E8(NSEG_, NQ2_)                                                                                      \
     hipLaunchKernelGGL((k_match_wq<NSEG_, NQ2_, false, false, 1, false, true>), dim3(wgrid), dim3(64), 0, st, dp, d_reads, d_flags, n, \
@@ -2145,6 +2148,10 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                         else if (nq2 == 1) BC_WAVE_P(3, 1);
                         else if (nq2 == 2) BC_WAVE_P(3, 2);
                         else BC_WAVE_P(3, 4);
+                    } else if (!wide && listing) {
+                        if (nseg == 2) BC_WAVE_LIST2(2, 2);
+                        else if (nq2 == 2) BC_WAVE_LIST2(3, 2);
+                        else BC_WAVE_LIST2(3, 4);
                     } else if (!wide) {
                         if (nseg == 2) BC_WAVE_LAUNCH(2, 2, false, false, 2);
                         else if (nq2 == 2) BC_WAVE_LAUNCH(3, 2, false, false, 2);
@@ -2156,6 +2163,7 @@ int launch_match_kernel(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_f
                     }
 #undef BC_WAVE_P
 #undef BC_WAVE_LIST
+#undef BC_WAVE_LIST2
 #undef BC_WAVE_E8
 #undef BC_WAVE_LAUNCH
                     note_kernel(lib, "k_match_wq");
@@ -2469,6 +2477,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.pair_chunk_log2 = env_int("BC_PAIR_CHUNK_LOG2", 27);
     lib->knobs.pair_grid = std::max(1, env_int("BC_PAIR_GRID", 16384));
     lib->knobs.pair_four = env_int("BC_PAIR_FOUR", 1);
+    lib->knobs.pair_bucket_pct = std::max(25, env_int("BC_PAIR_BUCKET_PCT", 800));
     lib->knobs.prefetch = std::max(0, std::min(255, env_int("BC_PREFETCH", 8)));
     {
         PartOut pg{};

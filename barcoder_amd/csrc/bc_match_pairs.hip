@@ -463,7 +463,7 @@ int build_pair_index(bc_lib* lib) {
     // key length in bases: ~6 guides per bucket, at least k - 16 (the rest must fit 16 bases per plane), at most 9
     int want = 1;
     // (32-byte slabs hold seven: about 1.5 per bucket; 64-byte slabs fifteen: about 6)
-    while (want < 9 && ((double)lib->G / (double)(1ull << (2 * want))) > (PSW == 8u ? 2.0 : 8.0)) ++want;
+    while (want < 9 && ((double)lib->G / (double)(1ull << (2 * want))) > (PSW == 8u ? 2.0 : lib->knobs.pair_bucket_pct / 100.0)) ++want;
     want = std::max(want, k - 16);
     if (want > 9) return BC_OK;
     // the ten tables are independent: one host thread each (50 ms single-threaded at 1e5 guides)

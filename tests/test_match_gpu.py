@@ -56,7 +56,10 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
                                  # d = 2 as a cascade too (then d = 3 is a cascade over a cascade and gathers its own list)
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_GROUP_KB": "64"},
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_CHUNK_LOG2": "13"},  # (very long inputs: several launches)
-                                 {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1"}, {"BC_CASCADE2_MIN_G": "1"}])
+                                 {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1"}, {"BC_CASCADE2_MIN_G": "1"},
+                                 {"BC_CASCADE2_MIN_G": "1", "BC_PAIR_FOUR": "0"},
+                                 {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1", "BC_PAIR_BUCKET_PCT": "50"},
+                                 {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1", "BC_PAIR_BUCKET_PCT": "6400"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
     """Tally by global atomics vs LDS histogram vs records, wave vs quad vs single
     slab kernel, 4 vs 8 lanes per read, slab sizes with and without overflow
@@ -156,6 +159,17 @@ def test_wave_kernel_geometries_at_scale(gpu_device, oracle, k, G):
     """Default d = 1, 2 path over k-mer lengths and library sizes (different seed / rest widths, bucket loads from
     1 to 16 per slab, neighbour densities from none to dense), 300 k reads each, every per-read output against the
     indexed oracle; counts and first-seen against numpy."""
+    _geometry_case(gpu_device, oracle, k, G, cascade_from=350_000)
+
+
+def test_wave_kernel_on_a_large_library_when_the_cascade_is_off(gpu_device, oracle, monkeypatch):
+    """From 3.5e5 guides on d = 2 runs as the cascade by default (d <= 1 pass + four pair tables: faster there);
+    BC_CASCADE2_MIN_G=0 keeps the wave matcher on its 128-byte slabs at 37 guides per bucket — the same results."""
+    monkeypatch.setenv("BC_CASCADE2_MIN_G", "0")
+    _geometry_case(gpu_device, oracle, 20, 600_000, cascade_from=None)
+
+
+def _geometry_case(gpu_device, oracle, k, G, cascade_from):
     lib = S.library(G, k, seed=S.LIB_SEED + 7 * k + G)
     n = 300_007
     reads = S.reads(lib, k, 11 + k, 0, n, 1)
@@ -175,7 +189,9 @@ def test_wave_kernel_geometries_at_scale(gpu_device, oracle, k, G):
         # the wave matcher serves 64-byte slabs, 128-byte slabs for 20-mer libraries up to 40 guides per bucket and
         # wide entries above k = 28; short k-mers whose d = 2 seeds leave 16+ guides per bucket, and tables 0 / 1 of
         # unequal slab size (k = 16, d = 2), stay on the quad kernels
-        if (k, d) not in ((12, 2), (16, 2)):
+        if d == 2 and cascade_from is not None and G >= cascade_from:
+            assert dl.last_kernel == "cascade2:d1+k_match_pairs", (k, d, dl.last_kernel)
+        elif (k, d) not in ((12, 2), (16, 2)):
             assert dl.last_kernel == "k_match_wq", (k, d, dl.last_kernel)
         else:
             assert dl.last_kernel in ("k_match_wq", "k_match_fused", "k_match_slab", "k_match_seed", "cascade2:d1+k_match_pairs")
