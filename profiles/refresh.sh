@@ -56,6 +56,7 @@ if has pam; then    # configs[3]: the scan at 4.6 Mbp and 3.1e9 bp, the fused si
   rm -rf gpurun_out/kt_pam
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_pam -- python3 profiles/pam_bench.py > $OUT/kt_pam.log 2>&1
   kstats gpurun_out/kt_pam pam > $OUT/${TAG}_pam_kernels.txt
+  python3 profiles/pam_big_row.py gpurun_out/kt_pam >> $OUT/${TAG}_pam_kernels.txt   # the 3.1e9-bp launches as rows of their own (by grid size)
 fi
 if has diag; then
   echo "stage attribution" >> $OUT/progress.log
