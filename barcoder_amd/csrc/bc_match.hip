@@ -1992,14 +1992,18 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
         if (lib->knobs.cascade == 1 && lib->d_pairs && aligned16(o_in.best_idx)) return launch_cascade(lib, d_reads, d_flags, n, 3, o_in, st);
     }
     // d = 2 on a library the wave matcher cannot serve at d = 2 (buckets above 40 guides) but can at d = 1, or serves
-    // more slowly than the cascade does (from BC_CASCADE2_MIN_G = 3.5e5 guides on; 0: never): the d <= 1 pass, then the
+    // more slowly than the cascade does (by bucket load, below; BC_CASCADE2_MIN_G = n: from n guides on, 0: never): the d <= 1 pass, then the
     // pair index for the rest — for budgets <= 2 only FOUR of its ten tables (bc_device.h, d_pairs2).  Measured, kernel ms
     // per 1e8 reads, wave matcher / cascade: 2.43 / 2.52 at 3e5 guides, 3.57 / 2.72 at 4e5, 4.62 / 3.39 at 5e5,
     // 6.13 / 3.70 at 6.5e5; 1e6: 6.54 with ten tables, 4.49 with four (profiles/r04_cascade2_ab.txt)
     if (algo == BC_ALGO_SEED && max_mm == 2 && lib->knobs.cascade == 1 && lib->knobs.lane && aligned16(o_in.best_idx)) {
         int q01, q2;
         const bool vec_ok = vector_io_ok(d_reads, o_in, n);
-        const bool big = lib->knobs.cascade2_min_g > 0 && lib->G >= (uint32_t)lib->knobs.cascade2_min_g;
+        // default (-1): by the load of the wave matcher's d = 2 buckets, 19 guides in a bucket of tables 0/1 — 3.11e5
+        // 20-mers; a 24-mer's 8-base seeds reach that load at 1.4e6 guides only, and the wave matcher stays
+        const double load2 = lib->slab_ok[2] ? (double)lib->G / (double)(1ull << (2 * lib->slab[2].t[0].slen)) : 0.0;
+        const bool big = lib->knobs.cascade2_min_g > 0 ? lib->G >= (uint32_t)lib->knobs.cascade2_min_g
+                                                       : (lib->knobs.cascade2_min_g < 0 && load2 >= 19.0);
         if ((big || !wave_kernel_serves(lib, 2, algo, vec_ok, &q01, &q2)) && wave_kernel_serves(lib, 1, algo, vec_ok, &q01, &q2)) {
             int rc = ensure_pair_index(lib);
             if (rc != BC_OK) return rc;
@@ -2473,7 +2477,7 @@ int bc_lib_create(const uint64_t* h_guides, uint32_t n_guides, int k, int device
     lib->knobs.e8 = env_int("BC_E8", 1);
     lib->knobs.pair_group_kb = env_int("BC_PAIR_GROUP_KB", 3300);
     lib->knobs.pair_pass_min = env_int("BC_PAIR_PASS_MIN_READS", 65536);
-    lib->knobs.cascade2_min_g = env_int("BC_CASCADE2_MIN_G", 350000);
+    lib->knobs.cascade2_min_g = env_int("BC_CASCADE2_MIN_G", -1);
     lib->knobs.pair_chunk_log2 = env_int("BC_PAIR_CHUNK_LOG2", 27);
     lib->knobs.pair_grid = std::max(1, env_int("BC_PAIR_GRID", 16384));
     lib->knobs.pair_four = env_int("BC_PAIR_FOUR", 1);
