@@ -1992,15 +1992,15 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
         if (lib->knobs.cascade == 1 && lib->d_pairs && aligned16(o_in.best_idx)) return launch_cascade(lib, d_reads, d_flags, n, 3, o_in, st);
     }
     // d = 2 on a library the wave matcher cannot serve at d = 2 (buckets above 40 guides) but can at d = 1, or serves
-    // more slowly than the cascade does (by bucket load, below; BC_CASCADE2_MIN_G = n: from n guides on, 0: never): the d <= 1 pass, then the
-    // pair index for the rest — for budgets <= 2 only FOUR of its ten tables (bc_device.h, d_pairs2).  Measured, kernel ms
+    // more slowly than the cascade does (by bucket load, below; BC_CASCADE2_MIN_G = n: from n guides on, 0: never): the
+    // d <= 1 pass, then the pair index for the rest — for budgets <= 2 only FOUR of its ten tables (bc_device.h, d_pairs2).  Measured, kernel ms
     // per 1e8 reads, wave matcher / cascade: 2.43 / 2.52 at 3e5 guides, 3.57 / 2.72 at 4e5, 4.62 / 3.39 at 5e5,
     // 6.13 / 3.70 at 6.5e5; 1e6: 6.54 with ten tables, 4.49 with four (profiles/r04_cascade2_ab.txt)
     if (algo == BC_ALGO_SEED && max_mm == 2 && lib->knobs.cascade == 1 && lib->knobs.lane && aligned16(o_in.best_idx)) {
         int q01, q2;
         const bool vec_ok = vector_io_ok(d_reads, o_in, n);
         // default (-1): by the load of the wave matcher's d = 2 buckets, 19 guides in a bucket of tables 0/1 — 3.11e5
-        // 20-mers; a 24-mer's 8-base seeds reach that load at 1.4e6 guides only, and the wave matcher stays
+        // 20-mers; a 24-mer's 8-base seeds reach that load at 1.2e6 guides only, and the wave matcher stays (1.94 against 3.12 ms at 5e5)
         const double load2 = lib->slab_ok[2] ? (double)lib->G / (double)(1ull << (2 * lib->slab[2].t[0].slen)) : 0.0;
         const bool big = lib->knobs.cascade2_min_g > 0 ? lib->G >= (uint32_t)lib->knobs.cascade2_min_g
                                                        : (lib->knobs.cascade2_min_g < 0 && load2 >= 19.0);
