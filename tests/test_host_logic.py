@@ -850,3 +850,33 @@ def test_native_sampling_mate_pairs_equal_loop_form(tmp_path):
     assert tuple(smp.flanks(0, smp.offset1, k)) == tuple(H.find_flanks(want[3], want[1], k))
     assert tuple(smp.flanks(1, smp.offset2, k)) == tuple(H.find_flanks(want[4], want[2], k))
     smp.close()
+
+
+def test_four_pair_tables_cover_two_substitutions_and_count_every_guide_once():
+    """The combinatorics behind the d <= 2 cascade's second stage (bc_match_pairs.hip, build_pair_index / d_pairs2).  A
+    k-mer is cut into five pieces; a guide within two substitutions of a read keeps at least three pieces clean.
+    (1) The four pair tables (0,1) (2,3) (2,4) (3,4) hold every such guide in one of the read's buckets (a pair of clean
+    pieces), and no three pair tables do — four is the minimum.  (2) The count-once rule the kernel evaluates per
+    candidate — pieces a and b clean, and every `other` mask non-zero (= at least one piece of the mask's set dirty) —
+    with the masks build_pair_index gives the four tables counts the guide in EXACTLY one of them, for every set of clean
+    pieces of size >= 3.  (3) Budget three (two clean pieces at least) needs all ten pairs."""
+    from itertools import combinations
+    pieces = range(5)
+    pairs = list(combinations(pieces, 2))
+    triples_plus = [set(c) for r in (3, 4, 5) for c in combinations(pieces, r)]
+    four = [(0, 1), (2, 3), (2, 4), (3, 4)]
+    covers = lambda tabs, clean_sets: all(any(a in c and b in c for a, b in tabs) for c in clean_sets)
+    assert covers(four, triples_plus)
+    assert not any(covers(t, triples_plus) for t in combinations(pairs, 3))
+    # `other` sets as build_pair_index fills them for the four tables (a mask over several pieces = their union)
+    other = {(0, 1): [], (2, 3): [{0, 1}], (2, 4): [{0, 1}, {3}], (3, 4): [{0, 1}, {2}]}
+    for clean in triples_plus:
+        counted = [t for t in four if t[0] in clean and t[1] in clean and all(m - clean for m in other[t])]
+        assert len(counted) == 1, (clean, counted)
+    # the ten-table rule (lexicographically first clean pair: every piece below b other than a is dirty) counts once too,
+    # and nine tables do not cover two clean pieces
+    doubles_plus = [set(c) for r in (2, 3, 4, 5) for c in combinations(pieces, r)]
+    for clean in doubles_plus:
+        counted = [(a, b) for a, b in pairs if a in clean and b in clean and all(c not in clean for c in range(b) if c != a)]
+        assert len(counted) == 1, (clean, counted)
+    assert not any(covers(t, doubles_plus) for t in combinations(pairs, 9))
