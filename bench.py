@@ -307,7 +307,31 @@ def secondary_workloads(torch, dev, local, stream, lib_packed, matcher, n, steps
         finally:
             shutil.rmtree(d, ignore_errors=True)
 
+    def wider():  # beyond the BASELINE configurations: three mismatches, and a five times larger library
+        from barcoder_amd import DeviceLibrary, GpuMatcher
+        reads = torch.empty(n, dtype=torch.int64, device=dev)
+        bi = torch.empty(n, dtype=torch.int32, device=dev)
+        bd = torch.empty(n, dtype=torch.uint8, device=dev)
+        nb = torch.empty(n, dtype=torch.uint8, device=dev)
+        res = {"workload": f"{n} reads of the standard stream (seed 2), HBM-resident; pass = matcher + tally, HIP events (bc_match_time_dev)"}
+
+        def one(m_, lib_size, d_):
+            c32 = torch.zeros(lib_size, dtype=torch.int32, device=dev)
+            fs = torch.full((lib_size,), -1, dtype=torch.int64, device=dev)
+            m_.synth_reads_dev(2, 0, n, 1, reads.data_ptr(), stream)
+            kw = dict(d_best_dist=bd.data_ptr(), d_n_best=nb.data_ptr(), d_counts=c32.data_ptr(), d_first_seen=fs.data_ptr(), stream=stream)
+            m_.time_dev(reads.data_ptr(), n, bi.data_ptr(), d_, "seed", iters=3, **kw)
+            p_ms = m_.time_dev(reads.data_ptr(), n, bi.data_ptr(), d_, "seed", iters=max(30, steps), **kw)
+            return {"guides": lib_size, "max_mismatch": d_, "kernel": m_.lib.last_kernel, "pass_ms": p_ms, "Mreads_per_s": n / p_ms / 1e3,
+                    "matched_fraction": float((bi >= 0).float().mean().item())}
+
+        res["d3_1e5_guides"] = one(matcher, int(lib_packed.size), 3)
+        big = S.library(500_000, K)
+        res["d2_5e5_guides"] = one(GpuMatcher(DeviceLibrary(big, K, local)), int(big.size), 2)
+        return res
+
     guarded("exact_1e8", exact)
+    guarded("wider", wider)
     guarded("pam_4p6Mbp", pam)
     guarded("host_pcie", host_pcie)
     guarded("from_file", from_file)
