@@ -147,8 +147,8 @@ struct Knobs {
     int pair_group_kb = 3300;  // BC_PAIR_GROUP_KB: pair tables taken together in one pass of the cascade's second stage
                           // (their slabs stay in an XCD's 4 MiB L2); 0: the one-kernel form over all ten tables
     int cascade2_min_g = -1;   // BC_CASCADE2_MIN_G: d = 2 as d <= 1 pass + pair index from that many guides on (0: only where
-                          // the wave matcher cannot serve d = 2; -1, the default: from 19 guides per bucket of its tables
-                          // 0/1 on — 3.11e5 20-mers; measured: 2.43 / 2.47 ms at 3e5, 2.91 / 2.58 at 3.4e5)
+                          // the wave matcher cannot serve d = 2; -1, the default: by the load of its buckets, see
+                          // launch_match — 3.6e5 20-mers, 6.4e4 16-mers, never for 18- / 21- / 24-mers)
     int pair_bucket_pct = 800; // BC_PAIR_BUCKET_PCT: the pair tables' key grows while a bucket would hold more than this many guides / 100
     int pair_four = 1;         // BC_PAIR_FOUR=0: budgets <= 2 walk all ten pair tables instead of the four that cover three clean pieces
     int pair_grid = 16384;     // BC_PAIR_GRID: workgroups of a second-stage pass at most (2 048 = 8 per CU fill the chip; more balance the tail: 226 -> 210 us)

@@ -1999,11 +1999,19 @@ int launch_match(bc_lib* lib, const uint64_t* d_reads, const uint8_t* d_flags, u
     if (algo == BC_ALGO_SEED && max_mm == 2 && lib->knobs.cascade == 1 && lib->knobs.lane && aligned16(o_in.best_idx)) {
         int q01, q2;
         const bool vec_ok = vector_io_ok(d_reads, o_in, n);
-        // default (-1): by the load of the wave matcher's d = 2 buckets, 19 guides in a bucket of tables 0/1 — 3.11e5
-        // 20-mers; a 24-mer's 8-base seeds reach that load at 1.2e6 guides only, and the wave matcher stays (1.94 against 3.12 ms at 5e5)
-        const double load2 = lib->slab_ok[2] ? (double)lib->G / (double)(1ull << (2 * lib->slab[2].t[0].slen)) : 0.0;
+        // default (-1): by the load of the wave matcher's d = 2 buckets (guides per bucket of tables 0 / 1 / 2), weighted by
+        // the share of the benchmark's reads that reach each table: L = load0 + 0.23 load1 + 0.10 load2 >= 36, and only
+        // where table 2's seed is shorter than table 0's (load2 >= 3 load0; with three equal seeds — 18-, 21-, 24-mers —
+        // the wave matcher wins up to its own limit of 40 per bucket).  Measured by PASS time (matcher + tally), wave
+        // matcher / cascade, ms per 1e8 reads (profiles/r04_cascade2_ab_list.txt, r04_cascade2_crossover_k.txt):
+        // 20-mers 2.66 / 2.98 at 3e5 guides, 3.87 / 3.30 at 4e5 (L = 36 at 3.6e5); 16-mers 1.98 / 2.23 at 6e4, 2.53 / 2.22
+        // at 7.5e4 (L = 36 at 6.35e4); 18-mers 1.79 / 2.30 at 1e5, 2.59 / 2.68 at 1.5e5; 24-mers 3.12 / 5.08 at 1e6
+        double ld[3] = {0.0, 0.0, 0.0};
+        if (lib->slab_ok[2])
+            for (int t = 0; t < 3; ++t) ld[t] = (double)lib->G / (double)(1ull << (2 * lib->slab[2].t[t].slen));
+        const bool by_load = ld[2] >= 3.0 * ld[0] && ld[0] + 0.23 * ld[1] + 0.10 * ld[2] >= 36.0;
         const bool big = lib->knobs.cascade2_min_g > 0 ? lib->G >= (uint32_t)lib->knobs.cascade2_min_g
-                                                       : (lib->knobs.cascade2_min_g < 0 && load2 >= 19.0);
+                                                       : (lib->knobs.cascade2_min_g < 0 && by_load);
         if ((big || !wave_kernel_serves(lib, 2, algo, vec_ok, &q01, &q2)) && wave_kernel_serves(lib, 1, algo, vec_ok, &q01, &q2)) {
             int rc = ensure_pair_index(lib);
             if (rc != BC_OK) return rc;

@@ -159,12 +159,12 @@ def test_wave_kernel_geometries_at_scale(gpu_device, oracle, k, G):
     """Default d = 1, 2 path over k-mer lengths and library sizes (different seed / rest widths, bucket loads from
     1 to 16 per slab, neighbour densities from none to dense), 300 k reads each, every per-read output against the
     indexed oracle; counts and first-seen against numpy."""
-    _geometry_case(gpu_device, oracle, k, G, cascade_from=19.0)
+    _geometry_case(gpu_device, oracle, k, G, cascade_from=True)
 
 
 def test_wave_kernel_on_a_large_library_when_the_cascade_is_off(gpu_device, oracle, monkeypatch):
-    """From 19 guides per bucket of the wave matcher's tables 0/1 on (3.11e5 20-mers; a 24-mer's 8-base seeds are far from
-    it at 4e5 guides) d = 2 runs as the cascade by default (d <= 1 pass + four pair tables: faster there);
+    """From a weighted load of the wave matcher's buckets on (3.6e5 20-mers; never for 24-mers with their three equal
+    8-base seeds) d = 2 runs as the cascade by default (d <= 1 pass + four pair tables: faster there);
     BC_CASCADE2_MIN_G=0 keeps the wave matcher on its 128-byte slabs at 37 guides per bucket — the same results."""
     monkeypatch.setenv("BC_CASCADE2_MIN_G", "0")
     _geometry_case(gpu_device, oracle, 20, 600_000, cascade_from=None)
@@ -190,8 +190,11 @@ def _geometry_case(gpu_device, oracle, k, G, cascade_from):
         # the wave matcher serves 64-byte slabs, 128-byte slabs for 20-mer libraries up to 40 guides per bucket and
         # wide entries above k = 28; short k-mers whose d = 2 seeds leave 16+ guides per bucket, and tables 0 / 1 of
         # unequal slab size (k = 16, d = 2), stay on the quad kernels
-        seed = min(k // 3 + (1 if k % 3 else 0), max(4, min(12, int(np.log(max(G // 4, 1)) / np.log(4) + 1e-9))))  # build_seed_index
-        if d == 2 and cascade_from is not None and G / 4.0 ** seed >= cascade_from:
+        # the default's load rule (launch_match): guides per bucket of the wave matcher's three d = 2 tables
+        want = max(4, min(12, int(np.log(max(G // 4, 1)) / np.log(4) + 1e-9)))                      # build_seed_index
+        ld = [G / 4.0 ** min(k // 3 + (1 if t < k % 3 else 0), want) for t in range(3)]
+        by_load = ld[2] >= 3 * ld[0] and ld[0] + 0.23 * ld[1] + 0.10 * ld[2] >= 36.0
+        if d == 2 and cascade_from is not None and by_load:
             assert dl.last_kernel == "cascade2:d1+k_match_pairs", (k, d, dl.last_kernel)
         elif (k, d) not in ((12, 2), (16, 2)):
             assert dl.last_kernel == "k_match_wq", (k, d, dl.last_kernel)
