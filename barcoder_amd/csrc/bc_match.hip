@@ -1589,7 +1589,7 @@ int build_seed_index(bc_lib* lib, int d) {
     sp.nseg = std::min(d + 1, k);
     // seed length: about 4..16 guides per bucket (G=1e5 -> 7 nt).  Longer seeds mean bigger tables;
     // for d=1 (two 10-nt segments) 7-nt seeds measured 2.10 ms per 1e8 reads against 2.40 ms with 8-nt seeds.
-    int want = std::max(4, std::min(12, floor_log4(std::max(lib->G / 4, 1u))));
+    int want = std::max(4, std::min(12, floor_log4(std::max(lib->G / 4, 1u)) + env_int("BC_SEED_WANT_BIAS", 0)));  // (bias: experiments, profiles/seed_want_ab.sh)
     int pos = 0;
     for (int s = 0; s < sp.nseg; ++s) {
         int seg = k / sp.nseg + (s < k % sp.nseg ? 1 : 0);
