@@ -57,7 +57,7 @@ def test_match_parity(gpu_device, oracle, algo, max_mm, k):
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_GROUP_KB": "64"},
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_PAIR_CHUNK_LOG2": "13"},  # (very long inputs: several launches)
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1"}, {"BC_CASCADE2_MIN_G": "1"},
-                                 {"BC_CASCADE2_MIN_G": "1", "BC_PAIR_FOUR": "0"},
+                                 {"BC_CASCADE2_MIN_G": "1", "BC_PAIR_FOUR": "0"}, {"BC_SEED_WANT_BIAS": "1"}, {"BC_SEED_WANT_BIAS": "-1"},
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1", "BC_PAIR_BUCKET_PCT": "50"},
                                  {"BC_PAIR_PASS_MIN_READS": "0", "BC_CASCADE2_MIN_G": "1", "BC_PAIR_BUCKET_PCT": "6400"}])
 def test_tuning_knobs_do_not_change_results(gpu_device, oracle, env, monkeypatch):
