@@ -317,6 +317,11 @@ const char *bc_lib_last_kernel(const bc_lib *lib);
  * prefix sum on the device, k_cascade_pack, then k_cascade_pass over groups of
  * tables); smaller ones find them in d_best_idx (k_cascade_stage2).  Either way
  * the count of missed reads stays on the device: nothing the host waits for.
+ * max_mismatch = 2 runs the same way — the <= 1-mismatch pass, then the pair index,
+ * for this budget only the four of its ten tables that cover three clean pieces —
+ * on libraries whose three seed tables are too crowded for k_match_wq to be the
+ * faster choice (from about 3.6e5 20-mers or 6.4e4 16-mers on; bc_lib_last_kernel
+ * then reports "cascade2:d1+k_match_pairs"; BC_CASCADE2_MIN_G overrides).
  * (The first launch with a tally or a cascade on a stream, or one larger than
  * every earlier launch on it, allocates that stream's workspace — records, and
  * for the list form 32 bytes per read — and waits for the stream once;
